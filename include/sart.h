@@ -1,0 +1,315 @@
+/*
+ * sart.h — C-ABI of the MI355X-native solar-axion ray tracer ("sart").
+ *
+ * This is the drop-in boundary for ONE hot path of jovoy/SolarAxionRayTracing:
+ * the per-ray loop `traceAxionWrapper` -> `traceAxion`
+ * (reference src/raytracer.nim:2223-2244 and :1736-2221) plus the accumulation
+ * that follows it (`prepareHeatmap` :818-842, flux sum :2800).
+ *
+ * Plain C: extern "C", PODs, pointers and sizes only.  Every entry point
+ * returns 0 on success and a negative sart_status on error; the message of the
+ * last error on the calling thread is available from sart_last_error().
+ * A context is bound to one GPU; it is not thread-safe; distinct contexts are
+ * independent.  All calls are blocking unless stated otherwise.
+ *
+ * All floating point is IEEE f64, as in the reference.  Lengths are mm, angles
+ * degrees unless the field name says otherwise, energies keV.
+ */
+#ifndef SART_H
+#define SART_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SART_ABI_VERSION 1
+#define SART_MAX_SHELLS 64
+#define SART_MAX_COATINGS 8
+
+typedef enum sart_status {
+  SART_OK = 0,
+  SART_ERR_INVALID_ARGUMENT = -1,
+  SART_ERR_NO_DEVICE = -2,      /* no HIP device / HIP runtime error             */
+  SART_ERR_NOT_READY = -3,      /* setup or tables missing                       */
+  SART_ERR_UNSUPPORTED = -4,    /* e.g. telescope kind the reference asserts on  */
+  SART_ERR_OUT_OF_MEMORY = -5,
+  SART_ERR_INTERNAL = -6
+} sart_status;
+
+/* ---- enums: numeric values follow the declaration order of the reference ---- */
+
+/* ExperimentSetupKind, raytracer.nim:16-18 */
+enum { SART_ES_CAST = 0, SART_ES_BABYIAXO = 1 };
+/* StageKind, raytracer.nim:39-41 */
+enum { SART_SK_VACUUM = 0, SART_SK_GAS = 1 };
+/* TelescopeKind, raytracer.nim:31-37 */
+enum { SART_TK_LLNL = 0, SART_TK_XMM = 1, SART_TK_CUSTOM_BABYIAXO = 2,
+       SART_TK_ABRIXAS = 3, SART_TK_OTHER = 4 };
+/* DetectorSetupKind, raytracer.nim:164-167 */
+enum { SART_DK_INGRID2017 = 0, SART_DK_INGRID2018 = 1, SART_DK_INGRIDIAXO = 2 };
+/* HoleType, raytracer.nim:23-29 */
+enum { SART_HT_NONE = 0, SART_HT_CROSS = 1, SART_HT_STAR = 2, SART_HT_CIRCLE = 3,
+       SART_HT_SQUARE = 4, SART_HT_DIAMOND = 5 };
+/* ReflectivityKind, raytracer.nim:59-64 */
+enum { SART_RK_EFFECTIVE_AREA = 0, SART_RK_SINGLE_COATING = 1, SART_RK_MULTI_COATING = 2 };
+/* MaterialKind, raytracer.nim:186-189 */
+enum { SART_MK_SI3N4 = 0, SART_MK_SI = 1, SART_MK_AR = 2 };
+
+/* ConfigFlags, raytracer.nim:223-230: bit i <=> i-th enum value (a Nim set[ConfigFlags]) */
+enum {
+  SART_CF_IGNORE_DET_WINDOW = 1u << 0,
+  SART_CF_IGNORE_GAS_ABS = 1u << 1,
+  SART_CF_IGNORE_REFLECTION = 1u << 2,
+  SART_CF_IGNORE_CONV_PROB = 1u << 3,
+  SART_CF_XRAY_TEST = 1u << 4,
+  SART_CF_READ_MAGNET_CONFIG = 1u << 5,
+  SART_CF_READ_DET_INSTALL_CONFIG = 1u << 6
+};
+
+/*
+ * sart_setup_t — everything `traceAxion` reads from `ExperimentSetup`,
+ * `DetectorSetup`, `CenterVectors` and the module-level constants, flattened.
+ * Replaces: ExperimentSetup raytracer.nim:155-162 (Magnet :83-89, Telescope
+ * :91-105, TestXraySource :108-122, Pipes :131-140, DetectorInstallation
+ * :146-153), DetectorSetup :170-184 and the `let` constants :248-272.
+ * The centre vectors of :278-320 are functions of these fields and are derived
+ * by the callee.
+ */
+typedef struct sart_setup_t {
+  int32_t experiment;      /* SART_ES_*   */
+  int32_t stage;           /* SART_SK_*   */
+  int32_t telescope_kind;  /* SART_TK_*   */
+  int32_t detector_kind;   /* SART_DK_*   (informational; theta etc. below are what is used) */
+
+  /* Magnet, raytracer.nim:83-89 */
+  double magnet_B;              /* T   */
+  double magnet_lengthB;        /* mm  */
+  double magnet_lengthColdbore; /* mm  */
+  double magnet_radiusCB;       /* mm  */
+  double magnet_pGasRoom;       /* bar */
+  double magnet_tGas;           /* K   */
+
+  /* Pipes, raytracer.nim:125-140 */
+  double pipe_cb_vt3_length, pipe_cb_vt3_radius;
+  double pipe_vt3_xrt_length, pipe_vt3_xrt_radius;
+  double pipes_turned_deg;
+  double distance_cb_axis_xrt_axis;
+
+  /* Telescope, raytracer.nim:91-105 */
+  double optics_entrance[3];
+  double optics_exit[3];
+  double telescope_turned_x_deg;
+  double telescope_turned_y_deg;
+  int32_t n_shells;
+  int32_t hole_type;        /* SART_HT_* */
+  int32_t number_of_holes;
+  int32_t reflectivity_kind; /* SART_RK_* */
+  double all_r1[SART_MAX_SHELLS];
+  double all_thickness[SART_MAX_SHELLS];
+  double all_xsep[SART_MAX_SHELLS];
+  double all_angles_deg[SART_MAX_SHELLS];
+  double l_mirror;
+  double hole_in_optics;
+  /* Reflectivity.layers, raytracer.nim:78-81, :1167 ("boundary layers") */
+  int32_t n_coatings;
+  int32_t coating_layers[SART_MAX_COATINGS];
+
+  /* DetectorInstallation, raytracer.nim:146-153 */
+  double distance_detector_xrt;
+  double distance_window_focal_plane;
+  double lateral_shift;
+  double transversal_shift;
+
+  /* DetectorSetup, raytracer.nim:170-184 */
+  double radius_window;
+  int32_t number_of_strips;
+  int32_t _pad0;
+  double open_aperture_ratio;
+  double strip_dist_window;
+  double strip_width_window;
+  double theta_rad;
+  double depth_det;
+
+  /* TestXraySource, raytracer.nim:108-122 */
+  int32_t test_active;
+  int32_t test_parallel;
+  double test_energy;       /* keV */
+  double test_distance;
+  double test_radius;
+  double test_off_axis_up;
+  double test_off_axis_left;
+  double test_activity;     /* GBq */
+  double test_length_col;
+
+  /* module constants, raytracer.nim:248-272 — runtime parameters here */
+  double distance_sun_earth; /* 1.5e14 mm  */
+  double radius_sun;         /* 6.9e11 mm  */
+  double room_temp;          /* 293.15 K   */
+  double m_axion;            /* eV         */
+  double g_agamma;           /* GeV^-1     */
+  double chip_x_max;         /* 14 mm (ChipXMax; ChipCenterX = chip_x_max/2) */
+  double chip_y_max;
+} sart_setup_t;
+
+/*
+ * sart_axion_t — binary image of the reference's `Axion` object
+ * (raytracer.nim:192-221; a Nim object is a C struct in declaration order):
+ * 3 bools, 23 f64, 2 one-byte enums, 1 int => 208 bytes.
+ */
+typedef struct sart_axion_t {
+  uint8_t passed;
+  uint8_t passedTillWindow;
+  uint8_t hitNickel;
+  uint8_t _pad0[5];
+  double pointdataX;
+  double pointdataY;
+  double pointdataXBefore;
+  double pointdataYBefore;
+  double pointdataR;
+  double weights;
+  double weightsAll;
+  double transmissionMagnet;
+  double yawAngles;
+  double pixvalsX;
+  double pixvalsY;
+  double radii;
+  double energiesAx;
+  double energiesAxAll;
+  double energiesAxWindow;
+  uint8_t kinds;
+  uint8_t kindsWindow;
+  uint8_t _pad1[6];
+  double transProbWindow;
+  double transProbArgon;
+  double transProbDetector;
+  double transProbMagnet;
+  double deviationDet;
+  int64_t shellNumber;
+  double energiesPre;
+  double emratesPre;
+  double reflect;
+} sart_axion_t;
+
+/* Parameters of one trace call. */
+typedef struct sart_trace_params_t {
+  uint64_t n_rays;         /* bufLen of traceAxionWrapper                               */
+  uint64_t seed;           /* Philox4x32-10 key (replaces randomize(299792458), :276)    */
+  uint64_t ray_id_offset;  /* global id of ray 0 of this call: counter = offset + i      */
+  uint32_t flags;          /* SART_CF_* bitset                                          */
+  int32_t image_nx;        /* columns (x bins) of the focal-plane image, 256 in :2629    */
+  int32_t image_ny;        /* rows    (y bins)                                          */
+  int32_t accumulate;      /* histogram mode: 0 = zero the accumulator first, 1 = add    */
+  double image_x_min, image_x_max;  /* 0 .. ChipXMax in :2622-2625 */
+  double image_y_min, image_y_max;
+} sart_trace_params_t;
+
+/*
+ * Layout of the fused f64 accumulator a histogram trace adds into
+ * (one buffer so that a multi-GPU reduce is a single RCCL call):
+ *   [0, nx*ny)                     image, row-major img[y][x]  (prepareHeatmap :838-842, norm = 1)
+ *   [nx*ny + SART_ACC_*]           scalars below
+ */
+enum {
+  SART_ACC_SUM_WEIGHTS = 0,   /* sum of weights over passed rays (:2800)                 */
+  SART_ACC_N_PASSED = 1,      /* axions.filterIt(it.passed).len (:2252)                  */
+  SART_ACC_N_PASSED_TILL_WINDOW = 2, /* :2254 */
+  SART_ACC_N_HIT_NICKEL = 3,  /* :2256 */
+  SART_ACC_SUM_X = 4,         /* sums of pointdataX/Y/R over passed rays (means :2276-2278) */
+  SART_ACC_SUM_Y = 5,
+  SART_ACC_SUM_R = 6,
+  SART_ACC_SUM_WEIGHTS_SQ = 7, /* for the Monte-Carlo error of the flux                   */
+  SART_ACC_N_RAYS = 8,        /* rays traced into this accumulator                        */
+  SART_ACC_N_REACHED_TELESCOPE = 9, /* survived bore + pipes (:1813-1868)                 */
+  SART_ACC_N_SHELL_SELECTED = 10,   /* survived opaque structures + shell selection (:1910-1957) */
+  SART_ACC_N_OUTSIDE_IMAGE = 11,    /* passed rays whose (x,y) fall outside the image range */
+  SART_ACC_COUNT = 16
+};
+
+static inline size_t sart_accumulator_len(int32_t nx, int32_t ny) {
+  return (size_t)nx * (size_t)ny + (size_t)SART_ACC_COUNT;
+}
+
+/* Host-side view of the scalar tail. */
+typedef struct sart_summary_t {
+  double v[SART_ACC_COUNT];
+} sart_summary_t;
+
+typedef struct sart_context sart_context;
+
+/* ---- lifecycle --------------------------------------------------------- */
+int sart_abi_version(void);
+const char* sart_last_error(void);
+/* device_ordinal: HIP device index of this process. Fails with SART_ERR_NO_DEVICE without a GPU. */
+int sart_create(int device_ordinal, sart_context** out);
+int sart_destroy(sart_context* ctx);
+/* Use an existing HIP stream (hipStream_t cast to void*) for all launches; NULL = the context's own stream. */
+int sart_set_stream(sart_context* ctx, void* hip_stream);
+int sart_synchronize(sart_context* ctx);
+
+/* ---- inputs (the captures of traceAxionWrapper, raytracer.nim:2223-2232) -- */
+/* expSetup + detectorSetup + centerVecs. The library copies; caller keeps ownership. */
+int sart_set_setup(sart_context* ctx, const sart_setup_t* setup);
+int sart_get_setup(sart_context* ctx, sart_setup_t* out);
+/* Cheap updates used by the scan drivers (performAngularScan :2796; m_a scan). */
+/* A NaN leaves the corresponding angle unchanged. */
+int sart_set_telescope_angles(sart_context* ctx, double turned_x_deg, double turned_y_deg);
+int sart_set_axion_mass(sart_context* ctx, double m_axion_ev);
+/* fluxRadiusCDF[nR], diffFluxCDFs[nR][nE] row-major, energies[nE] (FullRaytraceSetup :237-241). */
+int sart_set_solar_tables(sart_context* ctx, const double* flux_radius_cdf,
+                          const double* diff_flux_cdfs, const double* energies_kev,
+                          int32_t n_radii, int32_t n_energies);
+/* Reflectivity grids as read by initReflectivity (:1160-1231): data[coating][angle][energy],
+ * uniform grid defined by (min,max) of the axes (newBilinearSpline :1181/:1204/:1226). */
+int sart_set_reflectivity(sart_context* ctx, int32_t n_coatings, int32_t n_angles,
+                          int32_t n_energies, double angle_min_deg, double angle_max_deg,
+                          double energy_min_kev, double energy_max_kev, const double* data);
+/* The three newLinear1D tables of newDetectorSetup (:1522-1527): x in keV ascending. */
+int sart_set_detector_tables(sart_context* ctx,
+                             const double* strongback_x, const double* strongback_y, int32_t n_strongback,
+                             const double* window_x, const double* window_y, int32_t n_window,
+                             const double* gas_abs_x, const double* gas_abs_y, int32_t n_gas_abs);
+
+/* ---- the hot path ------------------------------------------------------- */
+/*
+ * Literal drop-in for traceAxionWrapper (:2223-2244): traces params->n_rays rays and writes
+ * one Axion record per ray to `ax_buf` (HOST memory, caller-allocated, n_rays * 208 bytes).
+ * Every field of every record is written (the reference relies on zero-initialised seqs).
+ */
+int sart_trace_records(sart_context* ctx, const sart_trace_params_t* params, sart_axion_t* ax_buf);
+/* Same, but `ax_buf_device` is DEVICE memory and the call only enqueues on the stream. */
+int sart_trace_records_device(sart_context* ctx, const sart_trace_params_t* params,
+                              sart_axion_t* ax_buf_device);
+
+/*
+ * Fused trace + accumulation: traceAxionWrapper + prepareHeatmap(256,256,...,norm=1) (:2629)
+ * + flux sum (:2800) + the counters echoed at :2253-2257, without materialising records.
+ * `accumulator_device` is DEVICE memory of sart_accumulator_len(nx,ny) doubles; the call is
+ * asynchronous on the context's stream (pair with sart_synchronize).
+ */
+int sart_trace_histogram_device(sart_context* ctx, const sart_trace_params_t* params,
+                                double* accumulator_device);
+/* Blocking convenience form with HOST outputs (image may be NULL, summary may be NULL). */
+int sart_trace_histogram(sart_context* ctx, const sart_trace_params_t* params,
+                         double* image_out_host, sart_summary_t* summary_out);
+
+/* ---- measurement -------------------------------------------------------- */
+/*
+ * HIP-event timing of the hot-path kernels on the stream they are launched on.
+ * enable != 0: every subsequent sart_trace_*_device launch is bracketed by events.
+ * sart_get_kernel_timing synchronises the stream, returns the sum of kernel durations and
+ * the number of launches since the last reset, and resets.
+ */
+int sart_enable_kernel_timing(sart_context* ctx, int enable);
+int sart_get_kernel_timing(sart_context* ctx, double* total_ms, int64_t* n_launches);
+
+/* Device properties the bench reports (CU count etc.). Any pointer may be NULL. */
+int sart_device_info(sart_context* ctx, int32_t* n_cu, int32_t* wave_size,
+                     char* name_buf, size_t name_buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SART_H */

@@ -1,0 +1,78 @@
+/*
+ * sart_host.h — C bindings of the host-side mirror of the reference's setup / driver layer
+ * for the per-ray hot path (libsart_host.so, C++ above the sart.h C-ABI).
+ *
+ * The reference's host is Nim; no Nim toolchain exists in the build image, so the host
+ * layer that sits directly above the hot path is written in C++ with the reference's
+ * names, argument meaning and error behaviour.  Nothing here touches the GPU except the
+ * two drivers at the bottom, which only call the sart.h entry points.
+ */
+#ifndef SART_HOST_H
+#define SART_HOST_H
+
+#include "sart.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Optional `[Magnet]`, `[TestXraySource]`, `[DetectorInstallation]` blocks of config.toml
+ * (config/config_default.toml:24-50; parsers raytracer.nim:1032-1096).  A NULL pointer means
+ * "useConfig = false and the corresponding flag not given". */
+typedef struct sart_magnet_config_t {
+  double B, radiusCB, lengthColdbore, lengthB, pGasRoom, tGas;
+} sart_magnet_config_t;
+typedef struct sart_test_source_config_t {
+  int32_t active, parallel;
+  double energy, distance, radius, offAxisUp, offAxisLeft, activity, lengthCol;
+} sart_test_source_config_t;
+typedef struct sart_detector_install_config_t {
+  double distanceDetectorXRT, distanceWindowFocalPlane, lateralShift, transversalShift;
+} sart_detector_install_config_t;
+
+const char* sart_host_last_error(void);
+
+/* newExperimentSetup (raytracer.nim:1411-1423) = initMagnet :1098 + initTelescope :1251 +
+ * initTestXraySource :1350 + initPipes :1125 + initDetectorInstallation :1381, followed by
+ * newDetectorSetup (:1464-1528, without the file reads) and the module constants :248-272.
+ * Fails (like the reference's doAssert) for tkCustomBabyIAXO / tkOther. */
+int sart_host_new_full_setup(int32_t experiment, int32_t detector, int32_t stage, int32_t telescope,
+                             uint32_t flags, const sart_magnet_config_t* magnet_cfg,
+                             const sart_test_source_config_t* source_cfg,
+                             const sart_detector_install_config_t* install_cfg, sart_setup_t* out);
+
+/* calcWindowVals, raytracer.nim:1431-1462 */
+int sart_host_calc_window_vals(double radius_window, int32_t number_of_strips,
+                               double open_aperture_ratio, double* width, double* dist);
+
+/* The CDF construction of initFullSetup (raytracer.nim:2670-2705):
+ * diffFlux[r][e] = emRate[r][e] * E^2 * r^2; per-radius cumulative sum / last; radius cumulative / last. */
+int sart_host_build_cdfs(const double* em_rates, const double* radii, const double* energies_kev,
+                         int32_t n_radii, int32_t n_energies, double* flux_radius_cdf_out,
+                         double* diff_flux_cdfs_out);
+
+/* The three 1-D tables of newDetectorSetup (:1509-1527) from the raw TSV columns:
+ * strongback = T_Si * T_Al, window = T_Si3N4 * T_Al, gas absorption = 1 - T_Ar; x = eV / 1000. */
+int sart_host_detector_tables(const double* energy_ev, const double* t_si3n4, const double* t_si,
+                              const double* t_al, int32_t n, const double* argon_energy_ev,
+                              const double* t_argon, int32_t n_argon, double* x_kev_out,
+                              double* strongback_out, double* window_out, double* argon_x_kev_out,
+                              double* gas_abs_out);
+
+/* traceAxionWrapper, raytracer.nim:2223-2244: identical to sart_trace_records (kept so that
+ * host code reads like the reference). */
+int sart_host_trace_axion_wrapper(sart_context* ctx, sart_axion_t* ax_buf, int64_t buf_len,
+                                  uint64_t seed, uint64_t ray_id_offset, uint32_t flags);
+
+/* performAngularScan, raytracer.nim:2778-2802: for each angle set telescope_turned_y, trace
+ * n_rays_per_angle rays and sum the weights of the passed rays; fluxes_out[i] holds the raw sums,
+ * rel_fluxes_out[i] the max-normalised curve (:2801-2802).  Angle i uses ray ids
+ * [ray_id_offset + i*n_rays_per_angle, ...). */
+int sart_host_perform_angular_scan(sart_context* ctx, const double* angles_deg, int32_t n_angles,
+                                   uint64_t n_rays_per_angle, uint64_t seed, uint64_t ray_id_offset,
+                                   uint32_t flags, double* fluxes_out, double* rel_fluxes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

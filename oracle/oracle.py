@@ -1,0 +1,132 @@
+"""ctypes wrapper of the CPU oracle (oracle/libsart_oracle.so).  TEST INFRASTRUCTURE: only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from solaraxionraytracing_amd import _lib
+from solaraxionraytracing_amd._lib import AXION_DTYPE, Setup, TraceParams
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_d, _i, _dp = C.c_double, C.c_int32, C.POINTER(C.c_double)
+
+
+class OracleTables(C.Structure):
+    """sart_oracle_tables_t"""
+    _fields_ = [
+        ("flux_radius_cdf", _dp), ("diff_flux_cdfs", _dp), ("energies_kev", _dp), ("n_radii", _i), ("n_energies", _i),
+        ("refl_data", _dp), ("refl_n_coatings", _i), ("refl_n_angles", _i), ("refl_n_energies", _i), ("_pad", _i),
+        ("refl_angle_min", _d), ("refl_angle_max", _d), ("refl_energy_min", _d), ("refl_energy_max", _d),
+        ("strongback_x", _dp), ("strongback_y", _dp), ("n_strongback", _i), ("_pad1", _i),
+        ("window_x", _dp), ("window_y", _dp), ("n_window", _i), ("_pad2", _i),
+        ("gas_abs_x", _dp), ("gas_abs_y", _dp), ("n_gas_abs", _i), ("_pad3", _i),
+    ]
+
+
+def build(variant: str = "f64") -> str:
+    """Compiles the oracle with gcc if needed; returns the library path."""
+    target = {"f64": "libsart_oracle.so", "ld": "libsart_oracle_ld.so"}[variant]
+    subprocess.run(["make", "-s", "-C", _DIR, target], check=True)
+    return os.path.join(_DIR, target)
+
+
+_libs = {}
+
+
+def load(variant: str = "f64") -> C.CDLL:
+    if variant not in _libs:
+        path = os.path.join(_DIR, {"f64": "libsart_oracle.so", "ld": "libsart_oracle_ld.so"}[variant])
+        if not os.path.exists(path):
+            build(variant)
+        lib = C.CDLL(path)
+        vp = C.c_void_p
+        lib.sart_oracle_uniforms.argtypes = [C.c_uint64, C.c_uint64, _dp]
+        lib.sart_oracle_uniforms.restype = None
+        lib.sart_oracle_trace_records.argtypes = [C.POINTER(Setup), C.POINTER(OracleTables), C.POINTER(TraceParams), vp, C.c_int]
+        lib.sart_oracle_trace_records.restype = C.c_int
+        lib.sart_oracle_trace_histogram.argtypes = [C.POINTER(Setup), C.POINTER(OracleTables), C.POINTER(TraceParams), _dp, C.c_int]
+        lib.sart_oracle_trace_histogram.restype = C.c_int
+        lib.sart_oracle_conversion_prob.argtypes = [_d, _d, _d]
+        lib.sart_oracle_conversion_prob.restype = _d
+        lib.sart_oracle_eff_photon_mass2.argtypes = [_d] * 4
+        lib.sart_oracle_eff_photon_mass2.restype = _d
+        lib.sart_oracle_axion_conversion_prob2.argtypes = [_d] * 8
+        lib.sart_oracle_axion_conversion_prob2.restype = _d
+        lib.sart_oracle_intensity_suppression2.argtypes = [_d] * 6
+        lib.sart_oracle_intensity_suppression2.restype = _d
+        lib.sart_oracle_bilinear.argtypes = [_dp, _i, _i, _d, _d, _d, _d, _d, _d]
+        lib.sart_oracle_bilinear.restype = _d
+        lib.sart_oracle_linear1d.argtypes = [_dp, _dp, _i, _d]
+        lib.sart_oracle_linear1d.restype = _d
+        lib.sart_oracle_lower_bound.argtypes = [_dp, C.c_int64, _d]
+        lib.sart_oracle_lower_bound.restype = C.c_int64
+        lib.sart_oracle_almost_equal.argtypes = [_d, _d]
+        lib.sart_oracle_almost_equal.restype = C.c_int
+        lib.sart_oracle_find_pos.argtypes = [C.c_int, _dp, _dp, _d, _d, _d, _d, _d, _dp]
+        lib.sart_oracle_find_pos.restype = None
+        lib.sart_oracle_vector_after_mirror.argtypes = [_dp, _dp, _dp, _d, _d, _d, _d, C.c_int, _dp]
+        lib.sart_oracle_vector_after_mirror.restype = None
+        lib.sart_oracle_mirror_angle_deg.argtypes = [_dp, _dp, _dp, _d, _d, _d, _d, C.c_int]
+        lib.sart_oracle_mirror_angle_deg.restype = _d
+        lib.sart_oracle_length_telescope.argtypes = [C.POINTER(Setup)]
+        lib.sart_oracle_length_telescope.restype = _d
+        _libs[variant] = lib
+    return _libs[variant]
+
+
+class Oracle:
+    """The oracle bound to one FullRaytraceSetup (same inputs the HIP path gets)."""
+
+    def __init__(self, full, variant: str = "f64"):
+        self.lib = load(variant)
+        self.full = full
+        t = OracleTables()
+        self._keep = []
+
+        def dp(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            self._keep.append(a)
+            return a.ctypes.data_as(_dp)
+
+        t.flux_radius_cdf, t.diff_flux_cdfs, t.energies_kev = dp(full.fluxRadiusCDF), dp(full.diffFluxCDFs), dp(full.energies)
+        t.n_radii, t.n_energies = full.diffFluxCDFs.shape
+        r = full.reflectivity
+        t.refl_data = dp(r.data)
+        t.refl_n_coatings, t.refl_n_angles, t.refl_n_energies = r.data.shape
+        t.refl_angle_min, t.refl_angle_max, t.refl_energy_min, t.refl_energy_max = r.angle_min, r.angle_max, r.energy_min, r.energy_max
+        d = full.detector_tables
+        t.strongback_x, t.strongback_y, t.n_strongback = dp(d.x_kev), dp(d.strongback), d.x_kev.size
+        t.window_x, t.window_y, t.n_window = dp(d.x_kev), dp(d.window), d.x_kev.size
+        t.gas_abs_x, t.gas_abs_y, t.n_gas_abs = dp(d.gas_x_kev), dp(d.gas_absorption), d.gas_x_kev.size
+        self.tables = t
+
+    def params(self, n_rays, seed=299792458, ray_id_offset=0, flags=None, image_n=256, accumulate=False) -> TraceParams:
+        s = self.full.setup
+        p = TraceParams()
+        p.n_rays, p.seed, p.ray_id_offset = int(n_rays), int(seed), int(ray_id_offset)
+        p.flags = self.full.flags if flags is None else flags
+        p.image_nx = p.image_ny = image_n
+        p.accumulate = 1 if accumulate else 0
+        p.image_x_min, p.image_x_max = 0.0, s.chip_x_max
+        p.image_y_min, p.image_y_max = 0.0, s.chip_y_max
+        return p
+
+    def trace_records(self, n_rays, seed=299792458, ray_id_offset=0, flags=None, n_threads=0, setup=None) -> np.ndarray:
+        buf = np.zeros(n_rays, dtype=AXION_DTYPE)
+        p = self.params(n_rays, seed, ray_id_offset, flags)
+        s = setup if setup is not None else self.full.setup
+        self.lib.sart_oracle_trace_records(C.byref(s), C.byref(self.tables), C.byref(p), buf.ctypes.data_as(C.c_void_p), n_threads)
+        return buf
+
+    def trace_histogram(self, n_rays, seed=299792458, ray_id_offset=0, flags=None, image_n=256, n_threads=0, setup=None):
+        p = self.params(n_rays, seed, ray_id_offset, flags, image_n)
+        acc = np.zeros(image_n * image_n + _lib.SART_ACC_COUNT)
+        s = setup if setup is not None else self.full.setup
+        used = self.lib.sart_oracle_trace_histogram(C.byref(s), C.byref(self.tables), C.byref(p), acc.ctypes.data_as(_dp), n_threads)
+        img = acc[:image_n * image_n].reshape(image_n, image_n).copy()
+        summ = {k: acc[image_n * image_n + i] for k, i in _lib.ACC.items()}
+        return img, summ, used

@@ -1,0 +1,688 @@
+// sart_api.hip — implementation of the sart.h C-ABI: context, table upload, hoisting of
+// per-setup / per-shell / per-energy-index constants, kernel launches, timing.
+//
+// There is NO CPU fallback in this library: without a HIP device sart_create() fails with
+// SART_ERR_NO_DEVICE, and nothing here links or loads oracle/.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sart.h"
+#include "sart_device.h"
+
+namespace sart {
+void launch_trace_histogram(const DevTables& T, const TraceArgs& A, double* acc, int n_blocks, hipStream_t stream);
+void launch_trace_records(const DevTables& T, const TraceArgs& A, sart_axion_t* out, int n_blocks, hipStream_t stream);
+int trace_block_size();
+}  // namespace sart
+
+using namespace sart;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define SART_HIP(call)                                                                              \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return fail(e_ == hipErrorOutOfMemory ? SART_ERR_OUT_OF_MEMORY : SART_ERR_NO_DEVICE,          \
+                  std::string(#call) + ": " + hipGetErrorString(e_));                               \
+  } while (0)
+
+constexpr double kPi = 3.14159265358979323846;
+inline double deg2rad(double d) { return d * (kPi / 180.0); }  // Nim std/math degToRad
+inline double cot(double x) { return 1.0 / std::tan(x); }
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int upload(const T* host, size_t count) {
+    if (count != n || !p) {
+      if (p) (void)hipFree(p);
+      p = nullptr; n = 0;
+      SART_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+      n = count;
+    }
+    SART_HIP(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+  }
+  int resize(size_t count) {
+    if (count == n && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+    SART_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    n = count;
+    return 0;
+  }
+};
+
+// numericalnim newLinear1D.eval (reference call sites raytracer.nim:1522-1527, 2170-2190)
+double linear1d(const std::vector<double>& xs, const std::vector<double>& ys, double x) {
+  size_t lo = 0, hi = xs.size() - 1;
+  while (hi - lo > 1) {
+    const size_t mid = (lo + hi) / 2;
+    if (xs[mid] <= x) lo = mid; else hi = mid;
+  }
+  return ys[lo] + (x - xs[lo]) * (ys[lo + 1] - ys[lo]) / (xs[lo + 1] - xs[lo]);
+}
+
+size_t lower_bound_idx(const double* a, size_t n, double key) {
+  return static_cast<size_t>(std::lower_bound(a, a + n, key) - a);
+}
+
+}  // namespace
+
+struct sart_context {
+  int device = 0;
+  int n_cu = 0;
+  int blocks_per_cu_hist = 0, blocks_per_cu_rec = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string device_name;
+
+  // host copies of the inputs
+  bool have_setup = false, have_solar = false, have_refl = false, have_det = false;
+  sart_setup_t setup;
+  std::vector<double> energies;   // [nE]
+  int n_radii = 0, n_energies = 0;
+  std::vector<double> refl_data;  // [nC][nA][nEr]
+  int refl_nc = 0, refl_na = 0, refl_ne = 0;
+  double refl_amin = 0, refl_amax = 0, refl_emin = 0, refl_emax = 0;
+  std::vector<double> sb_x, sb_y, win_x, win_y, gas_x, gas_y;
+
+  // device state
+  DevParams params;  // host mirror
+  DevBuf<DevParams> d_params;
+  DevBuf<double> d_rcdf, d_ecdf, d_refl;
+  DevBuf<uint16_t> d_rguide, d_eguide;
+  DevBuf<EnergyDev> d_etab;
+  DevBuf<double> d_acc;        // scratch accumulator of the blocking convenience call
+  DevBuf<sart_axion_t> d_rec;  // scratch records of the blocking convenience call
+  bool derived_dirty = true;
+
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  size_t events_used = 0;
+};
+
+namespace {
+
+// ---- hoisting: sart_setup_t -> DevParams (geometry part) -------------------------------------
+int hoist_setup(sart_context* c) {
+  const sart_setup_t& s = c->setup;
+  DevParams& P = c->params;
+  std::memset(&P, 0, sizeof P);
+  P.sun_distance = s.distance_sun_earth;
+  P.sun_radius = s.radius_sun;
+  P.radius_cb = s.magnet_radiusCB;
+  P.radius_cb_sq = s.magnet_radiusCB * s.magnet_radiusCB;
+  P.length_b = s.magnet_lengthB;
+  P.length_coldbore = s.magnet_lengthColdbore;
+  P.pipe1_len = s.pipe_cb_vt3_length;
+  P.pipe2_len = s.pipe_vt3_xrt_length;
+  P.pipe1_radius_sq = s.pipe_cb_vt3_radius * s.pipe_cb_vt3_radius;
+  P.n_radii = c->n_radii;
+  P.n_energies = c->n_energies;
+  // X-ray test source, initCenterVectors raytracer.nim:305-311
+  P.test_active = s.test_active;
+  P.test_parallel = s.test_parallel;
+  P.test_x = s.test_off_axis_left;
+  P.test_y = s.test_off_axis_up;
+  P.test_z = -s.test_distance;
+  P.test_radius = s.test_radius;
+  P.test_radius_sq = s.test_radius * s.test_radius;
+  P.test_collimator_z = -s.test_distance + s.test_length_col;
+  // telescope frame, :1878-1899
+  P.telescope_kind = s.telescope_kind;
+  P.telescope_wolter = (s.telescope_kind == SART_TK_XMM || s.telescope_kind == SART_TK_ABRIXAS) ? 1 : 0;
+  P.n_shells = s.n_shells;
+  P.l_mirror = s.l_mirror;
+  const double turnedX = deg2rad(s.telescope_turned_x_deg), turnedY = deg2rad(s.telescope_turned_y_deg);
+  P.rotated = (s.telescope_turned_x_deg != 0.0 || s.telescope_turned_y_deg != 0.0) ? 1 : 0;
+  P.rx_c = std::cos(turnedX); P.rx_s = std::sin(turnedX);
+  P.ry_c = std::cos(turnedY); P.ry_s = std::sin(turnedY);
+  {
+    const double a0 = deg2rad(s.all_angles_deg[0]);  // lengthTelescope :1883-1884
+    const double lt = (s.l_mirror + 0.5 * s.all_xsep[0]) * std::cos(a0) + (s.l_mirror + 0.5 * s.all_xsep[0]) * std::cos(3.0 * a0);
+    P.half_length_telescope = lt / 2;
+  }
+  P.entrance_x = s.optics_entrance[0];
+  P.entrance_y = s.optics_entrance[1];
+  // opaque structures, :1635-1704
+  double spoke_step = 0.0, spoke_half = 0.0;
+  int spoke_count = 0;
+  if (s.telescope_kind == SART_TK_XMM) {
+    P.spider_z = -85.0; P.inner_radius = 64.7; P.ring_lo = 151.6 - 20.9; P.ring_hi = 151.6;
+    spoke_step = 22.5; spoke_half = 1.145; spoke_count = 17;
+  } else if (s.telescope_kind == SART_TK_ABRIXAS) {
+    P.spider_z = -35.0; P.inner_radius = 37.5; P.ring_lo = 0.0; P.ring_hi = 0.0;
+    spoke_step = 60.0; spoke_half = 3.75; spoke_count = 7;
+  }
+  P.n_spokes = 0;
+  for (int i = 0; i < spoke_count; ++i) {
+    const double lo = -spoke_half + spoke_step * i, hi = spoke_half + spoke_step * i;
+    if (lo > 180.0) break;  // phi = acos(..) never exceeds 180 deg
+    if (P.n_spokes >= 12) return fail(SART_ERR_INTERNAL, "too many spider spokes");
+    P.spoke_cos_hi[P.n_spokes] = (lo <= 0.0) ? 2.0 : std::cos(deg2rad(lo));
+    P.spoke_cos_lo[P.n_spokes] = (hi >= 180.0) ? -2.0 : std::cos(deg2rad(hi));
+    P.n_spokes++;
+  }
+  P.hole_type = s.hole_type;
+  P.number_of_holes = s.number_of_holes;
+  P.hole_in_optics = s.hole_in_optics;
+  P.inner_blocks = (s.hole_type == SART_HT_NONE) ? 1 : -1;
+  // detector plane
+  const double pipeRad = deg2rad(s.pipes_turned_deg);
+  P.pipe_c = std::cos(pipeRad); P.pipe_s = std::sin(pipeRad);
+  P.d_cb_xray = -s.optics_entrance[0];  // :2073
+  P.lateral_shift = s.lateral_shift;
+  P.transversal_shift = s.transversal_shift;
+  P.radius_window_sq = s.radius_window * s.radius_window;
+  P.chip_cx = s.chip_x_max / 2.0;
+  P.chip_cy = s.chip_y_max / 2.0;
+  P.theta_c = std::cos(s.theta_rad); P.theta_s = std::sin(s.theta_rad);
+  P.n_half_strips = static_cast<int>(std::round(s.number_of_strips / 2.0));  // :2167
+  if (P.n_half_strips > kMaxStrips) return fail(SART_ERR_INVALID_ARGUMENT, "number_of_strips too large");
+  for (int i = 0; i < P.n_half_strips; ++i) {  // :2168-2169
+    P.strip_lo[i] = (1.0 * i + 0.5) * s.strip_dist_window + i * s.strip_width_window;
+    P.strip_hi[i] = (1.0 * i + 0.5) * s.strip_dist_window + (i + 1.0) * s.strip_width_window;
+  }
+  P.stage_gas = (s.stage == SART_SK_GAS) ? 1 : 0;
+  // weights
+  {
+    // conversionProb :363-365 with unchained's natural units: T -> eV^2 (195.353), m -> eV^-1 (1/1.97327e-7)
+    const double k = (s.g_agamma * 1e-9) * (s.magnet_B * 195.353) * (1e-3 / 1.97327e-7) / 2.0;
+    P.conv_k = k * k;
+  }
+  P.exposure = (s.experiment == SART_ES_CAST) ? 3.585e3 * 3600.0 * 1.5 * 90.0 : 9.5e6 * 3600.0 * 12.0 * 90.0;  // :2207-2212
+  {
+    // gas stage, axionMassforMagnet.nim:30-101 (pGas in bar handed to mbar-documented functions — sic, :1601)
+    const double pGas = s.magnet_pGasRoom / s.room_temp * s.magnet_tGas;
+    const double length = s.magnet_lengthB * 1e-3, radBore = s.magnet_radiusCB * 1e-3;
+    const double vol = length * (kPi * std::pow(radBore, 2));
+    const double amountMol = (pGas * 1e2) * vol / (8.314 * s.magnet_tGas);
+    const double ne = 2 * 6.022e23 * (amountMol / vol);
+    const double m_gamma = std::sqrt(std::pow(1.97e-7, 3) * 4 * kPi * (1.0 / 137.0) * ne / 511e3);
+    P.gas_m_gamma_sq = m_gamma * m_gamma;
+    const double g_ev = s.g_agamma * 1e-9, beV = s.magnet_B * 1e3 / 1.444;
+    P.gas_term1 = std::pow(g_ev * beV / 2.0, 2);
+    P.gas_inv_hbarc_m = 1e-3 / 1.97e-7;
+    P.m_axion_sq = s.m_axion * s.m_axion;
+  }
+  // reflectivity
+  P.n_coatings = c->refl_nc;
+  P.refl_n_angles = c->refl_na;
+  if (c->have_refl) {
+    P.refl_angle_min = c->refl_amin;
+    P.refl_dangle = (c->refl_amax - c->refl_amin) / static_cast<double>(c->refl_na - 1);
+    P.refl_inv_dangle = 1.0 / P.refl_dangle;
+  }
+  for (int j = 0; j < s.n_shells; ++j) {
+    int coat = 0;
+    if (s.reflectivity_kind == SART_RK_MULTI_COATING) {
+      // layers.lowerBound(hitLayer) :1573 (first boundary >= hitLayer)
+      coat = static_cast<int>(std::lower_bound(s.coating_layers, s.coating_layers + s.n_coatings, j) - s.coating_layers);
+    }
+    P.shell_coating[j] = coat;
+  }
+  // shells
+  for (int j = 0; j < s.n_shells; ++j) {
+    ShellDev& sh = P.shells[j];
+    const double r1 = s.all_r1[j], l = s.l_mirror, xSep = s.all_xsep[j];
+    const double beta = deg2rad(s.all_angles_deg[j]), beta3 = 3.0 * beta;
+    const double distanceMirrors = std::cos(beta) * (xSep + l);  // :1973
+    sh.r1 = r1;
+    sh.r1_outer = r1 + s.all_thickness[j];
+    if (!P.telescope_wolter) {
+      // findPosCone :628-658
+      const double r2 = r1 - l * std::sin(beta);               // :1954-1957
+      const double r3 = r2 - 0.5 * xSep * std::tan(beta);
+      const double r4 = r3 - 0.5 * xSep * std::tan(3.0 * beta);
+      const double t1 = std::tan(beta), k1 = t1 * t1;
+      sh.m1_k = k1; sh.m1_hb = r1 * t1; sh.m1_cc = r1 * r1; sh.m1_zhi = l * std::cos(beta);
+      const double t2 = std::tan(beta3), k2 = t2 * t2, zm = distanceMirrors;
+      sh.m2_k = k2;
+      sh.m2_hb = r4 * t2 + k2 * zm;
+      sh.m2_cc = r4 * r4 + 2.0 * r4 * t2 * zm + k2 * zm * zm;
+      sh.m2_zlo = zm; sh.m2_zhi = zm + l * std::cos(beta3);
+      sh.m2_rc = r4;
+      sh.n1_tan = t1; sh.n2_tan = t2;
+    } else {
+      // findPosParabolic :660-690
+      const double tb = std::tan(beta);
+      const double r3 = -tb * l + std::sqrt(tb * l * tb * l + r1 * r1);
+      const double e = 2.0 * r3 * tb;
+      sh.m1_k = 0.0; sh.m1_hb = e / 2.0; sh.m1_cc = r3 * r3 + e * l; sh.m1_zhi = l * std::cos(beta);
+      sh.n1_r3t = r3 * tb; sh.n1_r3sq = r3 * r3; sh.n1_e = e; sh.n1_tan = tb;
+      // findPosHyperbolic :692-729 (angle = 3 beta)
+      const double ta = std::tan(beta3 / 3.0);
+      const double r3h = -ta * l + std::sqrt(ta * l * ta * l + r1 * r1);
+      const double f = s.distance_detector_xrt;
+      const double t3 = std::tan(beta3);
+      const double eh = 2.0 * r3h * t3;
+      const double F = f + r3h * cot(2.0 * beta3 / 3.0);
+      const double g = 2.0 * r3h * t3 / F;
+      sh.m2_k = g;
+      sh.m2_hb = g * l + eh / 2.0;
+      sh.m2_cc = r3h * r3h + eh * l + g * l * l;
+      sh.m2_zlo = distanceMirrors; sh.m2_zhi = distanceMirrors + l * std::cos(beta3);
+      sh.m2_rc = 0.0;
+      sh.n2_r3t = r3h * t3; sh.n2_r3sq = r3h * r3h; sh.n2_e = eh; sh.n2_invF = 1.0 / F; sh.n2_tan = t3;
+    }
+    // distDet :2070-2072 (hard-coded shell index 8 — sic), getPointDetectorWindow :811
+    const double distDet = distanceMirrors - 0.5 * s.all_xsep[8] * std::cos(beta) + s.distance_detector_xrt -
+                           s.distance_window_focal_plane;
+    sh.dist_det_raw = distDet;
+    sh.dist_det = distDet / std::cos(pipeRad);
+    sh.dist_det_end = (distDet + s.depth_det) / std::cos(pipeRad);
+    sh.nickel_num = (j > 0) ? (r1 - (s.all_r1[j - 1] + s.all_thickness[j - 1])) : 0.0;  // :1722
+  }
+  return 0;
+}
+
+// ---- per-energy-index tables -------------------------------------------------------------------
+int hoist_energy_tables(sart_context* c) {
+  const sart_setup_t& s = c->setup;
+  const int nE = c->n_energies;
+  std::vector<EnergyDev> tab(static_cast<size_t>(nE) + 1);
+  const double pGas = s.magnet_pGasRoom / s.room_temp * s.magnet_tGas;
+  auto density = [](double p, double temp) {  // axionMassforMagnet.nim:4-15
+    const double pressure = p * 1e2;
+    double r = pressure * 4.002602 / (8.314 * temp * 1000.0);
+    return r / 1000.0;
+  };
+  for (int i = 0; i <= nE; ++i) {
+    const double E = (i < nE) ? std::max(0.03, c->energies[i]) : s.test_energy;  // :470-471 / :1771
+    EnergyDev& e = tab[i];
+    e.energy = E;
+    e.t_window = linear1d(c->win_x, c->win_y, E);
+    e.t_strongback = linear1d(c->sb_x, c->sb_y, E);
+    e.a_gas = linear1d(c->gas_x, c->gas_y, E);
+    const double massAtt = std::exp(-1.5832 + 5.9195 * std::exp(-0.353808 * E) + 4.03598 * std::exp(-0.970557 * E));  // :70-73
+    e.gamma = 1.97e-7 * 100.0 * density(pGas, s.magnet_tGas) * massAtt;  // :84
+    e.two_e_ev = 2 * (E * 1000.0);                                         // :68
+    e.mu_pipe = massAtt * density(pGas, s.room_temp) * 100;                // :109-113
+    e.mu_magnet = massAtt * density(pGas, s.magnet_tGas) * 100;
+  }
+  return c->d_etab.upload(tab.data(), tab.size());
+}
+
+// Reflectivity re-tabulated per energy index: for each coating and each energy index the bilinear
+// interpolation (numericalnim eval_bilinear; call sites :1567-1568, :1577-1578) is carried out along
+// the energy axis, leaving g[i] with  R(alpha, E_idx) = g[i] + xUnit (g[i+1] - g[i]).
+int hoist_reflectivity(sart_context* c) {
+  const int nE = c->n_energies, nA = c->refl_na, nEr = c->refl_ne, nC = c->refl_nc;
+  std::vector<double> out(static_cast<size_t>(nC) * (nE + 1) * nA);
+  const double dy = (c->refl_emax - c->refl_emin) / static_cast<double>(nEr - 1);
+  for (int e = 0; e <= nE; ++e) {
+    const double E = (e < nE) ? std::max(0.03, c->energies[e]) : c->setup.test_energy;
+    long j = static_cast<long>(std::floor((E - c->refl_emin) / dy));
+    j = std::min<long>(j, nEr - 2);
+    if (j < 0) j = 0;  // below the grid the reference would index out of bounds; hold the first cell
+    const double yCorner = c->refl_emin + static_cast<double>(j) * dy;
+    const double yUnit = (E - yCorner) / dy;
+    for (int cc = 0; cc < nC; ++cc) {
+      const double* z = c->refl_data.data() + static_cast<size_t>(cc) * nA * nEr;
+      double* g = out.data() + (static_cast<size_t>(cc) * (nE + 1) + e) * nA;
+      for (int i = 0; i < nA; ++i) {
+        const double f0 = z[static_cast<size_t>(i) * nEr + j], f1 = z[static_cast<size_t>(i) * nEr + j + 1];
+        g[i] = f0 + (f1 - f0) * yUnit;
+      }
+    }
+  }
+  return c->d_refl.upload(out.data(), out.size());
+}
+
+int refresh_derived(sart_context* c) {
+  if (!c->derived_dirty) return 0;
+  if (!(c->have_setup && c->have_solar && c->have_refl && c->have_det))
+    return fail(SART_ERR_NOT_READY, "setup, solar tables, reflectivity and detector tables must all be set before tracing");
+  const sart_setup_t& s = c->setup;
+  if (s.reflectivity_kind == SART_RK_MULTI_COATING && c->refl_nc < s.n_coatings)
+    return fail(SART_ERR_INVALID_ARGUMENT, "multi-coating telescope needs one reflectivity grid per coating");
+  if (int rc = hoist_setup(c)) return rc;
+  if (int rc = c->d_params.upload(&c->params, 1)) return rc;
+  if (int rc = hoist_energy_tables(c)) return rc;
+  if (int rc = hoist_reflectivity(c)) return rc;
+  c->derived_dirty = false;
+  return 0;
+}
+
+int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
+  if (!p) return fail(SART_ERR_INVALID_ARGUMENT, "params is NULL");
+  if (p->image_nx < 1 || p->image_ny < 1 || !(p->image_x_max > p->image_x_min) || !(p->image_y_max > p->image_y_min))
+    return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
+  a.n_rays = p->n_rays;
+  a.ray_id_offset = p->ray_id_offset;
+  a.seed_lo = static_cast<uint32_t>(p->seed);
+  a.seed_hi = static_cast<uint32_t>(p->seed >> 32);
+  a.flags = p->flags;
+  a.image_nx = p->image_nx;
+  a.image_ny = p->image_ny;
+  a.image_x_min = p->image_x_min;
+  a.image_y_min = p->image_y_min;
+  a.image_inv_step_x = 1.0 / ((p->image_x_max - p->image_x_min) / static_cast<double>(p->image_nx));  // :828-830
+  a.image_inv_step_y = 1.0 / ((p->image_y_max - p->image_y_min) / static_cast<double>(p->image_ny));
+  (void)c;
+  return 0;
+}
+
+DevTables tables_of(sart_context* c) {
+  DevTables t;
+  t.params = c->d_params.p;
+  t.flux_radius_cdf = c->d_rcdf.p;
+  t.radius_guide = c->d_rguide.p;
+  t.diff_flux_cdfs = c->d_ecdf.p;
+  t.energy_guide = c->d_eguide.p;
+  t.energy_tab = c->d_etab.p;
+  t.refl = c->d_refl.p;
+  return t;
+}
+
+int grid_for(uint64_t n_rays, int n_cu, int blocks_per_cu) {
+  const uint64_t bs = static_cast<uint64_t>(trace_block_size());
+  const uint64_t need = (n_rays + bs - 1) / bs;
+  const uint64_t cap = static_cast<uint64_t>(n_cu) * static_cast<uint64_t>(std::max(1, blocks_per_cu));
+  return static_cast<int>(std::max<uint64_t>(1, std::min(need, cap)));
+}
+
+struct TimedLaunch {
+  sart_context* c;
+  hipEvent_t stop = nullptr;
+  explicit TimedLaunch(sart_context* ctx) : c(ctx) {
+    if (!c->timing) return;
+    if (c->events_used == c->events.size()) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      c->events.emplace_back(a, b);
+    }
+    auto& ev = c->events[c->events_used++];
+    (void)hipEventRecord(ev.first, c->stream);
+    stop = ev.second;
+  }
+  ~TimedLaunch() { if (stop) (void)hipEventRecord(stop, c->stream); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int sart_abi_version(void) { return SART_ABI_VERSION; }
+const char* sart_last_error(void) { return g_err.c_str(); }
+
+int sart_create(int device_ordinal, sart_context** out) {
+  if (!out) return fail(SART_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(SART_ERR_NO_DEVICE, "no HIP device available (libsart has no CPU fallback)");
+  if (device_ordinal < 0 || device_ordinal >= n_dev) return fail(SART_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+  SART_HIP(hipSetDevice(device_ordinal));
+  auto* c = new sart_context();
+  c->device = device_ordinal;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) {
+    delete c;
+    return fail(SART_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+  }
+  c->n_cu = prop.multiProcessorCount;
+  c->device_name = prop.name;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return fail(SART_ERR_NO_DEVICE, "hipStreamCreate failed");
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return 0;
+}
+
+int sart_destroy(sart_context* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return 0;
+}
+
+int sart_set_stream(sart_context* c, void* hip_stream) {
+  if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return 0;
+}
+
+int sart_synchronize(sart_context* c) {
+  if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SART_HIP(hipSetDevice(c->device));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int sart_set_setup(sart_context* c, const sart_setup_t* s) {
+  if (!c || !s) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (s->telescope_kind != SART_TK_LLNL && s->telescope_kind != SART_TK_XMM && s->telescope_kind != SART_TK_ABRIXAS)
+    return fail(SART_ERR_UNSUPPORTED,
+                "telescope kind has no opaque structures / reflectivities implemented (reference asserts, raytracer.nim:1233, 1703)");
+  if (s->n_shells < 9 || s->n_shells > SART_MAX_SHELLS)
+    return fail(SART_ERR_INVALID_ARGUMENT, "n_shells must be in [9, 64] (allXsep[8] is read, raytracer.nim:2070)");
+  for (int j = 1; j < s->n_shells; ++j)
+    if (!(s->all_r1[j] > s->all_r1[j - 1])) return fail(SART_ERR_INVALID_ARGUMENT, "all_r1 must be strictly ascending");
+  if (s->reflectivity_kind != SART_RK_SINGLE_COATING && s->reflectivity_kind != SART_RK_MULTI_COATING)
+    return fail(SART_ERR_UNSUPPORTED, "rkEffectiveArea is unreachable in the reference (raytracer.nim:1347) and not supported");
+  if (s->n_coatings < 1 || s->n_coatings > SART_MAX_COATINGS) return fail(SART_ERR_INVALID_ARGUMENT, "n_coatings out of range");
+  if (s->experiment != SART_ES_CAST && s->experiment != SART_ES_BABYIAXO) return fail(SART_ERR_INVALID_ARGUMENT, "experiment");
+  if (s->stage != SART_SK_VACUUM && s->stage != SART_SK_GAS) return fail(SART_ERR_INVALID_ARGUMENT, "stage");
+  if (!(s->magnet_radiusCB > 0) || !(s->magnet_lengthB > 0) || !(s->magnet_lengthColdbore >= s->magnet_lengthB))
+    return fail(SART_ERR_INVALID_ARGUMENT, "magnet geometry");
+  if (s->number_of_strips < 0 || s->number_of_strips > 2 * kMaxStrips) return fail(SART_ERR_INVALID_ARGUMENT, "number_of_strips");
+  c->setup = *s;
+  c->have_setup = true;
+  c->derived_dirty = true;
+  return 0;
+}
+
+int sart_get_setup(sart_context* c, sart_setup_t* out) {
+  if (!c || !out) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (!c->have_setup) return fail(SART_ERR_NOT_READY, "no setup");
+  *out = c->setup;
+  return 0;
+}
+
+int sart_set_telescope_angles(sart_context* c, double tx, double ty) {
+  if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!c->have_setup) return fail(SART_ERR_NOT_READY, "no setup");
+  if (!std::isnan(tx)) c->setup.telescope_turned_x_deg = tx;
+  if (!std::isnan(ty)) c->setup.telescope_turned_y_deg = ty;
+  if (c->derived_dirty) return 0;
+  // cheap path: only the geometry block changes
+  SART_HIP(hipSetDevice(c->device));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  if (int rc = hoist_setup(c)) return rc;
+  return c->d_params.upload(&c->params, 1);
+}
+
+int sart_set_axion_mass(sart_context* c, double m) {
+  if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!c->have_setup) return fail(SART_ERR_NOT_READY, "no setup");
+  c->setup.m_axion = m;
+  if (c->derived_dirty) return 0;
+  SART_HIP(hipSetDevice(c->device));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  c->params.m_axion_sq = m * m;
+  return c->d_params.upload(&c->params, 1);
+}
+
+int sart_set_solar_tables(sart_context* c, const double* rcdf, const double* ecdf, const double* energies, int32_t nR,
+                          int32_t nE) {
+  if (!c || !rcdf || !ecdf || !energies) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (nR < 1 || nR > 2048) return fail(SART_ERR_INVALID_ARGUMENT, "n_radii must be in [1, 2048] (LDS-resident radius CDF)");
+  if (nE < 2 || nE > 65535) return fail(SART_ERR_INVALID_ARGUMENT, "n_energies must be in [2, 65535]");
+  // both CDFs must be non-decreasing and end at exactly 1.0 (toCdf, raytracer.nim:2675-2677)
+  for (int i = 1; i < nR; ++i) if (rcdf[i] < rcdf[i - 1]) return fail(SART_ERR_INVALID_ARGUMENT, "flux_radius_cdf not monotone");
+  if (rcdf[nR - 1] != 1.0) return fail(SART_ERR_INVALID_ARGUMENT, "flux_radius_cdf must end at 1.0");
+  SART_HIP(hipSetDevice(c->device));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  // guide tables: g[k] = lowerBound(cdf, k / K); lowerBound(cdf, u) for u in [k/K, (k+1)/K) lies in [g[k], g[k+1]]
+  std::vector<uint16_t> rg(kRadiusGuide + 1);
+  for (int k = 0; k <= kRadiusGuide; ++k)
+    rg[k] = static_cast<uint16_t>(std::min<size_t>(lower_bound_idx(rcdf, nR, static_cast<double>(k) / kRadiusGuide), nR - 1));
+  std::vector<uint16_t> eg(static_cast<size_t>(nR) * (kEnergyGuide + 1));
+  for (int r = 0; r < nR; ++r) {
+    const double* row = ecdf + static_cast<size_t>(r) * nE;
+    for (int i = 1; i < nE; ++i)
+      if (row[i] < row[i - 1]) return fail(SART_ERR_INVALID_ARGUMENT, "diff_flux_cdfs row not monotone");
+    if (row[nE - 1] != 1.0) return fail(SART_ERR_INVALID_ARGUMENT, "every diff_flux_cdfs row must end at 1.0");
+    for (int k = 0; k <= kEnergyGuide; ++k)
+      eg[static_cast<size_t>(r) * (kEnergyGuide + 1) + k] =
+          static_cast<uint16_t>(std::min<size_t>(lower_bound_idx(row, nE, static_cast<double>(k) / kEnergyGuide), nE - 1));
+  }
+  if (int rc = c->d_rcdf.upload(rcdf, nR)) return rc;
+  if (int rc = c->d_ecdf.upload(ecdf, static_cast<size_t>(nR) * nE)) return rc;
+  if (int rc = c->d_rguide.upload(rg.data(), rg.size())) return rc;
+  if (int rc = c->d_eguide.upload(eg.data(), eg.size())) return rc;
+  c->energies.assign(energies, energies + nE);
+  c->n_radii = nR;
+  c->n_energies = nE;
+  c->have_solar = true;
+  c->derived_dirty = true;
+  return 0;
+}
+
+int sart_set_reflectivity(sart_context* c, int32_t nC, int32_t nA, int32_t nE, double amin, double amax, double emin,
+                          double emax, const double* data) {
+  if (!c || !data) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (nC < 1 || nC > SART_MAX_COATINGS || nA < 2 || nE < 2 || !(amax > amin) || !(emax > emin))
+    return fail(SART_ERR_INVALID_ARGUMENT, "invalid reflectivity grid");
+  c->refl_data.assign(data, data + static_cast<size_t>(nC) * nA * nE);
+  c->refl_nc = nC; c->refl_na = nA; c->refl_ne = nE;
+  c->refl_amin = amin; c->refl_amax = amax; c->refl_emin = emin; c->refl_emax = emax;
+  c->have_refl = true;
+  c->derived_dirty = true;
+  return 0;
+}
+
+int sart_set_detector_tables(sart_context* c, const double* sbx, const double* sby, int32_t nsb, const double* wx,
+                             const double* wy, int32_t nw, const double* gx, const double* gy, int32_t ng) {
+  if (!c || !sbx || !sby || !wx || !wy || !gx || !gy) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (nsb < 2 || nw < 2 || ng < 2) return fail(SART_ERR_INVALID_ARGUMENT, "tables need at least two points");
+  auto ascending = [](const double* x, int n) { for (int i = 1; i < n; ++i) if (!(x[i] > x[i - 1])) return false; return true; };
+  if (!ascending(sbx, nsb) || !ascending(wx, nw) || !ascending(gx, ng))
+    return fail(SART_ERR_INVALID_ARGUMENT, "table abscissae must be strictly ascending");
+  c->sb_x.assign(sbx, sbx + nsb); c->sb_y.assign(sby, sby + nsb);
+  c->win_x.assign(wx, wx + nw); c->win_y.assign(wy, wy + nw);
+  c->gas_x.assign(gx, gx + ng); c->gas_y.assign(gy, gy + ng);
+  c->have_det = true;
+  c->derived_dirty = true;
+  return 0;
+}
+
+int sart_trace_records_device(sart_context* c, const sart_trace_params_t* p, sart_axion_t* out_dev) {
+  if (!c || !out_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  SART_HIP(hipSetDevice(c->device));
+  if (int rc = refresh_derived(c)) return rc;
+  TraceArgs a;
+  if (int rc = make_args(c, p, a)) return rc;
+  if (a.n_rays == 0) return 0;
+  if (c->blocks_per_cu_rec == 0) c->blocks_per_cu_rec = 4;
+  {
+    TimedLaunch tl(c);
+    launch_trace_records(tables_of(c), a, out_dev, grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_rec), c->stream);
+  }
+  SART_HIP(hipGetLastError());
+  return 0;
+}
+
+int sart_trace_records(sart_context* c, const sart_trace_params_t* p, sart_axion_t* out) {
+  if (!c || !p || (!out && p->n_rays)) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (p->n_rays == 0) return 0;
+  SART_HIP(hipSetDevice(c->device));
+  if (int rc = c->d_rec.resize(p->n_rays)) return rc;
+  if (int rc = sart_trace_records_device(c, p, c->d_rec.p)) return rc;
+  SART_HIP(hipMemcpyAsync(out, c->d_rec.p, p->n_rays * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->stream));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, double* acc_dev) {
+  if (!c || !acc_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  SART_HIP(hipSetDevice(c->device));
+  if (int rc = refresh_derived(c)) return rc;
+  TraceArgs a;
+  if (int rc = make_args(c, p, a)) return rc;
+  if (!p->accumulate)
+    SART_HIP(hipMemsetAsync(acc_dev, 0, sart_accumulator_len(p->image_nx, p->image_ny) * sizeof(double), c->stream));
+  if (a.n_rays == 0) return 0;
+  if (c->blocks_per_cu_hist == 0) c->blocks_per_cu_hist = 8;
+  {
+    TimedLaunch tl(c);
+    launch_trace_histogram(tables_of(c), a, acc_dev, grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_hist), c->stream);
+  }
+  SART_HIP(hipGetLastError());
+  return 0;
+}
+
+int sart_trace_histogram(sart_context* c, const sart_trace_params_t* p, double* image_out, sart_summary_t* summary) {
+  if (!c || !p) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  SART_HIP(hipSetDevice(c->device));
+  const size_t len = sart_accumulator_len(p->image_nx, p->image_ny);
+  if (p->image_nx < 1 || p->image_ny < 1) return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
+  const bool fresh = (c->d_acc.n != len) || !c->d_acc.p;
+  if (int rc = c->d_acc.resize(len)) return rc;
+  sart_trace_params_t q = *p;
+  if (fresh) q.accumulate = 0;
+  if (int rc = sart_trace_histogram_device(c, &q, c->d_acc.p)) return rc;
+  const size_t nimg = static_cast<size_t>(p->image_nx) * p->image_ny;
+  if (image_out) SART_HIP(hipMemcpyAsync(image_out, c->d_acc.p, nimg * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (summary)
+    SART_HIP(hipMemcpyAsync(summary->v, c->d_acc.p + nimg, SART_ACC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int sart_enable_kernel_timing(sart_context* c, int enable) {
+  if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  c->timing = enable != 0;
+  c->events_used = 0;
+  return 0;
+}
+
+int sart_get_kernel_timing(sart_context* c, double* total_ms, int64_t* n_launches) {
+  if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SART_HIP(hipSetDevice(c->device));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  double tot = 0.0;
+  for (size_t i = 0; i < c->events_used; ++i) {
+    float ms = 0.f;
+    SART_HIP(hipEventElapsedTime(&ms, c->events[i].first, c->events[i].second));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (n_launches) *n_launches = static_cast<int64_t>(c->events_used);
+  c->events_used = 0;
+  return 0;
+}
+
+int sart_device_info(sart_context* c, int32_t* n_cu, int32_t* wave_size, char* name_buf, size_t name_buf_len) {
+  if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (n_cu) *n_cu = c->n_cu;
+  if (wave_size) *wave_size = 64;
+  if (name_buf && name_buf_len) {
+    std::snprintf(name_buf, name_buf_len, "%s", c->device_name.c_str());
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// sart_device.h — PODs shared by the host side of libsart (sart_api.hip) and the gfx950 kernels
+// (sart_kernels.hip).  Everything here is *derived* from sart_setup_t + the tables by
+// hoist_setup() in sart_api.hip: per-setup / per-shell / per-energy-index constants are
+// evaluated once on the host with the reference's formulas (cited there) so that the per-ray
+// kernel contains no setup-only transcendental.
+#pragma once
+#include <stdint.h>
+
+namespace sart {
+
+constexpr int kMaxShells = 64;
+constexpr int kMaxStrips = 32;       // half the number of window strips that are looped over
+constexpr int kRadiusGuide = 2048;   // buckets of the guide table in front of fluxRadiusCDF
+constexpr int kEnergyGuide = 256;    // buckets per radius row in front of diffFluxCDFs
+
+// Per-shell constants (Wolter-I pair j).  Quadratics are expressed in the telescope frame with
+// the ray parametrised by z:  X(z) = X0 + sx z,  Y(z) = Y0 + sy z, so that with
+//   A = sx^2 + sy^2,  D = X0 sx + Y0 sy,  Q = X0^2 + Y0^2
+// a = A - k,  half_b = D + hb,  c = Q - cc   (findPosCone/Parabolic/Hyperbolic, raytracer.nim:628-729).
+struct ShellDev {
+  double r1;        // allR1[j]
+  double r1_outer;  // allR1[j] + allThickness[j]
+  // mirror 1 (cone, angle beta | paraboloid)
+  double m1_k, m1_hb, m1_cc, m1_zhi;   // z range (0, m1_zhi)
+  // mirror 2 (cone r4, angle 3 beta | hyperboloid)
+  double m2_k, m2_hb, m2_cc, m2_zlo, m2_zhi;
+  double m2_rc;     // cone 2: radius at z = m2_zlo (r4)
+  // surface normals (calcNormalVec, raytracer.nim:731-759)
+  double n1_tan;    // cone: tan(beta)
+  double n1_r3t;    // paraboloid: r3 * tan(beta);    n1_r3sq = r3^2, n1_e = 2 r3 tan(beta)
+  double n1_r3sq, n1_e;
+  double n2_tan;    // cone: tan(3 beta)
+  double n2_r3t;    // hyperboloid: r3 * tan(3 beta); n2_r3sq = r3^2, n2_e = 2 r3 tan(3 beta)
+  double n2_r3sq, n2_e, n2_invF;       // invF = 1 / (f + r3 cot(2 beta))
+  // detector distance for this shell (raytracer.nim:2070-2072), already divided by cos(pipe angle)
+  double dist_det, dist_det_end;
+  double dist_det_raw;                 // distDet before the 1/cos (xray-test straight-through, :2131)
+  // lineHitsNickel (raytracer.nim:1722): r1 - (R1[j-1] + t[j-1]); unused for j == 0
+  double nickel_num;
+};
+
+// Per-energy-index constants: the energy of a ray is one of the n_energies table values
+// (raytracer.nim:470-471: energies[idx], clamped to >= 0.03 keV), so every E-only factor is a table.
+// Row n_energies holds the same quantities for the X-ray test source's fixed energy (:1771).
+struct EnergyDev {
+  double energy;       // max(0.03, energies[idx])
+  double t_window;     // windowTransmission.eval(E)      (:2179)
+  double t_strongback; // strongbackTransmission.eval(E)  (:2170)
+  double a_gas;        // gasAbsorption.eval(E)           (:2190)
+  // gas stage (axionMassforMagnet.nim:75-113)
+  double gamma;        // Γ(E) in eV
+  double two_e_ev;     // 2 * E[eV]  (momentumTransfer denominator)
+  double mu_pipe;      // massAtt * rhoPipe   * 100   [1/m]
+  double mu_magnet;    // massAtt * rhoMagnet * 100   [1/m]
+};
+
+struct DevParams {
+  // ---- sampling (raytracer.nim:412-471) ----
+  double sun_distance, sun_radius;
+  double radius_cb, radius_cb_sq, length_b, length_coldbore;
+  double pipe1_len, pipe2_len, pipe1_radius_sq;
+  int32_t n_radii, n_energies;
+  // ---- X-ray test source (raytracer.nim:1765-1806) ----
+  int32_t test_active, test_parallel;
+  double test_x, test_y, test_z, test_radius, test_radius_sq, test_collimator_z;
+  // ---- telescope frame (raytracer.nim:1878-1899) ----
+  int32_t telescope_wolter;   // 1: paraboloid + hyperboloid (XMM, Abrixas); 0: cones (LLNL)
+  int32_t telescope_kind;     // SART_TK_*
+  int32_t n_shells, rotated;
+  double l_mirror;
+  double rx_c, rx_s, ry_c, ry_s, half_length_telescope;
+  double entrance_x, entrance_y;
+  // ---- opaque structures (raytracer.nim:1635-1704) ----
+  double spider_z;            // -85 (XMM) / -35 (Abrixas)
+  double inner_radius;        // XMM: 64.7 (<=) ; Abrixas: 37.5 (<)
+  double ring_lo, ring_hi;    // XMM: 130.7 .. 151.6 (exclusive)
+  int32_t n_spokes;           // bands actually reachable with phi in [0, 180]
+  int32_t inner_blocks;       // XMM: result of the hole loop for r <= 64.7 when it is ray-independent (-1: evaluate)
+  double spoke_cos_lo[12];    // cos(centre + half width)
+  double spoke_cos_hi[12];    // cos(centre - half width)
+  int32_t hole_type, number_of_holes;
+  double hole_in_optics;
+  // ---- detector plane (raytracer.nim:797-814, 2133-2204) ----
+  double pipe_c, pipe_s, d_cb_xray;
+  double lateral_shift, transversal_shift;
+  double radius_window_sq, chip_cx, chip_cy;
+  double theta_c, theta_s;
+  int32_t n_half_strips, stage_gas;
+  double strip_lo[kMaxStrips], strip_hi[kMaxStrips];
+  // ---- weights (raytracer.nim:363-365, 1582-1625, 2207-2212) ----
+  double conv_k;              // P(a->gamma) = conv_k * pathCB^2 (vacuum)
+  double exposure;            // 3.585e3*3600*1.5*90 | 9.5e6*3600*12*90
+  double gas_m_gamma_sq, gas_term1, gas_inv_hbarc_m;   // m_gamma^2, (g B / 2)^2, 1/(1.97e-7) * 1e-3 (mm -> 1/eV)
+  double m_axion_sq;
+  // ---- reflectivity (raytracer.nim:1533-1580) ----
+  int32_t refl_n_angles, n_coatings;
+  double refl_angle_min, refl_inv_dangle, refl_dangle;
+  int32_t shell_coating[kMaxShells];
+  // ---- shells ----
+  ShellDev shells[kMaxShells];
+};
+
+// Device pointers of one context.
+struct DevTables {
+  const DevParams* params;
+  const double* flux_radius_cdf;      // [n_radii]
+  const uint16_t* radius_guide;       // [kRadiusGuide + 1]
+  const double* diff_flux_cdfs;       // [n_radii][n_energies]
+  const uint16_t* energy_guide;       // [n_radii][kEnergyGuide + 1]
+  const EnergyDev* energy_tab;        // [n_energies + 1]
+  // reflectivity re-tabulated per energy index: refl[coating][e_idx][angle] (see hoist_reflectivity)
+  const double* refl;                 // [n_coatings][n_energies + 1][n_angles]
+};
+
+struct TraceArgs {
+  uint64_t n_rays, ray_id_offset;
+  uint32_t seed_lo, seed_hi;
+  uint32_t flags;
+  int32_t image_nx, image_ny;
+  double image_x_min, image_y_min, image_inv_step_x, image_inv_step_y;
+};
+
+}  // namespace sart

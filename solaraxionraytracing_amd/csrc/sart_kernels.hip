@@ -1,0 +1,681 @@
+// sart_kernels.hip — gfx950 (MI355X, CDNA4) kernels of the per-ray hot path.
+//
+// One ray per lane, f64 throughout (the Sun sits 1.5e14 mm away and the mirror quadratics cancel
+// ~1e5-magnitude terms).  The algorithm is the reference's `traceAxion`
+// (src/raytracer.nim:1736-2221), restructured for the device:
+//   * every per-setup / per-shell / per-energy-index quantity is a table built on the host
+//     (sart_api.hip: hoist_*), so the kernel has no setup-only transcendental;
+//   * the straight line through bore and pipes is carried as (point on the bore exit, slopes
+//     dx/dz, dy/dz) instead of differences of 1e11-magnitude points: same geometry, without the
+//     reference's ~1e-5 mm cancellation noise;
+//   * mirror hits use the cancellation-free form of the same quadratic roots; the reflection
+//     v cos2a - (v x axis) sin2a (:778-779) is evaluated algebraically (no asin/sin/cos), and on a
+//     hit the surface normals reduce to closed forms without a square root;
+//   * a Philox4x32-10 counter block per ray (key = seed, counter = global ray id) replaces the
+//     reference's shared xoroshiro stream, draw order as in the reference;
+//   * results are accumulated on the device: f64 atomics into the focal-plane image, wave
+//     reductions for the scalars.
+// Lines cited as ":NNNN" refer to src/raytracer.nim of the reference.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sart.h"
+#include "sart_device.h"
+
+namespace sart {
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10
+// ------------------------------------------------------------------------------------------------
+struct U4 { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                            uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0;
+    const uint32_t n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return U4{c0, c1, c2, c3};
+}
+
+// 53-bit uniform in [0, 1) from two words (hi word first) — same construction as the oracle.
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+  const uint64_t bits = ((uint64_t)hi << 32) | (uint64_t)lo;
+  return (double)(bits >> 11) * 0x1.0p-53;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small math helpers
+// ------------------------------------------------------------------------------------------------
+// asin for the grazing angles of the path (|x| < ~0.03): odd Taylor series
+// asin x = x + x^3/6 + 3x^5/40 + 5x^7/112 + 35x^9/1152 + 63x^11/2816 + 231x^13/13312 + 143x^15/10240,
+// truncation error < 1e-19 below 0.06; the library function outside.
+__device__ __forceinline__ double asin_small(double x) {
+  if (fabs(x) < 0.06) {
+    const double x2 = x * x;
+    double p = 0.01396484375;               // 143/10240
+    p = fma(p, x2, 0.017352764423076924);   // 231/13312
+    p = fma(p, x2, 0.022372159090909092);   // 63/2816
+    p = fma(p, x2, 0.030381944444444444);   // 35/1152
+    p = fma(p, x2, 0.044642857142857144);   // 5/112
+    p = fma(p, x2, 0.075);                  // 3/40
+    p = fma(p, x2, 0.16666666666666666);    // 1/6
+    return fma(x * x2, p, x);
+  }
+  return asin(x);
+}
+
+// atan for ray slopes (|x| < 0.05): alternating series to x^15; library outside.
+__device__ __forceinline__ double atan_small(double x) {
+  if (fabs(x) < 0.05) {
+    const double x2 = x * x;
+    double p = -1.0 / 15.0;
+    p = fma(p, x2, 1.0 / 13.0);
+    p = fma(p, x2, -1.0 / 11.0);
+    p = fma(p, x2, 1.0 / 9.0);
+    p = fma(p, x2, -1.0 / 7.0);
+    p = fma(p, x2, 1.0 / 5.0);
+    p = fma(p, x2, -1.0 / 3.0);
+    return fma(x * x2, p, x);
+  }
+  return atan(x);
+}
+
+// cos on |x| <= 1 by its Taylor series to x^20 (error < 1e-19 there); library outside.
+__device__ __forceinline__ double cos_small(double x) {
+  if (fabs(x) <= 1.0) {
+    const double x2 = x * x;
+    double p = 4.110317623312165e-19;          //  1/20!
+    p = fma(p, x2, -1.5619206968586225e-16);   // -1/18!
+    p = fma(p, x2, 4.779477332387385e-14);     //  1/16!
+    p = fma(p, x2, -1.1470745597729725e-11);   // -1/14!
+    p = fma(p, x2, 2.08767569878681e-09);      //  1/12!
+    p = fma(p, x2, -2.755731922398589e-07);    // -1/10!
+    p = fma(p, x2, 2.48015873015873e-05);      //  1/8!
+    p = fma(p, x2, -0.001388888888888889);     // -1/6!
+    p = fma(p, x2, 0.041666666666666664);      //  1/4!
+    p = fma(p, x2, -0.5);
+    return fma(p, x2, 1.0);
+  }
+  return cos(x);
+}
+
+// lowerBound(a, key) with the answer known to lie in [lo, hi] (guide-table bracket):
+// first index i with a[i] >= key  (std/algorithm.lowerBound semantics).
+template <typename Ptr>
+__device__ __forceinline__ int lower_bound_bracket(Ptr a, int lo, int hi, double key) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// Roots of a z^2 + 2 hb z + c = 0 in the reference's naming:
+//   root1 = (-hb - sqrt(hb^2 - a c)) / a,  root2 = (-hb + sqrt(hb^2 - a c)) / a     (:649-650)
+// evaluated without cancellation (q-form); root1 is preferred, then root2, else miss (:651-656).
+__device__ __forceinline__ bool pick_root(double a, double hb, double c, double zlo, double zhi, double& z) {
+  const double disc = fma(hb, hb, -a * c);
+  const double sq = sqrt(disc);  // NaN for disc < 0 -> every comparison below is false -> miss
+  double root1, root2;
+  if (hb >= 0.0) {
+    const double q = -hb - sq;
+    root1 = q / a;
+    root2 = c / q;
+  } else {
+    const double q = -hb + sq;
+    root2 = q / a;
+    root1 = c / q;
+  }
+  if (root1 > zlo && root1 < zhi) { z = root1; return true; }
+  if (root2 > zlo && root2 < zhi) { z = root2; return true; }
+  return false;
+}
+
+// Reflection of the (un-normalised) direction w, |w|^2 = L, at a surface with (un-normalised)
+// normal n, |n|^2 = N2:  the reference's v' = v cos 2a - (v x axis) sin 2a with a = asin|n.v|/|n|
+// (:774-779) equals  v (1 - 2c^2 + 2c|c|) - 2|c| n^  with c = n^.v ; written for w = |w| v.
+// Returns sin^2(a) = c^2.
+__device__ __forceinline__ double reflect(double& wx, double& wy, double& wz, double L, double nx, double ny,
+                                          double nz, double N2) {
+  const double dnw = fma(nx, wx, fma(ny, wy, nz * wz));
+  const double f = dnw / N2;
+  const double c2 = dnw * f / L;
+  if (dnw >= 0.0) {
+    wx = fma(-2.0 * f, nx, wx);
+    wy = fma(-2.0 * f, ny, wy);
+    wz = fma(-2.0 * f, nz, wz);
+  } else {  // normal facing the ray: the reference's formula is then not a mirror reflection; keep it
+    const double k = 1.0 - 4.0 * c2;
+    wx = fma(2.0 * f, nx, k * wx);
+    wy = fma(2.0 * f, ny, k * wy);
+    wz = fma(2.0 * f, nz, k * wz);
+  }
+  return c2;
+}
+
+// calcNormalVec (:731-759) z-component for an arbitrary point (general form with the square root;
+// only needed when the ray missed the mirror and the reference evaluates the normal at its input point).
+__device__ __forceinline__ double normal_z_general(const DevParams& P, const ShellDev& sh, int mirror, double x,
+                                                   double y, double z) {
+  const double rho = sqrt(fma(x, x, y * y));
+  if (!P.telescope_wolter) return (mirror == 1 ? sh.n1_tan : sh.n2_tan) * rho;
+  const double lz = P.l_mirror - z;
+  if (mirror == 1) return rho * sh.n1_r3t / sqrt(fma(sh.n1_e, lz, sh.n1_r3sq));
+  const double w = fma(sh.n2_e * lz, fma(lz, sh.n2_invF, 1.0), sh.n2_r3sq);
+  return rho * sh.n2_r3t * fma(2.0 * lz, sh.n2_invF, 1.0) / sqrt(w);
+}
+
+// Per-thread accumulators of the scalar tail of the fused accumulator.
+struct Scalars {
+  double sum_w = 0.0, sum_w2 = 0.0, sum_x = 0.0, sum_y = 0.0, sum_r = 0.0;
+  uint32_t n_passed = 0, n_till_window = 0, n_nickel = 0, n_reached = 0, n_shell = 0, n_outside = 0;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// one ray
+// ------------------------------------------------------------------------------------------------
+template <bool RECORDS>
+__device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T, const TraceArgs& A,
+                                          const double* __restrict__ lds_rcdf, uint64_t ray_id, sart_axion_t* rec,
+                                          double* __restrict__ acc, Scalars& S) {
+  const uint32_t id_lo = (uint32_t)ray_id, id_hi = (uint32_t)(ray_id >> 32);
+  // ---- sample: origin in the Sun / on the source, point on the bore exit (:1751-1806) ----
+  const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, A.seed_lo, A.seed_hi);
+  const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, A.seed_lo, A.seed_hi);
+  const U4 b2 = philox4x32_10(id_lo, id_hi, 2u, 0u, A.seed_lo, A.seed_hi);
+  const double u0 = u53(b0.x, b0.y), u1 = u53(b0.z, b0.w);
+  const double u2 = u53(b1.x, b1.y), u3 = u53(b1.z, b1.w);
+  const double u4 = u53(b2.x, b2.y), u5 = u53(b2.z, b2.w);
+
+  double ex, ey;            // point on the magnetic-field exit plane z = lengthB
+  double sx, sy;            // ray slopes dx/dz, dy/dz in the magnet frame
+  int e_idx = 0;            // energy index into EnergyDev / refl tables
+  int r_idx = 0;
+  bool energy_pending = false;
+  if (!P.test_active) {
+    // getRandomPointFromSolarModel (:425-442): theta1 = 360 u0 deg, theta2 = 180 u1 deg (uniform in theta)
+    double s1, c1, s2, c2;
+    sincospi(2.0 * u0, &s1, &c1);
+    sincospi(u1, &s2, &c2);
+    {
+      const int k = (int)(u2 * (double)kRadiusGuide);
+      r_idx = lower_bound_bracket(lds_rcdf, (int)T.radius_guide[k], (int)T.radius_guide[k + 1], u2);
+    }
+    const double r = (0.0015 + (double)r_idx * 0.0005) * P.sun_radius;
+    const double ox = c1 * s2 * r, oy = s1 * s2 * r, oz = c2 * r - P.sun_distance;
+    // getRandomPointOnDisk (:412-422)
+    double sp, cp;
+    sincospi(2.0 * u4, &sp, &cp);
+    const double rr = P.radius_cb * sqrt(u3);
+    ex = cp * rr;
+    ey = sp * rr;
+    const double inv_dz = 1.0 / (P.length_b - oz);
+    sx = (ex - ox) * inv_dz;
+    sy = (ey - oy) * inv_dz;
+    energy_pending = true;   // getRandomEnergyFromSolarModel (:444-471) is evaluated lazily below
+  } else {
+    // X-ray test source (:1765-1806)
+    double sp, cp;
+    sincospi(2.0 * u1, &sp, &cp);
+    const double rr = P.test_radius * sqrt(u0);
+    const double ox = cp * rr + P.test_x, oy = sp * rr + P.test_y, oz = P.test_z;
+    if (P.test_parallel) {
+      ex = ox + (u2 * 0.5) - 0.25;
+      ey = oy + (u3 * 0.5) - 0.25;
+    } else {
+      double sq, cq;
+      sincospi(2.0 * u3, &sq, &cq);
+      const double r2 = P.radius_cb * sqrt(u2);
+      ex = cq * r2;
+      ey = sq * r2;
+    }
+    const double inv_dz = 1.0 / (P.length_b - oz);
+    sx = (ex - ox) * inv_dz;
+    sy = (ey - oy) * inv_dz;
+    e_idx = P.n_energies;  // the extra row of the energy tables holds the source energy
+    // collimator (:1800): lineIntersectsCircle(origin, exit point, collimator, source radius)
+    const double dzc = P.test_collimator_z - P.length_b;
+    const double cx = fma(dzc, sx, ex) - P.test_x, cy = fma(dzc, sy, ey) - P.test_y;
+    if (!(fma(cx, cx, cy * cy) < P.test_radius_sq)) return;
+  }
+
+  // Energy index, drawn with u5 from the CDF row of the sampled radius (:462-471).
+  auto sample_energy = [&]() {
+    const double* row = T.diff_flux_cdfs + (size_t)r_idx * (size_t)P.n_energies;
+    const uint16_t* g = T.energy_guide + (size_t)r_idx * (size_t)(kEnergyGuide + 1);
+    const int k = (int)(u5 * (double)kEnergyGuide);
+    const int idx = lower_bound_bracket(row, (int)g[k], (int)g[k + 1], u5);
+    e_idx = min(idx, P.n_energies - 1);
+    energy_pending = false;
+  };
+  if (RECORDS) {
+    if (energy_pending) sample_energy();
+    rec->emratesPre = 1.0;                    // :1818
+    rec->energiesPre = T.energy_tab[e_idx].energy;
+  }
+
+  // ---- bore (:1813-1848) ----
+  const double A2 = fma(sx, sx, sy * sy);     // slope^2
+  double path_cb;                              // length of the path inside the magnetic field
+  {
+    // entrance plane z = 0
+    const double x0 = fma(-P.length_b, sx, ex), y0 = fma(-P.length_b, sy, ey);
+    const bool hits_entrance = fma(x0, x0, y0 * y0) < P.radius_cb_sq;
+    const double norm = sqrt(1.0 + A2);
+    if (hits_entrance) {
+      path_cb = P.length_b * norm;             // |exit point - entrance-plane point| (:1836-1843)
+    } else {
+      // lineIntersectsCylinderOnce (:591-604): intersections of the line with the bore wall,
+      // t = z - lengthB:  A2 t^2 + 2 Dm t + (Qm - R^2) = 0.  inter1 = larger z, inter2 = smaller z.
+      const double Dm = fma(ex, sx, ey * sy);
+      const double c = fma(ex, ex, ey * ey) - P.radius_cb_sq;
+      const double disc = fma(Dm, Dm, -A2 * c);
+      const double sq = sqrt(disc);
+      double t_hi, t_lo;
+      if (Dm >= 0.0) { const double q = -Dm - sq; t_lo = q / A2; t_hi = c / q; }
+      else           { const double q = -Dm + sq; t_hi = q / A2; t_lo = c / q; }
+      const double z_hi = P.length_b + t_hi, z_lo = P.length_b + t_lo;
+      const bool v1 = (z_hi > 0.0) && (z_hi < P.length_coldbore);
+      const bool v2 = (z_lo > 0.0) && (z_lo < P.length_coldbore);
+      if (!(v1 != v2)) return;                 // both or none (:598-600, :1825)
+      const double t = v1 ? t_hi : t_lo;       // :616
+      path_cb = fabs(t) * norm;
+    }
+  }
+  // exit of the cold bore (:1846)
+  const double dz1 = P.length_coldbore - P.length_b;
+  const double x1 = fma(dz1, sx, ex), y1 = fma(dz1, sy, ey);
+  if (!(fma(x1, x1, y1 * y1) < P.radius_cb_sq)) return;
+  // pipe CB -> VT3 (:1856) and VT3 -> XRT (:1866; same radius — sic)
+  const double dz2 = dz1 + P.pipe1_len;
+  const double x2 = fma(dz2, sx, ex), y2 = fma(dz2, sy, ey);
+  if (!(fma(x2, x2, y2 * y2) < P.pipe1_radius_sq)) return;
+  const double dz3 = dz2 + P.pipe2_len;
+  const double x3 = fma(dz3, sx, ex), y3 = fma(dz3, sy, ey);
+  if (!(fma(x3, x3, y3 * y3) < P.pipe1_radius_sq)) return;
+  S.n_reached++;
+
+  // ---- telescope frame (:1878-1899) ----
+  // pointExitCB' (z = -Lp before rotation) and pointExitPipeVT3XRT' (z = 0 before rotation)
+  const double Lp = P.pipe1_len + P.pipe2_len;
+  double X0, Y0, tsx, tsy;      // ray in the telescope frame: X(z) = X0 + tsx z, X0 = pointEntranceXRT
+  double zcb;                   // z of pointExitCB in the telescope frame (z0 of :2051)
+  if (!P.rotated) {
+    X0 = x3 - P.entrance_x;
+    Y0 = y3 - P.entrance_y;
+    tsx = sx;
+    tsy = sy;
+    zcb = -Lp;
+  } else {
+    // rotateInY(rotateInX(p, turnedX, lT/2), turnedY, lT/2) applied to both points (:1888-1894)
+    auto rot = [&](double px, double py, double pz, double& qx, double& qy, double& qz) {
+      const double zz = pz - P.half_length_telescope;
+      const double ax = fma(px, P.rx_c, zz * P.rx_s);
+      const double az = fma(zz, P.rx_c, -px * P.rx_s);   // rotateInX adds lT/2 back, rotateInY removes it again
+      qx = ax;
+      qy = fma(py, P.ry_c, -az * P.ry_s);
+      qz = fma(az, P.ry_c, py * P.ry_s) + P.half_length_telescope;
+    };
+    double ax, ay, az, bx, by, bz;
+    rot(x1, y1, -Lp, ax, ay, az);
+    rot(x3, y3, 0.0, bx, by, bz);
+    ax -= P.entrance_x; ay -= P.entrance_y;
+    bx -= P.entrance_x; by -= P.entrance_y;
+    const double inv = 1.0 / (bz - az);
+    tsx = (bx - ax) * inv;
+    tsy = (by - ay) * inv;
+    X0 = fma(-az, tsx, ax);     // pointEntranceXRT: z = 0 (:1897-1898)
+    Y0 = fma(-az, tsy, ay);
+    zcb = az;
+  }
+  const double Q0 = fma(X0, X0, Y0 * Y0);
+  const double radial = sqrt(Q0);              // radialDist (:1905)
+
+  // ---- opaque structures (:1635-1704) ----
+  if (P.telescope_kind != SART_TK_LLNL) {      // LLNL: the graphite block never blocks (:1646)
+    bool blocked = false;
+    const bool inner = (P.telescope_kind == SART_TK_XMM) ? (radial <= P.inner_radius) : (radial < P.inner_radius);
+    if (inner) {
+      if (P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) {
+        // hole loop (:1675-1688) with lineIntersectsObject (:494-527) on the entrance plane
+        const int nH = P.number_of_holes;
+        const int lim = nH - (int)ceil((double)nH / 2.0);
+        bool res = false;
+        for (int l = -lim; l <= lim; ++l) {
+          double hx = 0.0, hy = 0.0;
+          if (l != 0) {
+            if ((abs(l) & 1) == 0) hy += 2.0 * (double)l * P.hole_in_optics;
+            else hx += 2.0 * ((double)l + ((double)l / (double)abs(l))) * P.hole_in_optics;
+          }
+          const double ix = X0 - hx, iy = Y0 - hy, rad = P.hole_in_optics;
+          const double tx = ix / sqrt(2.0) - iy / sqrt(2.0), ty = ix / sqrt(2.0) + iy / sqrt(2.0);
+          const double axx = fabs(ix), ayy = fabs(iy), atx = fabs(tx), aty = fabs(ty);
+          bool through = false;
+          switch (P.hole_type) {
+            case SART_HT_CIRCLE: through = sqrt(fma(ix, ix, iy * iy)) < rad; break;
+            case SART_HT_CROSS:
+              through = (axx < rad && ayy < rad * 16.0) || (ayy < rad && axx < rad * 16.0); break;
+            case SART_HT_STAR:
+              through = (axx < rad && ayy < rad * 16.0) || (ayy < rad && axx < rad * 16.0) ||
+                        (atx < rad && aty < rad * 16.0) || (aty < rad && atx < rad * 16.0); break;
+            case SART_HT_SQUARE: through = axx < rad && ayy < rad; break;
+            case SART_HT_DIAMOND: through = atx < rad && aty < rad; break;
+            default: through = false;
+          }
+          if (through) { res = false; break; } else res = true;
+        }
+        blocked = res;
+      } else {
+        blocked = true;   // htNone: the hole test is always false => blocked (:1683-1688, :527); Abrixas :1653
+      }
+    } else if (P.telescope_kind == SART_TK_XMM && radial < P.ring_hi && radial > P.ring_lo) {
+      blocked = true;     // :1691
+    } else {
+      // spider spokes, tested on phi = acos(x / r) at the entrance plane and at z = spider_z (:1695-1701);
+      // phi in [lo, hi]  <=>  cos(hi) <= x/r <= cos(lo)
+      const double c_ent = X0 / radial;
+      // pointEntranceSpider = pointExitCB + ((spider_z - z_cb) / v_z) v: the ray at z = spider_z
+      const double xs = fma(P.spider_z, tsx, X0), ys = fma(P.spider_z, tsy, Y0);
+      const double c_sp = xs / sqrt(fma(xs, xs, ys * ys));
+      for (int i = 0; i < P.n_spokes; ++i) {
+        const double lo = P.spoke_cos_lo[i], hi = P.spoke_cos_hi[i];
+        if ((c_ent >= lo && c_ent <= hi) || (c_sp >= lo && c_sp <= hi)) { blocked = true; break; }
+      }
+    }
+    if (blocked) return;
+  }
+
+  // ---- shell selection (:1932-1957) ----
+  const int nS = P.n_shells;
+  if (radial > P.shells[nS - 1].r1) return;
+  int hit_layer = -1;
+  for (int j = 0; j < nS; ++j) {
+    const double r1j = P.shells[j].r1;
+    if (radial > r1j && radial < P.shells[j].r1_outer) return;   // glass front (:1942-1944)
+    if (r1j - radial > 0.0) { hit_layer = j; break; }             // R1 ascending: first positive distance is the minimum
+  }
+  if (hit_layer < 0) return;   // radial == R1[last] exactly (measure zero; the reference then uses a zero shell)
+  S.n_shell++;
+  const ShellDev& sh = P.shells[hit_layer];
+  const double min_dist = sh.r1 - radial;
+
+  // ---- mirror 1 (:1985-1992 / :2012-2019) ----
+  const double D0 = fma(X0, tsx, Y0 * tsy);
+  const double A0 = fma(tsx, tsx, tsy * tsy);
+  const double L0 = 1.0 + A0;                 // |w|^2 of the un-normalised direction w = (tsx, tsy, 1)
+  double z1;
+  const bool hit1 = pick_root(A0 - sh.m1_k, D0 + sh.m1_hb, Q0 - sh.m1_cc, 0.0, sh.m1_zhi, z1);
+  if (!hit1) z1 = zcb;                        // the reference returns its input point (:656-658)
+  const double m1x = fma(z1, tsx, X0), m1y = fma(z1, tsy, Y0);
+  double n1z;
+  if (hit1) {
+    // on the surface the normal's z-component is closed-form: cone tan(b) rho(z); paraboloid r3 tan(b)
+    n1z = P.telescope_wolter ? sh.n1_r3t : sh.n1_tan * fma(-sh.n1_tan, z1, sh.r1);
+  } else {
+    n1z = normal_z_general(P, sh, 1, m1x, m1y, z1);
+  }
+  double wx = tsx, wy = tsy, wz = 1.0;
+  const double N1 = fma(m1x, m1x, fma(m1y, m1y, n1z * n1z));
+  const double sin2_a1 = reflect(wx, wy, wz, L0, m1x, m1y, n1z, N1);
+
+  // lineHitsNickel (:1706-1734), evaluated before the no-hit test (:2040-2057):
+  // tan(a1) > num / (l - z1)  <=>  sin^2(a1) ((l - z1)^2 + num^2) > num^2   (num, l - z1 > 0)
+  bool hit_nickel = false;
+  if (hit_layer > 0) {
+    const double lz = P.l_mirror - z1, num = sh.nickel_num;
+    if (lz > 0.0 && num >= 0.0) hit_nickel = sin2_a1 * fma(lz, lz, num * num) > num * num;
+    else hit_nickel = sqrt(sin2_a1 / (1.0 - sin2_a1)) > num / lz;
+  }
+  if (hit_nickel) {
+    S.n_nickel++;
+    if (RECORDS) rec->hitNickel = 1;
+    return;
+  }
+  if (!hit1) return;                          // almostEqual(z1, z0) (:2055)
+
+  // ---- mirror 2 (:1994-2001 / :2021-2028): ray through (m1x, m1y, z1) along w ----
+  const double inv_wz = 1.0 / wz;
+  const double s2x = wx * inv_wz, s2y = wy * inv_wz;
+  const double X1 = fma(-z1, s2x, m1x), Y1 = fma(-z1, s2y, m1y);   // extrapolated to z = 0
+  const double A1 = fma(s2x, s2x, s2y * s2y);
+  const double D1 = fma(X1, s2x, Y1 * s2y);
+  const double Q1 = fma(X1, X1, Y1 * Y1);
+  double z2;
+  const bool hit2 = pick_root(A1 - sh.m2_k, D1 + sh.m2_hb, Q1 - sh.m2_cc, sh.m2_zlo, sh.m2_zhi, z2);
+  if (!hit2) return;                          // almostEqual(z1, z2) (:2055)
+  const double m2x = fma(z2, s2x, X1), m2y = fma(z2, s2y, Y1);
+  double n2z;
+  if (P.telescope_wolter) n2z = sh.n2_r3t * fma(2.0 * (P.l_mirror - z2), sh.n2_invF, 1.0);
+  else n2z = sh.n2_tan * fma(-sh.n2_tan, z2 - sh.m2_zlo, sh.m2_rc);
+  const double N2 = fma(m2x, m2x, fma(m2y, m2y, n2z * n2z));
+  const double sin2_a2 = reflect(wx, wy, wz, L0, m2x, m2y, n2z, N2);
+
+  // ---- detector plane: getPointDetectorWindow (:797-814, :2070-2083) ----
+  const double pmx = fma(m2x, P.pipe_c, z2 * P.pipe_s) - P.d_cb_xray;
+  const double pmz = fma(z2, P.pipe_c, -m2x * P.pipe_s);
+  const double vx = fma(wx, P.pipe_c, wz * P.pipe_s);
+  const double vz = fma(wz, P.pipe_c, -wx * P.pipe_s);
+  const double inv_vz = 1.0 / vz;
+  const double nwin = (sh.dist_det - pmz) * inv_vz;
+  double pdx = fma(nwin, vx, pmx), pdy = fma(nwin, wy, m2y), pdz = sh.dist_det;
+
+  // yaw angle (:2101-2115): ya = deg(atan2(-v_z, -v_y)) + 90 = -deg(atan(v_y / v_z))
+  const double ya = -atan_small(tsy) * 57.29577951308232;
+
+  if (RECORDS) {
+    const double nend = (sh.dist_det_end - pmz) * inv_vz;
+    const double ddx = (nend - nwin) * vx, ddy = (nend - nwin) * wy;
+    rec->deviationDet = sqrt(fma(ddx, ddx, ddy * ddy));           // :2085-2088
+    rec->pointdataXBefore = X0;                                    // :2091-2094
+    rec->pointdataYBefore = Y0;
+    rec->pixvalsX = floor(X0 / (48.0 / 1400.0)) + 700.0;           // getPixelValue (:618-623)
+    rec->pixvalsY = floor(Y0 / (48.0 / 1400.0)) + 700.0;
+  }
+
+  // ---- weights (:2116-2128) ----
+  if (energy_pending) sample_energy();
+  const EnergyDev en = T.energy_tab[e_idx];
+  double trans_magnet;
+  {
+    double prob = 1.0;
+    double absorb = 1.0;
+    if (!P.stage_gas) {
+      if (!(A.flags & SART_CF_IGNORE_CONV_PROB)) prob = P.conv_k * path_cb * path_cb;   // conversionProb (:363-365)
+    } else {
+      // axionConversionProb2 / intensitySuppression2 (axionMassforMagnet.nim:75-113) with pathCB as length
+      const double Lnat = path_cb * P.gas_inv_hbarc_m;               // length / 1.97e-7, length in m
+      if (!(A.flags & SART_CF_IGNORE_CONV_PROB)) {
+        const double q = fabs((P.gas_m_gamma_sq - P.m_axion_sq) / en.two_e_ev);
+        const double g = en.gamma;
+        const double term2 = 1.0 / fma(q, q, g * g * 0.25);
+        const double term3 = 1.0 + exp(-g * Lnat) - 2.0 * exp(-g * Lnat * 0.5) * cos(q * Lnat);
+        prob = P.gas_term1 * term2 * term3;
+      }
+      const double distance_pipe_m = (pdz - zcb) * 1e-3;             // :2116
+      absorb = exp(-en.mu_pipe * distance_pipe_m) * exp(-en.mu_magnet * (path_cb * 1e-3));
+    }
+    trans_magnet = cos_small(ya) * prob * absorb;   // cos of a degree value taken as radians — sic (:1598)
+  }
+  double reflectv = 1.0, weight = trans_magnet;
+  if (!(A.flags & SART_CF_IGNORE_REFLECTION)) {
+    // computeReflectivity (:1533-1580): bilinear in (angle, energy); the energy interpolation is folded
+    // into the per-energy-index table, leaving a linear interpolation in the angle.
+    const double* tab = T.refl + ((size_t)P.shell_coating[hit_layer] * (size_t)(P.n_energies + 1) + (size_t)e_idx) *
+                                     (size_t)P.refl_n_angles;
+    auto refl_at = [&](double sin2a) {
+      const double alpha = asin_small(sqrt(sin2a)) * 57.29577951308232;   // getMirrorAngle (:782-795), degrees
+      const double t = (alpha - P.refl_angle_min) * P.refl_inv_dangle;
+      int i = (int)floor(t);
+      i = min(i, P.refl_n_angles - 2);
+      const double xu = (alpha - (P.refl_angle_min + (double)i * P.refl_dangle)) * P.refl_inv_dangle;
+      const double g0 = tab[i], g1 = tab[i + 1];
+      return fma(xu, g1 - g0, g0);
+    };
+    reflectv = refl_at(sin2_a1) * refl_at(sin2_a2);
+    weight = reflectv * trans_magnet;
+  }
+  if (RECORDS) {
+    rec->transmissionMagnet = trans_magnet;
+    rec->yawAngles = ya;
+    rec->reflect = reflectv;
+  }
+
+  if (P.test_active && min_dist > 100.0) {    // straight through the hole in the optics (:2130-2132)
+    pdx = fma(sh.dist_det_raw, tsx, X0);
+    pdy = fma(sh.dist_det_raw, tsy, Y0);
+    pdz = sh.dist_det_raw;
+  }
+  pdx -= P.lateral_shift;
+  pdy -= P.transversal_shift;
+  if (weight != 0.0) {
+    S.n_till_window++;
+    if (RECORDS) rec->passedTillWindow = 1;
+  }
+
+  // ---- detector window / chip (:2138-2147) ----
+  const double rdet2 = fma(pdx, pdx, pdy * pdy);
+  if (!(A.flags & SART_CF_IGNORE_DET_WINDOW) && rdet2 > P.radius_window_sq) return;
+  if (fabs(pdx) > P.chip_cx || fabs(pdy) > P.chip_cy) return;
+
+  // window strips (:2149-2187): rotateAroundZ by theta, strips along x
+  const double yt = fabs(fma(pdy, P.theta_c, -pdx * P.theta_s));
+  double trans_window = 0.0;
+  uint8_t kind_w = 0;
+  for (int i = 0; i < P.n_half_strips; ++i) {
+    if (yt > P.strip_lo[i] && yt < P.strip_hi[i]) { trans_window = en.t_strongback; kind_w = SART_MK_SI; break; }
+    trans_window = en.t_window;
+    kind_w = SART_MK_SI3N4;
+  }
+  if (!(A.flags & SART_CF_IGNORE_DET_WINDOW)) weight *= trans_window;
+  if (!(A.flags & SART_CF_IGNORE_GAS_ABS)) weight *= en.a_gas;       // :2190-2192
+  if (!(A.flags & SART_CF_XRAY_TEST)) weight *= P.exposure;           // :2207-2212
+
+  const double rdet = sqrt(rdet2);
+  const double px = -pdx + P.chip_cx, py = pdy + P.chip_cy;          // :2203-2204
+  if (RECORDS) {
+    if (P.n_half_strips > 0) {
+      rec->transProbWindow = trans_window;
+      rec->energiesAxWindow = en.energy;
+      rec->kindsWindow = kind_w;
+    }
+    rec->transProbArgon = en.a_gas;
+    rec->transProbDetector = en.a_gas;
+    rec->energiesAxAll = en.energy;
+    rec->kinds = SART_MK_AR;
+    rec->energiesAx = en.energy;
+    rec->shellNumber = hit_layer;
+    rec->pointdataR = rdet;
+    rec->pointdataX = px;
+    rec->pointdataY = py;
+    rec->weights = weight;
+    rec->weightsAll = weight;
+    rec->passed = (weight != 0.0) ? 1 : 0;
+  } else if (weight != 0.0) {
+    S.n_passed++;
+    S.sum_w += weight;
+    S.sum_w2 = fma(weight, weight, S.sum_w2);
+    S.sum_x += px;
+    S.sum_y += py;
+    S.sum_r += rdet;
+    // prepareHeatmap (:838-842): img[floor(y / step_y), floor(x / step_x)] += w
+    const double fx = floor((px - A.image_x_min) * A.image_inv_step_x);
+    const double fy = floor((py - A.image_y_min) * A.image_inv_step_y);
+    if (fx >= 0.0 && fx < (double)A.image_nx && fy >= 0.0 && fy < (double)A.image_ny) {
+      unsafeAtomicAdd(&acc[(size_t)((int)fy) * (size_t)A.image_nx + (size_t)((int)fx)], weight);
+    } else {
+      S.n_outside++;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+constexpr int kBlock = 256;
+
+// Fused trace + accumulate (traceAxionWrapper + prepareHeatmap + flux sum + counters).
+// Grid-stride over rays: ray i of this launch has the global id ray_id_offset + i.
+__global__ __launch_bounds__(kBlock) void trace_histogram_kernel(DevTables T, TraceArgs A, double* __restrict__ acc) {
+  __shared__ double lds_rcdf[2048];
+  const DevParams& P = *T.params;
+  for (int i = threadIdx.x; i < P.n_radii; i += kBlock) lds_rcdf[i] = T.flux_radius_cdf[i];
+  __syncthreads();
+
+  Scalars S;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < A.n_rays; i += stride) {
+    trace_one<false>(P, T, A, lds_rcdf, A.ray_id_offset + i, nullptr, acc, S);
+  }
+
+  // scalars: wave reduction, then one atomic per wave and quantity
+  double* sc = acc + (size_t)A.image_nx * (size_t)A.image_ny;
+  const double sw = wave_sum(S.sum_w), sw2 = wave_sum(S.sum_w2), sxx = wave_sum(S.sum_x), syy = wave_sum(S.sum_y),
+               srr = wave_sum(S.sum_r);
+  const uint32_t np = wave_sum_u32(S.n_passed), ntw = wave_sum_u32(S.n_till_window), nn = wave_sum_u32(S.n_nickel),
+                 nr = wave_sum_u32(S.n_reached), ns = wave_sum_u32(S.n_shell), no = wave_sum_u32(S.n_outside);
+  if ((threadIdx.x & 63) == 0) {
+    unsafeAtomicAdd(&sc[SART_ACC_SUM_WEIGHTS], sw);
+    unsafeAtomicAdd(&sc[SART_ACC_SUM_WEIGHTS_SQ], sw2);
+    unsafeAtomicAdd(&sc[SART_ACC_SUM_X], sxx);
+    unsafeAtomicAdd(&sc[SART_ACC_SUM_Y], syy);
+    unsafeAtomicAdd(&sc[SART_ACC_SUM_R], srr);
+    unsafeAtomicAdd(&sc[SART_ACC_N_PASSED], (double)np);
+    unsafeAtomicAdd(&sc[SART_ACC_N_PASSED_TILL_WINDOW], (double)ntw);
+    unsafeAtomicAdd(&sc[SART_ACC_N_HIT_NICKEL], (double)nn);
+    unsafeAtomicAdd(&sc[SART_ACC_N_REACHED_TELESCOPE], (double)nr);
+    unsafeAtomicAdd(&sc[SART_ACC_N_SHELL_SELECTED], (double)ns);
+    unsafeAtomicAdd(&sc[SART_ACC_N_OUTSIDE_IMAGE], (double)no);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) unsafeAtomicAdd(&sc[SART_ACC_N_RAYS], (double)A.n_rays);
+}
+
+// Literal drop-in for traceAxionWrapper: one Axion record per ray.
+__global__ __launch_bounds__(kBlock) void trace_records_kernel(DevTables T, TraceArgs A, sart_axion_t* __restrict__ out) {
+  __shared__ double lds_rcdf[2048];
+  const DevParams& P = *T.params;
+  for (int i = threadIdx.x; i < P.n_radii; i += kBlock) lds_rcdf[i] = T.flux_radius_cdf[i];
+  __syncthreads();
+
+  Scalars S;
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < A.n_rays; i += stride) {
+    sart_axion_t rec;
+    // newSeq[Axion] zero-initialises (:2760)
+    uint64_t* w = reinterpret_cast<uint64_t*>(&rec);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(sart_axion_t) / 8); ++k) w[k] = 0;
+    trace_one<true>(P, T, A, lds_rcdf, A.ray_id_offset + i, &rec, nullptr, S);
+    uint64_t* o = reinterpret_cast<uint64_t*>(out + i);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(sart_axion_t) / 8); ++k) o[k] = w[k];
+  }
+}
+
+// ---- launch wrappers (called from sart_api.hip) ----
+void launch_trace_histogram(const DevTables& T, const TraceArgs& A, double* acc, int n_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(trace_histogram_kernel, dim3(n_blocks), dim3(kBlock), 0, stream, T, A, acc);
+}
+void launch_trace_records(const DevTables& T, const TraceArgs& A, sart_axion_t* out, int n_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL(trace_records_kernel, dim3(n_blocks), dim3(kBlock), 0, stream, T, A, out);
+}
+int trace_block_size() { return kBlock; }
+
+}  // namespace sart

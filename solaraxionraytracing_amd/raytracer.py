@@ -1,0 +1,229 @@
+"""Host-side mirror of the reference's driver layer for the per-ray hot path, in the reference's
+vocabulary (src/raytracer.nim): ``initFullSetup`` -> ``FullRaytraceSetup``; ``traceAxionWrapper``;
+``calculateFluxFractions``; ``performAngularScan``.
+
+This module is plumbing: it builds the inputs (through the C++ host library) and calls the C-ABI of
+libsart.so.  All per-ray work happens in the HIP kernels; there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib, tables
+from ._lib import (AXION_DTYPE, Setup, Summary, TraceParams)  # noqa: F401
+
+
+def newFullSetup(experiment: int, detector: int, stage: int, telescope: int, flags: int = 0,
+                 magnet_cfg=None, source_cfg=None, install_cfg=None) -> Setup:
+    """newExperimentSetup + newDetectorSetup + module constants (raytracer.nim:1411-1423, :1464-1496, :248-272)."""
+    host = _lib.load_host()
+    s = Setup()
+    _lib.check(host.sart_host_new_full_setup(
+        experiment, detector, stage, telescope, flags,
+        C.byref(magnet_cfg) if magnet_cfg is not None else None,
+        C.byref(source_cfg) if source_cfg is not None else None,
+        C.byref(install_cfg) if install_cfg is not None else None, C.byref(s)), host=True)
+    return s
+
+
+@dataclass
+class FullRaytraceSetup:
+    """FullRaytraceSetup, raytracer.nim:232-242 (centerVecs are derived from ``setup`` by the callee)."""
+    setup: Setup
+    energies: np.ndarray            # [nE] keV
+    fluxRadiusCDF: np.ndarray       # [nR]
+    diffFluxCDFs: np.ndarray        # [nR][nE]
+    reflectivity: tables.ReflectivityGrid
+    detector_tables: tables.DetectorTables
+    flags: int = 0
+    outpath: str = "out"
+    meta: dict = field(default_factory=dict)
+
+
+def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_INGRIDIAXO,
+                  stage: int = _lib.SK_VACUUM, telescope: int = _lib.TK_XMM, flags: int = 0, *,
+                  emission: str | np.ndarray = "primakoff", n_radii: int = tables.N_RADII,
+                  n_energies: int = tables.N_ENERGIES, reflectivity: str | tables.ReflectivityGrid = "henke",
+                  refl_n_angles: int = 1000, refl_n_energies: int = 1000, solar_model_csv: str | None = None,
+                  magnet_cfg=None, source_cfg=None, install_cfg=None) -> FullRaytraceSetup:
+    """initFullSetup, raytracer.nim:2637-2753.  Defaults = config/config_default.toml:19-22
+    (BabyIAXO / InGridIAXO / vacuum / XMM).  ``emission`` / ``reflectivity`` choose the synthetic stand-ins of
+    tables.py when the reference's own input files are not available."""
+    setup = newFullSetup(experiment, detector, stage, telescope, flags, magnet_cfg, source_cfg, install_cfg)
+    if solar_model_csv is not None:
+        radii, energies, em = tables.read_solar_model_csv(solar_model_csv)
+        meta_em = "csv:" + solar_model_csv
+    else:
+        radii, energies = tables.solar_grid(n_radii, n_energies)
+        if isinstance(emission, np.ndarray):
+            em, meta_em = emission, "user"
+        elif emission == "primakoff":
+            em, meta_em = tables.primakoff_emission_table(n_radii, n_energies), "E1-primakoff-agss09"
+        elif emission == "flat":
+            em, meta_em = tables.flat_emission_table(n_radii, n_energies), "E3-flat"
+        else:
+            raise ValueError("unknown emission table %r" % (emission,))
+    rcdf, ecdf = tables.build_cdfs(em, radii, energies)
+    if isinstance(reflectivity, tables.ReflectivityGrid):
+        refl, meta_r = reflectivity, "user"
+    else:
+        multi = setup.reflectivity_kind == _lib.RK_MULTI_COATING
+        if reflectivity == "henke":
+            refl = (tables.llnl_reflectivity_grids if multi else tables.gold_reflectivity_grid)(refl_n_angles, refl_n_energies)
+            meta_r = "L1-henke-x4" if multi else "G1-henke-gold"
+        elif reflectivity == "gold":   # single gold table on every shell (BASELINE config 2)
+            refl, meta_r = tables.gold_reflectivity_grid(refl_n_angles, refl_n_energies), "G1-henke-gold"
+            if multi:
+                setup.reflectivity_kind = _lib.RK_SINGLE_COATING
+                setup.n_coatings = 1
+                setup.coating_layers[0] = setup.n_shells
+        elif reflectivity == "analytic":
+            refl = tables.analytic_reflectivity_grid(4 if multi else 1, refl_n_angles, refl_n_energies)
+            meta_r = "G2-analytic"
+        else:
+            raise ValueError("unknown reflectivity %r" % (reflectivity,))
+    det = tables.detector_tables()
+    return FullRaytraceSetup(setup, np.ascontiguousarray(energies), rcdf, ecdf, refl, det, flags,
+                             meta={"emission": meta_em, "reflectivity": meta_r})
+
+
+class RayTracer:
+    """One libsart context on one GPU holding the captures of ``traceAxionWrapper``
+    (raytracer.nim:2223-2232)."""
+
+    def __init__(self, full: FullRaytraceSetup, device: int = 0):
+        self.lib = _lib.load_sart()
+        self.full = full
+        h = C.c_void_p()
+        _lib.check(self.lib.sart_create(device, C.byref(h)))
+        self.handle = h
+        try:
+            self._upload(full)
+        except Exception:
+            self.close()
+            raise
+
+    def _upload(self, full: FullRaytraceSetup):
+        lib, h = self.lib, self.handle
+        _lib.check(lib.sart_set_setup(h, C.byref(full.setup)))
+        n_r, n_e = full.diffFluxCDFs.shape
+        _lib.check(lib.sart_set_solar_tables(h, _lib.as_dp(full.fluxRadiusCDF), _lib.as_dp(full.diffFluxCDFs),
+                                             _lib.as_dp(full.energies), n_r, n_e))
+        r = full.reflectivity
+        n_c, n_a, n_er = r.data.shape
+        _lib.check(lib.sart_set_reflectivity(h, n_c, n_a, n_er, r.angle_min, r.angle_max, r.energy_min, r.energy_max,
+                                             _lib.as_dp(r.data)))
+        d = full.detector_tables
+        _lib.check(lib.sart_set_detector_tables(h, _lib.as_dp(d.x_kev), _lib.as_dp(d.strongback), d.x_kev.size,
+                                                _lib.as_dp(d.x_kev), _lib.as_dp(d.window), d.x_kev.size,
+                                                _lib.as_dp(d.gas_x_kev), _lib.as_dp(d.gas_absorption), d.gas_x_kev.size))
+
+    # -- lifecycle ----------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sart_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameters ---------------------------------------------------------------------------
+    def trace_params(self, n_rays: int, seed: int = 299792458, ray_id_offset: int = 0, flags: int | None = None,
+                     image_n: int = 256, accumulate: bool = False) -> TraceParams:
+        s = self.full.setup
+        p = TraceParams()
+        p.n_rays, p.seed, p.ray_id_offset = int(n_rays), int(seed), int(ray_id_offset)
+        p.flags = self.full.flags if flags is None else flags
+        p.image_nx = p.image_ny = image_n
+        p.accumulate = 1 if accumulate else 0
+        p.image_x_min, p.image_x_max = 0.0, s.chip_x_max      # beginX/endX (raytracer.nim:2622-2625)
+        p.image_y_min, p.image_y_max = 0.0, s.chip_y_max
+        return p
+
+    def set_telescope_angles(self, turned_x_deg: float = float("nan"), turned_y_deg: float = float("nan")):
+        _lib.check(self.lib.sart_set_telescope_angles(self.handle, turned_x_deg, turned_y_deg))
+
+    def set_axion_mass(self, m_axion_ev: float):
+        _lib.check(self.lib.sart_set_axion_mass(self.handle, m_axion_ev))
+
+    def set_stream(self, hip_stream: int | None):
+        _lib.check(self.lib.sart_set_stream(self.handle, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        _lib.check(self.lib.sart_synchronize(self.handle))
+
+    # -- the hot path -------------------------------------------------------------------------
+    def traceAxionWrapper(self, bufLen: int, seed: int = 299792458, ray_id_offset: int = 0,
+                          flags: int | None = None) -> np.ndarray:
+        """traceAxionWrapper (raytracer.nim:2223-2244): ``bufLen`` Axion records (numpy structured array with
+        the reference's field names)."""
+        buf = np.zeros(bufLen, dtype=AXION_DTYPE)
+        p = self.trace_params(bufLen, seed, ray_id_offset, flags)
+        _lib.check(self.lib.sart_trace_records(self.handle, C.byref(p), buf.ctypes.data_as(C.c_void_p)))
+        return buf
+
+    def trace_histogram(self, n_rays: int, seed: int = 299792458, ray_id_offset: int = 0, flags: int | None = None,
+                        image_n: int = 256, accumulate: bool = False):
+        """Fused trace + prepareHeatmap(256,256,norm=1) + flux sum + counters.  Returns (image[ny][nx], summary
+        dict keyed like include/sart.h SART_ACC_*)."""
+        p = self.trace_params(n_rays, seed, ray_id_offset, flags, image_n, accumulate)
+        img = np.empty((image_n, image_n))
+        summ = Summary()
+        _lib.check(self.lib.sart_trace_histogram(self.handle, C.byref(p), _lib.as_dp(img), C.byref(summ)))
+        return img, {k: summ.v[i] for k, i in _lib.ACC.items()}
+
+    def trace_histogram_device(self, params: TraceParams, accumulator_ptr: int):
+        """Asynchronous form: adds into a device accumulator (e.g. ``torch_tensor.data_ptr()``)."""
+        _lib.check(self.lib.sart_trace_histogram_device(self.handle, C.byref(params), C.c_void_p(accumulator_ptr)))
+
+    # -- measurement --------------------------------------------------------------------------
+    def enable_kernel_timing(self, enable: bool = True):
+        _lib.check(self.lib.sart_enable_kernel_timing(self.handle, 1 if enable else 0))
+
+    def kernel_timing(self):
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(self.lib.sart_get_kernel_timing(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def device_info(self):
+        ncu, ws = C.c_int32(), C.c_int32()
+        name = C.create_string_buffer(256)
+        _lib.check(self.lib.sart_device_info(self.handle, C.byref(ncu), C.byref(ws), name, 256))
+        return {"n_cu": ncu.value, "wave_size": ws.value, "name": name.value.decode()}
+
+
+def accumulator_len(image_n: int = 256) -> int:
+    return image_n * image_n + _lib.SART_ACC_COUNT
+
+
+def calculateFluxFractions(tracer: RayTracer, n_rays: int = 1_000_000, seed: int = 299792458,
+                           ray_id_offset: int = 0):
+    """calculateFluxFractions (raytracer.nim:2755-2776) in histogram form: NumberOfPointsSun rays ->
+    256x256 focal-plane image (heatmaptable2, :2629) + counters (:2252-2257) + total flux (:885)."""
+    return tracer.trace_histogram(n_rays, seed, ray_id_offset)
+
+
+def performAngularScan(tracer: RayTracer, angularScanMin: float, angularScanMax: float, numAngularScanPoints: int = 50,
+                       n_rays_per_angle: int = 1_000_000, seed: int = 299792458, flags: int | None = None):
+    """performAngularScan (raytracer.nim:2778-2802) through the C++ host driver: returns (angles, fluxes,
+    relative fluxes)."""
+    host = _lib.load_host()
+    angles = np.linspace(angularScanMin, angularScanMax, numAngularScanPoints)
+    fluxes = np.empty_like(angles)
+    rel = np.empty_like(angles)
+    fl = tracer.full.flags if flags is None else flags
+    _lib.check(host.sart_host_perform_angular_scan(tracer.handle, _lib.as_dp(angles), angles.size, n_rays_per_angle,
+                                                   seed, 0, fl, _lib.as_dp(fluxes), _lib.as_dp(rel)), host=True)
+    return angles, fluxes, rel

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Builds the small input-data files under solaraxionraytracing_amd/data/ from the DATA files of
+the reference checkout (/root/reference/resources/*).  Only data is read — no reference source.
+
+Outputs (all numpy .npz, float64):
+  detector_tables.npz   raw columns of the four TSVs newDetectorSetup reads
+                        (raytracer.nim:1499-1506): Si3N4 0.3 um, Si 200 um, Al 0.02 um
+                        (shared energy axis, eV) and argon 30 mm / 1050 mbar (own axis).
+  gold_henke.npz        the 71 Henke gold 0.25 um angle scans of resources/reflectivity.zip:
+                        angles_deg[71], energy_ev[500], reflectivity[71][500].
+  solar_profile.npz     per-radius plasma quantities of the AGSS09 model
+                        (resources/AGSS09_solar_model_stripped.dat, 1968 rows):
+                        temperature, electron density, Debye scale - what an OPCD-free Primakoff
+                        emission table needs (formulas of readOpacityFile.nim:394-413, 681-690, 788-792).
+  reference_curves.npz  McXtrace / XMM angular effective-area curves the reference overlays
+                        (raytracer.nim:2805-2813).
+Run from the repo root:  python tools/make_data.py
+"""
+import io
+import os
+import re
+import sys
+import zipfile
+
+import numpy as np
+
+REF = os.environ.get("SART_REFERENCE", "/root/reference")
+RES = os.path.join(REF, "resources")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "solaraxionraytracing_amd", "data")
+
+
+def read_tsv(path):
+    return np.loadtxt(path, skiprows=1)
+
+
+def detector_tables():
+    sin = read_tsv(os.path.join(RES, "Si3N4Density=3.44Thickness=0.3microns.tsv"))
+    si = read_tsv(os.path.join(RES, "SiDensity=2.33Thickness=200.microns.tsv"))
+    al = read_tsv(os.path.join(RES, "AlDensity=2.7Thickness=0.02microns.tsv"))
+    ar = read_tsv(os.path.join(RES, "transmission-argon-30mm-1050mbar-295K.tsv"))
+    assert np.array_equal(sin[:, 0], si[:, 0]) and np.array_equal(si[:, 0], al[:, 0])
+    np.savez_compressed(os.path.join(OUT, "detector_tables.npz"), energy_ev=sin[:, 0], t_si3n4=sin[:, 1],
+                        t_si=si[:, 1], t_al=al[:, 1], argon_energy_ev=ar[:, 0], t_argon=ar[:, 1])
+
+
+def gold_henke():
+    zf = zipfile.ZipFile(os.path.join(RES, "reflectivity.zip"))
+    scans = {}
+    for name in zf.namelist():
+        m = re.match(r"reflectivity/([0-9.]+)degGold0\.25microns$", name)
+        if not m:
+            continue
+        arr = np.loadtxt(io.BytesIO(zf.read(name)), skiprows=1)
+        scans[float(m.group(1))] = arr
+    angles = np.array(sorted(scans))
+    e0 = scans[angles[0]][:, 0]
+    refl = np.stack([scans[a][:, 1] for a in angles])
+    for a in angles:
+        assert np.allclose(scans[a][:, 0], e0, rtol=0, atol=1e-6)
+    np.savez_compressed(os.path.join(OUT, "gold_henke.npz"), angles_deg=angles, energy_ev=e0, reflectivity=refl)
+
+
+ELEMENTS = ["H1", "He4", "He3", "C12", "C13", "N14", "N15", "O16", "O17", "O18", "Ne", "Na", "Mg", "Al", "Si",
+            "P", "S", "Cl", "Ar", "K", "Ca", "Sc", "Ti", "V", "Cr", "Mn", "Fe", "Co", "Ni"]
+# nuclear charge and atomic mass per column (isotopes listed separately in the model file)
+CHARGE = [1, 2, 2, 6, 6, 7, 7, 8, 8, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28]
+MASS = [1.007825, 4.002603, 3.016029, 12.0, 13.003355, 14.003074, 15.000109, 15.994915, 16.999132, 17.999160,
+        20.1797, 22.989769, 24.305, 26.981539, 28.0855, 30.973762, 32.065, 35.453, 39.948, 39.0983, 40.078,
+        44.955912, 47.867, 50.9415, 51.9961, 54.938045, 55.845, 58.933195, 58.6934]
+
+
+def solar_profile():
+    path = os.path.join(RES, "AGSS09_solar_model_stripped.dat")
+    header = open(path).readline().lstrip("#").split()
+    data = np.loadtxt(path, skiprows=1)
+    col = {n: data[:, i] for i, n in enumerate(header)}
+    amu = 1.6605e-24
+    rho, temp = col["Rho"], col["Temp"]
+    n_e = np.zeros_like(rho)
+    for name, z, a in zip(ELEMENTS, CHARGE, MASS):
+        n_e += (rho / amu) * z * col[name] / a          # 1/cm^3, full ionisation
+    n_h = col["H1"] / MASS[0] * rho / amu
+    n_he = (col["He4"] + col["He3"]) / ((MASS[1] * col["He4"] + MASS[2] * col["He3"]) / (col["He4"] + col["He3"])) * rho / amu
+    alpha = 1.0 / 137.0
+    temp_kev = temp * 8.617e-8
+    n_e_kev = n_e * 7.683e-24                             # keV^3
+    ks2 = (4.0 * np.pi * alpha / temp_kev) * (n_e_kev + n_h * 7.645e-24 + 4.0 * n_he * 7.645e-24)
+    np.savez_compressed(os.path.join(OUT, "solar_profile.npz"), radius=col["Radius"], temp_kev=temp_kev,
+                        n_e_kev3=n_e_kev, n_h_kev3=n_h * 7.645e-24, n_he_kev3=n_he * 7.645e-24, debye_ks2=ks2)
+
+
+def reference_curves():
+    mc = np.loadtxt(os.path.join(RES, "McXtrace_angular_xmm.csv"), delimiter=",", skiprows=1)
+    xmm = np.loadtxt(os.path.join(RES, "xmm_newton_angular_effective_area.csv"), delimiter=",", comments="#")
+    np.savez_compressed(os.path.join(OUT, "reference_curves.npz"), mcxtrace_angle_deg=mc[:, 0], mcxtrace_rel_flux=mc[:, 2],
+                        xmm_angle_arcmin=xmm[:, 0], xmm_effective_area=xmm[:, 1])
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    detector_tables()
+    gold_henke()
+    solar_profile()
+    reference_curves()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
