@@ -147,6 +147,11 @@ static real bilinear_r(const double* z, int32_t nx, int32_t ny, real xmin, real 
   long j = (long)M_FLOOR((y - ymin) / dy);
   if (i > nx - 2) i = nx - 2;
   if (j > ny - 2) j = ny - 2;
+  /* Below the grid the library indexes out of bounds (IndexDefect, or garbage with -d:danger) - the
+   * BabyIAXO test source's 0.021 keV (raytracer.nim:1377) is such a point.  Undefined in the
+   * reference; defined here (and in the HIP path) as extrapolation from the first cell. */
+  if (i < 0) i = 0;
+  if (j < 0) j = 0;
   real xCorner = xmin + (real)i * dx;
   real yCorner = ymin + (real)j * dy;
   real xUnit = (x - xCorner) / dx;

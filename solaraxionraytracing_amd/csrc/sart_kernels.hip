@@ -657,15 +657,9 @@ __global__ __launch_bounds__(kBlock) void trace_records_kernel(DevTables T, Trac
   Scalars S;
   const uint64_t stride = (uint64_t)gridDim.x * kBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < A.n_rays; i += stride) {
-    sart_axion_t rec;
-    // newSeq[Axion] zero-initialises (:2760)
-    uint64_t* w = reinterpret_cast<uint64_t*>(&rec);
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(sart_axion_t) / 8); ++k) w[k] = 0;
+    sart_axion_t rec = {};   // newSeq[Axion] zero-initialises (:2760)
     trace_one<true>(P, T, A, lds_rcdf, A.ray_id_offset + i, &rec, nullptr, S);
-    uint64_t* o = reinterpret_cast<uint64_t*>(out + i);
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(sart_axion_t) / 8); ++k) o[k] = w[k];
+    out[i] = rec;
   }
 }
 

@@ -1,0 +1,92 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, rays shard by global ray id, one reduce of
+the fused output accumulator (image + scalars) per image — RCCL over xGMI on the GPU box
+(``torch.distributed`` backend "nccl"), gloo in the CPU tests.
+
+The reference has no distributed layer (weave threads over one ``parallelFor``, raytracer.nim:2234);
+rays are independent, so the partition is a pure index split and the only exchange is the final sum.
+Because the Philox counter is the *global* ray id, the union of the shards is the same set of rays for
+any world size; results agree up to f64 summation order.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Tuple
+
+import numpy as np
+
+
+def shard_range(n_total: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Global ray ids [lo, hi) of ``rank``: contiguous blocks, remainder spread over the first ranks."""
+    base, rem = divmod(int(n_total), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_angles(n_angles: int, rank: int, world_size: int):
+    """Angle bins of an angular scan owned by ``rank`` (round-robin, performAngularScan :2791-2800 is a
+    loop over independent full runs)."""
+    return list(range(rank, n_angles, world_size))
+
+
+def init_process_group_from_env(backend: str | None = None):
+    """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).  Returns
+    (rank, world_size, local_rank).  world_size 1 needs no process group."""
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def reduce_accumulator(acc, dst: int | None = 0):
+    """The single collective of the path: sum the fused accumulator tensor over ranks (``dst`` = root rank, or
+    None for an all-reduce).  No-op without a process group."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return acc
+    if dst is None:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+    else:
+        dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM)
+    return acc
+
+
+def trace_sharded(trace_fn: Callable[[int, int], "np.ndarray"], n_total: int, rank: int, world_size: int,
+                  to_tensor: Callable | None = None, dst: int | None = 0):
+    """Runs ``trace_fn(ray_id_offset, n_rays) -> accumulator`` on this rank's shard of [0, n_total) and reduces.
+    ``trace_fn`` returns either a torch tensor (device accumulator on the GPU box) or a numpy array."""
+    import torch
+
+    lo, hi = shard_range(n_total, rank, world_size)
+    acc = trace_fn(lo, hi - lo)
+    if not isinstance(acc, torch.Tensor):
+        acc = torch.from_numpy(np.ascontiguousarray(acc)) if to_tensor is None else to_tensor(acc)
+    return reduce_accumulator(acc, dst)
+
+
+def gather_scan(values_local, indices_local, n_total: int):
+    """Angular scan sharded by angle bin: every rank holds the fluxes of its bins; returns the full curve on
+    every rank (one all-reduce of an n_total vector with zeros elsewhere)."""
+    import torch
+    import torch.distributed as dist
+
+    full = torch.zeros(n_total, dtype=torch.float64, device=values_local.device if isinstance(values_local, torch.Tensor) else "cpu")
+    vals = values_local if isinstance(values_local, torch.Tensor) else torch.as_tensor(np.asarray(values_local), dtype=torch.float64)
+    if len(indices_local):
+        full[torch.as_tensor(indices_local, dtype=torch.long, device=full.device)] = vals.to(full.device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(full, op=dist.ReduceOp.SUM)
+    return full

@@ -1,0 +1,73 @@
+"""world_size-2 gloo tests of the multi-GPU path's host logic (sharding by global ray id + the single reduce
+of the fused accumulator).  No GPU here, so the per-rank tracer is the CPU oracle standing in for libsart
+(the sharding / reduce code under test is the product's solaraxionraytracing_amd.distributed)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from solaraxionraytracing_amd import distributed as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 1000, 10 ** 9 + 7):
+        for w in (1, 2, 3, 8):
+            spans = [D.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert sorted(sum((D.shard_angles(16, r, 3) for r in range(3)), [])) == list(range(16))
+
+
+def _worker(rank, world, port, n_total, seed, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from tests.conftest import make_setup
+    from oracle.oracle import Oracle
+    r, w, _ = D.init_process_group_from_env("gloo")
+    assert (r, w) == (rank, world)
+    o = Oracle(make_setup("babyiaxo_xmm"))
+
+    def trace_fn(offset, n):   # stands in for RayTracer.trace_histogram_device on this rank's GPU
+        img, summ, _ = o.trace_histogram(n, seed=seed, ray_id_offset=offset, n_threads=2)
+        from solaraxionraytracing_amd import _lib
+        acc = np.zeros(img.size + _lib.SART_ACC_COUNT)
+        acc[:img.size] = img.ravel()
+        for k, i in _lib.ACC.items():
+            acc[img.size + i] = summ[k]
+        return acc
+
+    acc = D.trace_sharded(trace_fn, n_total, rank, world, dst=0)
+    # angle-bin sharding of a scan: each rank "measures" f(angle) for its bins
+    idx = D.shard_angles(7, rank, world)
+    curve = D.gather_scan(np.array([10.0 + i for i in idx]), idx, 7)
+    if rank == 0:
+        np.save(out_path, acc.numpy())
+        np.save(out_path + ".curve.npy", curve.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_trace_equals_single_process(tmp_path):
+    from tests.conftest import make_setup
+    from oracle.oracle import Oracle
+    from solaraxionraytracing_amd import _lib
+    n_total, seed = 30_001, 77
+    out = str(tmp_path / "acc.npy")
+    mp.spawn(_worker, args=(2, 29611, n_total, seed, out), nprocs=2, join=True)
+    acc = np.load(out)
+    img, summ, _ = Oracle(make_setup("babyiaxo_xmm")).trace_histogram(n_total, seed=seed)
+    n_img = img.size
+    # counts are exact; sums agree up to f64 summation order
+    for k in ("N_RAYS", "N_PASSED", "N_HIT_NICKEL", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_PASSED_TILL_WINDOW"):
+        assert acc[n_img + _lib.ACC[k]] == summ[k], k
+    assert acc[n_img + _lib.ACC["SUM_WEIGHTS"]] == pytest.approx(summ["SUM_WEIGHTS"], rel=1e-12)
+    np.testing.assert_allclose(acc[:n_img].reshape(img.shape), img, rtol=1e-12, atol=1e-30)
+    np.testing.assert_array_equal(np.load(out + ".curve.npy"), 10.0 + np.arange(7))

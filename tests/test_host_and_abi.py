@@ -1,0 +1,162 @@
+"""CPU tests of the host layer (C++ libsart_host) and of the C-ABI surface (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import solaraxionraytracing_amd as sa
+from solaraxionraytracing_amd import _lib as L, tables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sart_[a-z0-9_]+)\s*\(", txt)) - {"sart_accumulator_len"})
+
+
+def test_libsart_exports_every_declared_symbol():
+    lib = L.load_sart()
+    names = _declared("sart.h")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(L.SART_SYMBOLS) == names          # the ctypes table binds exactly the header
+    assert lib.sart_abi_version() == 1
+
+
+def test_libsart_host_exports_every_declared_symbol():
+    lib = L.load_host()
+    names = _declared("sart_host.h")
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(L.SART_HOST_SYMBOLS) == names
+
+
+def test_struct_sizes_match_c_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include "sart.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(sart_setup_t),'
+                   ' sizeof(sart_axion_t), sizeof(sart_trace_params_t), sizeof(sart_summary_t));return 0;}')
+    import subprocess
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(x) for x in out] == [C.sizeof(L.Setup), C.sizeof(L.Axion), C.sizeof(L.TraceParams), C.sizeof(L.Summary)]
+    assert C.sizeof(L.Axion) == 208
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="only meaningful without a GPU")
+def test_product_path_fails_loudly_without_gpu():
+    # no CPU fallback: creating a context without a device is an error, not a silent oracle run
+    lib = L.load_sart()
+    h = C.c_void_p()
+    rc = lib.sart_create(0, C.byref(h))
+    assert rc == L.SART_ERR_NO_DEVICE and not h.value
+    assert b"no HIP device" in lib.sart_last_error() or b"hip" in lib.sart_last_error().lower()
+    with pytest.raises(L.SartError):
+        sa.RayTracer(sa.initFullSetup(n_radii=50, n_energies=40, refl_n_angles=20, refl_n_energies=20))
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    import subprocess
+    for lib in ("libsart.so", "libsart_host.so"):
+        out = subprocess.run(["ldd", os.path.join(ROOT, "solaraxionraytracing_amd", lib)], capture_output=True, text=True).stdout
+        assert "oracle" not in out
+    for f in os.listdir(os.path.join(ROOT, "solaraxionraytracing_amd")):
+        if f.endswith(".py"):
+            assert "oracle" not in re.sub(r'""".*?"""', "", open(os.path.join(ROOT, "solaraxionraytracing_amd", f)).read(), flags=re.S).lower(), f
+
+
+def test_setup_constants_match_reference_tables():
+    # SURVEY Appendix A (raytracer.nim:1098-1155, 1256-1346, 1381-1407, 1464-1490, 248-272)
+    s = sa.newFullSetup(L.ES_BABYIAXO, L.DK_INGRIDIAXO, L.SK_VACUUM, L.TK_XMM)
+    assert (s.magnet_B, s.magnet_radiusCB, s.magnet_lengthColdbore, s.magnet_lengthB, s.magnet_tGas) == (2.0, 500.0, 11300.0, 11000.0, 100.0)
+    assert (s.pipe_cb_vt3_length, s.pipe_cb_vt3_radius, s.pipe_vt3_xrt_length, s.pipes_turned_deg) == (225.0, 370.0, 250.0, 0.0)
+    assert s.n_shells == 58 and s.all_r1[0] == 153.118 and s.all_r1[57] == 349.996 and s.all_r1[33] == 247.2855
+    assert s.all_angles_deg[0] == 0.29 and s.all_angles_deg[57] == 0.661 and s.all_thickness[0] == 0.468 and s.all_thickness[57] == 1.070
+    assert s.l_mirror == 300.0 and s.hole_in_optics == 0.2 and s.number_of_holes == 1 and s.hole_type == L.HT_NONE
+    assert s.distance_detector_xrt == 7500.0 and s.reflectivity_kind == L.RK_SINGLE_COATING
+    assert s.theta_rad == pytest.approx(np.deg2rad(20.0)) and s.radius_window == 7.0 and s.depth_det == 30.0
+    assert (s.distance_sun_earth, s.radius_sun, s.m_axion, s.g_agamma, s.chip_x_max) == (1.5e14, 6.9e11, 0.0853, 1e-12, 14.0)
+    assert (s.test_active, s.test_parallel, s.test_distance, s.test_radius, s.test_energy) == (0, 1, 2000.0, 350.0, 0.021)
+
+    c = sa.newFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, L.CF_XRAY_TEST)
+    assert (c.magnet_B, c.magnet_radiusCB, c.magnet_lengthColdbore, c.magnet_lengthB, c.magnet_tGas) == (9.0, 21.5, 9756.0, 9260.0, 1.7)
+    assert (c.pipe_cb_vt3_length, c.pipe_cb_vt3_radius, c.pipe_vt3_xrt_length, c.pipe_vt3_xrt_radius, c.pipes_turned_deg) == (127.66, 39.89, 111.7, 23.935, 2.75)
+    assert c.n_shells == 14 and list(c.all_r1[:14])[::13] == [63.006, 105.632] and c.all_xsep[8] == 4.306 and c.all_angles_deg[7] == 0.767
+    assert list(c.optics_entrance) == [-83.0, 0.0, 0.0] and c.l_mirror == 225.0 and c.hole_type == L.HT_CROSS
+    assert c.reflectivity_kind == L.RK_MULTI_COATING and list(c.coating_layers[:4]) == [2, 5, 9, 14]
+    assert c.distance_detector_xrt == 1485.0 and c.theta_rad == pytest.approx(np.deg2rad(30.0))
+    assert (c.test_active, c.test_distance, c.test_radius, c.test_off_axis_up, c.test_length_col, c.test_energy) == (1, 100.0, 10.0, 200.0, 50.0, 1.0)
+
+    a = sa.newFullSetup(L.ES_CAST, L.DK_INGRID2017, L.SK_VACUUM, L.TK_ABRIXAS)
+    assert a.n_shells == 27 and a.all_r1[0] == 38.125 and a.all_r1[26] == 81.443 and a.all_angles_deg[26] == 0.7120
+    assert list(a.optics_entrance) == [0.0, -60.0, 0.0] and a.l_mirror == 150.0 and a.distance_detector_xrt == 1600.0
+    assert (a.pipe_cb_vt3_length, a.pipe_cb_vt3_radius, a.pipe_vt3_xrt_length, a.pipe_vt3_xrt_radius) == (114.3, 66.65, 171.43, 47.62)
+
+
+def test_unsupported_telescopes_raise_like_the_reference():
+    # doAssert for tkCustomBabyIAXO (raytracer.nim:1233) and tkOther (:1348); ValueError for bad enums (:1027-1030)
+    for tk in (L.TK_CUSTOM_BABYIAXO, L.TK_OTHER):
+        with pytest.raises(L.SartError) as e:
+            sa.newFullSetup(L.ES_BABYIAXO, L.DK_INGRIDIAXO, L.SK_VACUUM, tk)
+        assert e.value.code == -4
+    with pytest.raises(L.SartError):
+        sa.newFullSetup(7, L.DK_INGRIDIAXO, L.SK_VACUUM, L.TK_XMM)
+
+
+def test_config_overrides():
+    # maybeParseMagnetConfig / TestXraySource / DetectorInstallation (raytracer.nim:1032-1096) with config_default.toml values
+    m = L.MagnetConfig(2.0, 350.0, 11300.0, 11000.0, 1.0, 100.0)
+    t = L.TestSourceConfig(1, 0, 1.0, 2000.0, 350.0, 0.0, 0.0, 0.125, 0.021)
+    d = L.DetectorInstallConfig(1485.0, 0.0, 0.0, 0.0)
+    s = sa.newFullSetup(L.ES_BABYIAXO, L.DK_INGRIDIAXO, L.SK_VACUUM, L.TK_XMM, 0, m, t, d)
+    assert s.magnet_radiusCB == 350.0 and s.test_active == 1 and s.test_parallel == 0 and s.test_length_col == 0.021
+    assert s.distance_detector_xrt == 1485.0
+
+
+def test_build_cdfs_matches_numpy():
+    rng = np.random.default_rng(5)
+    n_r, n_e = 37, 53
+    em = rng.random((n_r, n_e)) + 0.01
+    radii, energies = tables.solar_grid(n_r, n_e)
+    rcdf, ecdf = tables.build_cdfs(em, radii, energies)
+    diff = em * energies[None, :] ** 2 * radii[:, None] ** 2          # raytracer.nim:2686
+    cs = np.cumsum(diff, axis=1)
+    np.testing.assert_allclose(ecdf, cs / cs[:, -1:], rtol=1e-13)
+    rs = np.cumsum(cs[:, -1])
+    np.testing.assert_allclose(rcdf, rs / rs[-1], rtol=1e-13)
+    assert np.all(ecdf[:, -1] == 1.0) and rcdf[-1] == 1.0 and np.all(np.diff(rcdf) >= 0)
+
+
+def test_default_tables_are_valid():
+    full = sa.initFullSetup()
+    assert full.diffFluxCDFs.shape == (1968, 1500) and full.fluxRadiusCDF.shape == (1968,)
+    assert np.all(full.diffFluxCDFs[:, -1] == 1.0) and np.all(np.diff(full.diffFluxCDFs, axis=1) >= 0)
+    assert full.energies[0] == pytest.approx(1e-3) and full.energies[-1] == 15.0
+    # solar core dominates: half of the flux from within ~0.15 R_sun
+    assert 0.05 < 0.0015 + 0.0005 * np.searchsorted(full.fluxRadiusCDF, 0.5) < 0.25
+    r = full.reflectivity
+    assert r.data.shape == (1, 1000, 1000) and 0.0 <= r.data.min() and r.data.max() <= 1.0
+    d = full.detector_tables
+    assert d.x_kev[0] == 0.0 and d.x_kev[-1] == 15.0 and d.gas_x_kev[-1] == 15.0
+    assert np.all((d.window >= 0) & (d.window <= 1)) and np.all((d.gas_absorption >= 0) & (d.gas_absorption <= 1))
+    llnl = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, n_radii=60, n_energies=50,
+                            refl_n_angles=30, refl_n_energies=30)
+    assert llnl.reflectivity.data.shape[0] == 4
+
+
+def test_solar_csv_reader_roundtrip(tmp_path):
+    radii, energies = tables.solar_grid(5, 7)
+    em = np.arange(35, dtype=float).reshape(5, 7) + 1
+    p = tmp_path / "solar_model_dataframe.csv"
+    with open(p, "w") as f:
+        f.write("Radius,Energy [keV],emRates\n")
+        for i, r in enumerate(radii):
+            for j, e in enumerate(energies):
+                f.write("%s,%s,%s\n" % (repr(float(r)), repr(float(e)), repr(float(em[i, j]))))
+    r2, e2, em2 = tables.read_solar_model_csv(str(p))
+    np.testing.assert_array_equal(r2, radii); np.testing.assert_array_equal(e2, energies); np.testing.assert_array_equal(em2, em)

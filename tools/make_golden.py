@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz with the CPU oracle (oracle/libsart_oracle.so, f64).
+
+The reference (Nim) cannot be run in the build image, so these vectors pin *HIP path vs oracle* and guard
+the oracle against regressions; oracle vs reference is pinned by tests/test_oracle_known_answers.py.
+Inputs are the deterministic synthetic tables of solaraxionraytracing_amd.tables at the SMALL sizes of
+tests/conftest.py.  Run from the repo root:  python tools/make_golden.py
+"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from tests.conftest import make_setup, SETUP_NAMES
+from oracle.oracle import Oracle
+
+N_REC, N_HIST, SEED = 4000, 100_000, 2024
+FIELDS = ["passed", "passedTillWindow", "hitNickel", "pointdataX", "pointdataY", "pointdataR", "weights",
+          "transmissionMagnet", "yawAngles", "reflect", "deviationDet", "pointdataXBefore", "pointdataYBefore",
+          "energiesAx", "energiesPre", "emratesPre", "transProbWindow", "transProbArgon", "shellNumber", "kindsWindow"]
+
+out_dir = os.path.join(ROOT, "tests", "golden")
+os.makedirs(out_dir, exist_ok=True)
+for name in SETUP_NAMES:
+    full = make_setup(name)
+    o = Oracle(full)
+    rec = o.trace_records(N_REC, seed=SEED)
+    img, summ, _ = o.trace_histogram(N_HIST, seed=SEED)
+    data = {"rec_" + f: rec[f] for f in FIELDS}
+    data["summary_keys"] = np.array(sorted(summ))
+    data["summary_vals"] = np.array([summ[k] for k in sorted(summ)])
+    # coarse image (32x32 blocks of the 256x256 image) - robust against single-pixel edge flips
+    data["image_coarse"] = img.reshape(32, 8, 32, 8).sum(axis=(1, 3))
+    data["inputs_checksum"] = np.array([full.fluxRadiusCDF.sum(), full.diffFluxCDFs.sum(), full.reflectivity.data.sum(),
+                                        full.detector_tables.window.sum()])
+    data["meta"] = np.array([N_REC, N_HIST, SEED, full.flags])
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **data)
+    print(name, "passed", int(rec["passed"].sum()), "/", N_REC, "flux", summ["SUM_WEIGHTS"])
