@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,9 +17,14 @@
 #include "sart_device.h"
 
 namespace sart {
-void launch_trace_histogram(const DevTables& T, const TraceArgs& A, double* acc, int n_blocks, hipStream_t stream);
-void launch_trace_records(const DevTables& T, const TraceArgs& A, sart_axion_t* out, int n_blocks, hipStream_t stream);
-int trace_block_size();
+void launch_trace_histogram(const DevParams& P, const DevTables& T, const TraceArgs& A, double* acc, int n_blocks,
+                            hipStream_t stream);
+void launch_trace_records(const DevParams& P, const DevTables& T, const TraceArgs& A, sart_axion_t* out, int n_blocks,
+                          hipStream_t stream);
+void set_histogram_block(int block);
+int histogram_block();
+int records_block();
+int histogram_blocks_per_cu(int block);
 }  // namespace sart
 
 using namespace sart;
@@ -102,8 +108,12 @@ struct sart_context {
   std::vector<double> sb_x, sb_y, win_x, win_y, gas_x, gas_y;
 
   // device state
-  DevParams params;  // host mirror
-  DevBuf<DevParams> d_params;
+  DevParams params;  // passed by value to every launch
+  std::vector<ShellDev> shells;
+  std::vector<uint8_t> shell_lut;
+  int radius_span = 0;
+  DevBuf<ShellDev> d_shells;
+  DevBuf<uint8_t> d_lut;
   DevBuf<double> d_rcdf, d_ecdf, d_refl;
   DevBuf<uint16_t> d_rguide, d_eguide;
   DevBuf<EnergyDev> d_etab;
@@ -135,6 +145,7 @@ int hoist_setup(sart_context* c) {
   P.pipe1_radius_sq = s.pipe_cb_vt3_radius * s.pipe_cb_vt3_radius;
   P.n_radii = c->n_radii;
   P.n_energies = c->n_energies;
+  P.radius_span = c->radius_span;
   // X-ray test source, initCenterVectors raytracer.nim:305-311
   P.test_active = s.test_active;
   P.test_parallel = s.test_parallel;
@@ -161,23 +172,16 @@ int hoist_setup(sart_context* c) {
   P.entrance_x = s.optics_entrance[0];
   P.entrance_y = s.optics_entrance[1];
   // opaque structures, :1635-1704
-  double spoke_step = 0.0, spoke_half = 0.0;
-  int spoke_count = 0;
+  P.spoke_n = 16;
+  P.spoke_cos_thr = 2.0;
   if (s.telescope_kind == SART_TK_XMM) {
+    // 17 bands at i * 22.5 deg +- 1.145 deg on phi in [0, 180] (:1695-1699) = 16 spokes around the circle
     P.spider_z = -85.0; P.inner_radius = 64.7; P.ring_lo = 151.6 - 20.9; P.ring_hi = 151.6;
-    spoke_step = 22.5; spoke_half = 1.145; spoke_count = 17;
+    P.spoke_n = 16; P.spoke_cos_thr = std::cos(deg2rad(16.0 * 1.145));
   } else if (s.telescope_kind == SART_TK_ABRIXAS) {
+    // 7 bands at i * 60 deg +- 3.75 deg (:1657-1660) = 6 spokes around the circle
     P.spider_z = -35.0; P.inner_radius = 37.5; P.ring_lo = 0.0; P.ring_hi = 0.0;
-    spoke_step = 60.0; spoke_half = 3.75; spoke_count = 7;
-  }
-  P.n_spokes = 0;
-  for (int i = 0; i < spoke_count; ++i) {
-    const double lo = -spoke_half + spoke_step * i, hi = spoke_half + spoke_step * i;
-    if (lo > 180.0) break;  // phi = acos(..) never exceeds 180 deg
-    if (P.n_spokes >= 12) return fail(SART_ERR_INTERNAL, "too many spider spokes");
-    P.spoke_cos_hi[P.n_spokes] = (lo <= 0.0) ? 2.0 : std::cos(deg2rad(lo));
-    P.spoke_cos_lo[P.n_spokes] = (hi >= 180.0) ? -2.0 : std::cos(deg2rad(hi));
-    P.n_spokes++;
+    P.spoke_n = 6; P.spoke_cos_thr = std::cos(deg2rad(6.0 * 3.75));
   }
   P.hole_type = s.hole_type;
   P.number_of_holes = s.number_of_holes;
@@ -229,17 +233,13 @@ int hoist_setup(sart_context* c) {
     P.refl_dangle = (c->refl_amax - c->refl_amin) / static_cast<double>(c->refl_na - 1);
     P.refl_inv_dangle = 1.0 / P.refl_dangle;
   }
-  for (int j = 0; j < s.n_shells; ++j) {
-    int coat = 0;
-    if (s.reflectivity_kind == SART_RK_MULTI_COATING) {
-      // layers.lowerBound(hitLayer) :1573 (first boundary >= hitLayer)
-      coat = static_cast<int>(std::lower_bound(s.coating_layers, s.coating_layers + s.n_coatings, j) - s.coating_layers);
-    }
-    P.shell_coating[j] = coat;
-  }
   // shells
+  c->shells.assign(static_cast<size_t>(s.n_shells), ShellDev{});
   for (int j = 0; j < s.n_shells; ++j) {
-    ShellDev& sh = P.shells[j];
+    ShellDev& sh = c->shells[j];
+    sh.coating = 0;
+    if (s.reflectivity_kind == SART_RK_MULTI_COATING)  // layers.lowerBound(hitLayer) :1573 (first boundary >= hitLayer)
+      sh.coating = static_cast<int>(std::lower_bound(s.coating_layers, s.coating_layers + s.n_coatings, j) - s.coating_layers);
     const double r1 = s.all_r1[j], l = s.l_mirror, xSep = s.all_xsep[j];
     const double beta = deg2rad(s.all_angles_deg[j]), beta3 = 3.0 * beta;
     const double distanceMirrors = std::cos(beta) * (xSep + l);  // :1973
@@ -288,6 +288,27 @@ int hoist_setup(sart_context* c) {
     sh.dist_det = distDet / std::cos(pipeRad);
     sh.dist_det_end = (distDet + s.depth_det) / std::cos(pipeRad);
     sh.nickel_num = (j > 0) ? (r1 - (s.all_r1[j - 1] + s.all_thickness[j - 1])) : 0.0;  // :1722
+  }
+  // radial look-up table of the shell selection: cell k = [k step, (k+1) step) -> first shell with R1 > k step;
+  // step is below the smallest shell spacing, so the answer is lut[k] or lut[k] + 1
+  {
+    double min_gap = s.all_r1[0];
+    for (int j = 1; j < s.n_shells; ++j) min_gap = std::min(min_gap, s.all_r1[j] - s.all_r1[j - 1]);
+    const double r_last = s.all_r1[s.n_shells - 1];
+    double step = std::min(1.0, 0.5 * min_gap);
+    step = std::max(step, r_last / (kShellLutMax - 2));
+    if (!(step < min_gap)) return fail(SART_ERR_UNSUPPORTED, "shell radii too dense for the shell look-up table");
+    P.r1_last = r_last;
+    P.lut_inv_step = 1.0 / step;
+    P.lut_n = static_cast<int>(r_last / step) + 2;
+    c->shell_lut.assign(static_cast<size_t>(P.lut_n), 0);
+    for (int k = 0; k < P.lut_n; ++k) {
+      // a little below k*step so that rounding of radial * inv_step can never skip a shell
+      const double lo = std::max(0.0, (k - 1e-9) * step);
+      int j = 0;
+      while (j < s.n_shells && !(s.all_r1[j] > lo)) ++j;
+      c->shell_lut[k] = static_cast<uint8_t>(j);
+    }
   }
   return 0;
 }
@@ -353,7 +374,8 @@ int refresh_derived(sart_context* c) {
   if (s.reflectivity_kind == SART_RK_MULTI_COATING && c->refl_nc < s.n_coatings)
     return fail(SART_ERR_INVALID_ARGUMENT, "multi-coating telescope needs one reflectivity grid per coating");
   if (int rc = hoist_setup(c)) return rc;
-  if (int rc = c->d_params.upload(&c->params, 1)) return rc;
+  if (int rc = c->d_shells.upload(c->shells.data(), c->shells.size())) return rc;
+  if (int rc = c->d_lut.upload(c->shell_lut.data(), c->shell_lut.size())) return rc;
   if (int rc = hoist_energy_tables(c)) return rc;
   if (int rc = hoist_reflectivity(c)) return rc;
   c->derived_dirty = false;
@@ -381,7 +403,8 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
 
 DevTables tables_of(sart_context* c) {
   DevTables t;
-  t.params = c->d_params.p;
+  t.shells = c->d_shells.p;
+  t.shell_lut = c->d_lut.p;
   t.flux_radius_cdf = c->d_rcdf.p;
   t.radius_guide = c->d_rguide.p;
   t.diff_flux_cdfs = c->d_ecdf.p;
@@ -391,8 +414,8 @@ DevTables tables_of(sart_context* c) {
   return t;
 }
 
-int grid_for(uint64_t n_rays, int n_cu, int blocks_per_cu) {
-  const uint64_t bs = static_cast<uint64_t>(trace_block_size());
+int grid_for(uint64_t n_rays, int n_cu, int blocks_per_cu, int block) {
+  const uint64_t bs = static_cast<uint64_t>(block);
   const uint64_t need = (n_rays + bs - 1) / bs;
   const uint64_t cap = static_cast<uint64_t>(n_cu) * static_cast<uint64_t>(std::max(1, blocks_per_cu));
   return static_cast<int>(std::max<uint64_t>(1, std::min(need, cap)));
@@ -480,6 +503,9 @@ int sart_set_setup(sart_context* c, const sart_setup_t* s) {
     return fail(SART_ERR_INVALID_ARGUMENT, "n_shells must be in [9, 64] (allXsep[8] is read, raytracer.nim:2070)");
   for (int j = 1; j < s->n_shells; ++j)
     if (!(s->all_r1[j] > s->all_r1[j - 1])) return fail(SART_ERR_INVALID_ARGUMENT, "all_r1 must be strictly ascending");
+  for (int j = 0; j + 1 < s->n_shells; ++j)
+    if (!(s->all_thickness[j] >= 0.0 && s->all_r1[j] + s->all_thickness[j] < s->all_r1[j + 1]))
+      return fail(SART_ERR_INVALID_ARGUMENT, "shell glass must be thinner than the spacing to the next shell");
   if (s->reflectivity_kind != SART_RK_SINGLE_COATING && s->reflectivity_kind != SART_RK_MULTI_COATING)
     return fail(SART_ERR_UNSUPPORTED, "rkEffectiveArea is unreachable in the reference (raytracer.nim:1347) and not supported");
   if (s->n_coatings < 1 || s->n_coatings > SART_MAX_COATINGS) return fail(SART_ERR_INVALID_ARGUMENT, "n_coatings out of range");
@@ -507,11 +533,8 @@ int sart_set_telescope_angles(sart_context* c, double tx, double ty) {
   if (!std::isnan(tx)) c->setup.telescope_turned_x_deg = tx;
   if (!std::isnan(ty)) c->setup.telescope_turned_y_deg = ty;
   if (c->derived_dirty) return 0;
-  // cheap path: only the geometry block changes
-  SART_HIP(hipSetDevice(c->device));
-  SART_HIP(hipStreamSynchronize(c->stream));
-  if (int rc = hoist_setup(c)) return rc;
-  return c->d_params.upload(&c->params, 1);
+  // cheap path: only the kernel-argument block changes (the shell table does not depend on the angles)
+  return hoist_setup(c);
 }
 
 int sart_set_axion_mass(sart_context* c, double m) {
@@ -519,10 +542,8 @@ int sart_set_axion_mass(sart_context* c, double m) {
   if (!c->have_setup) return fail(SART_ERR_NOT_READY, "no setup");
   c->setup.m_axion = m;
   if (c->derived_dirty) return 0;
-  SART_HIP(hipSetDevice(c->device));
-  SART_HIP(hipStreamSynchronize(c->stream));
-  c->params.m_axion_sq = m * m;
-  return c->d_params.upload(&c->params, 1);
+  c->params.m_axion_sq = m * m;   // travels with the next launch's kernel arguments
+  return 0;
 }
 
 int sart_set_solar_tables(sart_context* c, const double* rcdf, const double* ecdf, const double* energies, int32_t nR,
@@ -539,6 +560,9 @@ int sart_set_solar_tables(sart_context* c, const double* rcdf, const double* ecd
   std::vector<uint16_t> rg(kRadiusGuide + 1);
   for (int k = 0; k <= kRadiusGuide; ++k)
     rg[k] = static_cast<uint16_t>(std::min<size_t>(lower_bound_idx(rcdf, nR, static_cast<double>(k) / kRadiusGuide), nR - 1));
+  int span = 0;
+  for (int k = 0; k < kRadiusGuide; ++k) span = std::max(span, static_cast<int>(rg[k + 1]) - static_cast<int>(rg[k]));
+  c->radius_span = span;
   std::vector<uint16_t> eg(static_cast<size_t>(nR) * (kEnergyGuide + 1));
   for (int r = 0; r < nR; ++r) {
     const double* row = ecdf + static_cast<size_t>(r) * nE;
@@ -599,7 +623,8 @@ int sart_trace_records_device(sart_context* c, const sart_trace_params_t* p, sar
   if (c->blocks_per_cu_rec == 0) c->blocks_per_cu_rec = 4;
   {
     TimedLaunch tl(c);
-    launch_trace_records(tables_of(c), a, out_dev, grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_rec), c->stream);
+    launch_trace_records(c->params, tables_of(c), a, out_dev,
+                         grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_rec, records_block()), c->stream);
   }
   SART_HIP(hipGetLastError());
   return 0;
@@ -625,10 +650,15 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   if (!p->accumulate)
     SART_HIP(hipMemsetAsync(acc_dev, 0, sart_accumulator_len(p->image_nx, p->image_ny) * sizeof(double), c->stream));
   if (a.n_rays == 0) return 0;
-  if (c->blocks_per_cu_hist == 0) c->blocks_per_cu_hist = 8;
+  if (c->blocks_per_cu_hist == 0) {
+    if (const char* e = std::getenv("SART_HIST_BLOCK")) set_histogram_block(std::atoi(e));   // tuning knob
+    c->blocks_per_cu_hist = std::max(1, histogram_blocks_per_cu(histogram_block()));
+    if (const char* e = std::getenv("SART_HIST_BLOCKS_PER_CU")) c->blocks_per_cu_hist = std::max(1, std::atoi(e));
+  }
   {
     TimedLaunch tl(c);
-    launch_trace_histogram(tables_of(c), a, acc_dev, grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_hist), c->stream);
+    launch_trace_histogram(c->params, tables_of(c), a, acc_dev,
+                           grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_hist, histogram_block()), c->stream);
   }
   SART_HIP(hipGetLastError());
   return 0;

@@ -1,17 +1,26 @@
 // sart_device.h — PODs shared by the host side of libsart (sart_api.hip) and the gfx950 kernels
-// (sart_kernels.hip).  Everything here is *derived* from sart_setup_t + the tables by
-// hoist_setup() in sart_api.hip: per-setup / per-shell / per-energy-index constants are
-// evaluated once on the host with the reference's formulas (cited there) so that the per-ray
-// kernel contains no setup-only transcendental.
+// (sart_kernels.hip).  Everything here is *derived* from sart_setup_t + the tables by the hoist_*
+// functions of sart_api.hip: per-setup / per-shell / per-energy-index constants are evaluated once on
+// the host with the reference's formulas (cited there) so that the per-ray kernel contains no
+// setup-only transcendental.
+//
+// Where the data lives on the device:
+//   DevParams        by value in the kernel arguments (scalar registers; loop-invariant)
+//   ShellDev[], shell LUT, fluxRadiusCDF + its guide table
+//                    HBM -> staged into LDS once per workgroup (coalesced loads)
+//   diffFluxCDFs (23.6 MB), its guide table, EnergyDev[], reflectivity (12 MB / coating)
+//                    HBM, served by L2 / Infinity Cache (random, dependent gathers)
 #pragma once
 #include <stdint.h>
 
 namespace sart {
 
 constexpr int kMaxShells = 64;
-constexpr int kMaxStrips = 32;       // half the number of window strips that are looped over
+constexpr int kMaxStrips = 16;       // half the number of window strips that are looped over
 constexpr int kRadiusGuide = 2048;   // buckets of the guide table in front of fluxRadiusCDF
 constexpr int kEnergyGuide = 256;    // buckets per radius row in front of diffFluxCDFs
+constexpr int kShellLutMax = 1024;   // cells of the radial look-up table of the shell selection
+constexpr int kMaxRadii = 2048;      // fluxRadiusCDF entries that fit the LDS stage
 
 // Per-shell constants (Wolter-I pair j).  Quadratics are expressed in the telescope frame with
 // the ray parametrised by z:  X(z) = X0 + sx z,  Y(z) = Y0 + sy z, so that with
@@ -37,7 +46,11 @@ struct ShellDev {
   double dist_det_raw;                 // distDet before the 1/cos (xray-test straight-through, :2131)
   // lineHitsNickel (raytracer.nim:1722): r1 - (R1[j-1] + t[j-1]); unused for j == 0
   double nickel_num;
+  // reflectivity grid of this shell: layers.lowerBound(j) (raytracer.nim:1573)
+  int32_t coating;
+  int32_t _pad;
 };
+static_assert(sizeof(ShellDev) % 8 == 0, "ShellDev is staged into LDS as 8-byte words");
 
 // Per-energy-index constants: the energy of a ray is one of the n_energies table values
 // (raytracer.nim:470-471: energies[idx], clamped to >= 0.03 keV), so every E-only factor is a table.
@@ -48,18 +61,21 @@ struct EnergyDev {
   double t_strongback; // strongbackTransmission.eval(E)  (:2170)
   double a_gas;        // gasAbsorption.eval(E)           (:2190)
   // gas stage (axionMassforMagnet.nim:75-113)
-  double gamma;        // Γ(E) in eV
+  double gamma;        // Gamma(E) in eV
   double two_e_ev;     // 2 * E[eV]  (momentumTransfer denominator)
   double mu_pipe;      // massAtt * rhoPipe   * 100   [1/m]
   double mu_magnet;    // massAtt * rhoMagnet * 100   [1/m]
 };
 
+// Loop-invariant scalars, passed by value as a kernel argument.
 struct DevParams {
   // ---- sampling (raytracer.nim:412-471) ----
   double sun_distance, sun_radius;
   double radius_cb, radius_cb_sq, length_b, length_coldbore;
   double pipe1_len, pipe2_len, pipe1_radius_sq;
   int32_t n_radii, n_energies;
+  int32_t radius_span;        // max entries of fluxRadiusCDF between two guide marks (bounded search length)
+  int32_t _pad0;
   // ---- X-ray test source (raytracer.nim:1765-1806) ----
   int32_t test_active, test_parallel;
   double test_x, test_y, test_z, test_radius, test_radius_sq, test_collimator_z;
@@ -70,14 +86,18 @@ struct DevParams {
   double l_mirror;
   double rx_c, rx_s, ry_c, ry_s, half_length_telescope;
   double entrance_x, entrance_y;
+  // ---- shell selection (raytracer.nim:1932-1957) ----
+  double r1_last;             // allR1[^1]
+  double lut_inv_step;
+  int32_t lut_n, _pad1;
   // ---- opaque structures (raytracer.nim:1635-1704) ----
   double spider_z;            // -85 (XMM) / -35 (Abrixas)
   double inner_radius;        // XMM: 64.7 (<=) ; Abrixas: 37.5 (<)
   double ring_lo, ring_hi;    // XMM: 130.7 .. 151.6 (exclusive)
-  int32_t n_spokes;           // bands actually reachable with phi in [0, 180]
-  int32_t inner_blocks;       // XMM: result of the hole loop for r <= 64.7 when it is ray-independent (-1: evaluate)
-  double spoke_cos_lo[12];    // cos(centre + half width)
-  double spoke_cos_hi[12];    // cos(centre - half width)
+  // spokes every 360/spoke_n degrees, half width w:  blocked <=> cos(spoke_n phi) >= cos(spoke_n w)
+  int32_t spoke_n;            // 16 (XMM: 22.5 deg) | 6 (Abrixas: 60 deg)
+  int32_t inner_blocks;       // XMM: 1 if the hole loop always blocks (htNone), -1: evaluate it
+  double spoke_cos_thr;
   int32_t hole_type, number_of_holes;
   double hole_in_optics;
   // ---- detector plane (raytracer.nim:797-814, 2133-2204) ----
@@ -90,19 +110,18 @@ struct DevParams {
   // ---- weights (raytracer.nim:363-365, 1582-1625, 2207-2212) ----
   double conv_k;              // P(a->gamma) = conv_k * pathCB^2 (vacuum)
   double exposure;            // 3.585e3*3600*1.5*90 | 9.5e6*3600*12*90
-  double gas_m_gamma_sq, gas_term1, gas_inv_hbarc_m;   // m_gamma^2, (g B / 2)^2, 1/(1.97e-7) * 1e-3 (mm -> 1/eV)
+  double gas_m_gamma_sq, gas_term1, gas_inv_hbarc_m;   // m_gamma^2, (g B / 2)^2, 1e-3 / 1.97e-7 (mm -> 1/eV)
   double m_axion_sq;
   // ---- reflectivity (raytracer.nim:1533-1580) ----
   int32_t refl_n_angles, n_coatings;
   double refl_angle_min, refl_inv_dangle, refl_dangle;
-  int32_t shell_coating[kMaxShells];
-  // ---- shells ----
-  ShellDev shells[kMaxShells];
 };
+static_assert(sizeof(DevParams) < 2048, "DevParams travels in the kernel-argument segment");
 
 // Device pointers of one context.
 struct DevTables {
-  const DevParams* params;
+  const ShellDev* shells;             // [n_shells]
+  const uint8_t* shell_lut;           // [lut_n]: first shell with R1 > k * lut_step
   const double* flux_radius_cdf;      // [n_radii]
   const uint16_t* radius_guide;       // [kRadiusGuide + 1]
   const double* diff_flux_cdfs;       // [n_radii][n_energies]

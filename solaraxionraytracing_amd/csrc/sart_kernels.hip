@@ -13,6 +13,12 @@
 //     hit the surface normals reduce to closed forms without a square root;
 //   * a Philox4x32-10 counter block per ray (key = seed, counter = global ray id) replaces the
 //     reference's shared xoroshiro stream, draw order as in the reference;
+//   * the path is split at the point where most rays have died (bore, pipes, spider, glass fronts:
+//     ~2/3 of all rays for BabyIAXO): phase A (sample + cuts + shell selection) runs one ray per
+//     lane; survivors are compacted with a wavefront ballot + prefix count into a per-wave LDS
+//     ring, and phase B (mirrors + weights + accumulation) runs on full waves of survivors;
+//   * per-setup scalars travel in the kernel arguments (SGPRs); the radius CDF, its guide table,
+//     the shell table and the shell look-up table are staged into LDS once per workgroup;
 //   * results are accumulated on the device: f64 atomics into the focal-plane image, wave
 //     reductions for the scalars.
 // Lines cited as ":NNNN" refer to src/raytracer.nim of the reference.
@@ -33,8 +39,10 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
                                             uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;   // one v_mad_u64_u32 yields both halves
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c1 ^ k0;
     const uint32_t n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -172,10 +180,25 @@ __device__ __forceinline__ double normal_z_general(const DevParams& P, const She
   return rho * sh.n2_r3t * fma(2.0 * lz, sh.n2_invF, 1.0) / sqrt(w);
 }
 
-// Per-thread accumulators of the scalar tail of the fused accumulator.
-struct Scalars {
-  double sum_w = 0.0, sum_w2 = 0.0, sum_x = 0.0, sum_y = 0.0, sum_r = 0.0;
-  uint32_t n_passed = 0, n_till_window = 0, n_nickel = 0, n_reached = 0, n_shell = 0, n_outside = 0;
+// ------------------------------------------------------------------------------------------------
+// LDS-resident tables of one workgroup
+// ------------------------------------------------------------------------------------------------
+struct LdsTables {
+  const double* rcdf;        // fluxRadiusCDF
+  const uint16_t* rguide;    // guide table in front of it
+  const ShellDev* shells;
+  const uint8_t* lut;        // radial look-up table of the shell selection
+};
+
+// State of a ray between phase A and phase B.
+struct RayState {
+  double X0, Y0;     // pointEntranceXRT (telescope frame, z = 0)
+  double tsx, tsy;   // slopes dX/dz, dY/dz in the telescope frame
+  double path_cb;    // path length inside the magnetic field
+  double u5;         // uniform of the energy draw
+  double zcb;        // z of pointExitCB in the telescope frame (z0 of :2051)
+  int r_idx;         // sampled solar radius index (row of diffFluxCDFs)
+  int shell;         // hit layer
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -183,43 +206,67 @@ __device__ __forceinline__ double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+
+// Energy index drawn with u5 from the CDF row of the sampled radius (getRandomEnergyFromSolarModel, :444-471).
+__device__ __forceinline__ int sample_energy_index(const DevParams& P, const DevTables& T, int r_idx, double u5) {
+  const double* row = T.diff_flux_cdfs + (size_t)r_idx * (size_t)P.n_energies;
+  const uint16_t* g = T.energy_guide + (size_t)r_idx * (size_t)(kEnergyGuide + 1);
+  const int k = (int)(u5 * (double)kEnergyGuide);
+  const int idx = lower_bound_bracket(row, (int)g[k], (int)g[k + 1], u5);
+  return min(idx, P.n_energies - 1);
+}
+
+// cos(n phi) from c = cos(phi): Chebyshev T16 (four doublings) or T6 = T2(T3).
+__device__ __forceinline__ double cos_n_phi(int n, double c) {
+  if (n == 16) {
+    double t = fma(2.0 * c, c, -1.0);
+    t = fma(2.0 * t, t, -1.0);
+    t = fma(2.0 * t, t, -1.0);
+    return fma(2.0 * t, t, -1.0);
+  }
+  const double t3 = c * fma(4.0 * c, c, -3.0);
+  return fma(2.0 * t3, t3, -1.0);
 }
 
 // ------------------------------------------------------------------------------------------------
-// one ray
+// phase A: sample -> bore -> pipes -> telescope frame -> opaque structures -> shell selection
+// (:1746-1957).  Returns true if the ray goes on to the mirrors; `reached` = survived bore + pipes.
+// st.r_idx / st.u5 are valid whenever the collimator cut (X-ray test source) was passed (`sampled`).
 // ------------------------------------------------------------------------------------------------
-template <bool RECORDS>
-__device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T, const TraceArgs& A,
-                                          const double* __restrict__ lds_rcdf, uint64_t ray_id, sart_axion_t* rec,
-                                          double* __restrict__ acc, Scalars& S) {
+__device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, const TraceArgs& A, uint64_t ray_id,
+                                        RayState& st, bool& sampled, bool& reached) {
+  sampled = false;
+  reached = false;
   const uint32_t id_lo = (uint32_t)ray_id, id_hi = (uint32_t)(ray_id >> 32);
-  // ---- sample: origin in the Sun / on the source, point on the bore exit (:1751-1806) ----
   const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, A.seed_lo, A.seed_hi);
   const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, A.seed_lo, A.seed_hi);
   const U4 b2 = philox4x32_10(id_lo, id_hi, 2u, 0u, A.seed_lo, A.seed_hi);
   const double u0 = u53(b0.x, b0.y), u1 = u53(b0.z, b0.w);
   const double u2 = u53(b1.x, b1.y), u3 = u53(b1.z, b1.w);
-  const double u4 = u53(b2.x, b2.y), u5 = u53(b2.z, b2.w);
+  const double u4 = u53(b2.x, b2.y);
+  st.u5 = u53(b2.z, b2.w);
+  st.r_idx = 0;
 
   double ex, ey;            // point on the magnetic-field exit plane z = lengthB
   double sx, sy;            // ray slopes dx/dz, dy/dz in the magnet frame
-  int e_idx = 0;            // energy index into EnergyDev / refl tables
-  int r_idx = 0;
-  bool energy_pending = false;
   if (!P.test_active) {
     // getRandomPointFromSolarModel (:425-442): theta1 = 360 u0 deg, theta2 = 180 u1 deg (uniform in theta)
     double s1, c1, s2, c2;
     sincospi(2.0 * u0, &s1, &c1);
     sincospi(u1, &s2, &c2);
     {
+      // lowerBound(fluxRadiusCDF, u2) (:437) inside the guide bracket; bounded, branch-free walk
       const int k = (int)(u2 * (double)kRadiusGuide);
-      r_idx = lower_bound_bracket(lds_rcdf, (int)T.radius_guide[k], (int)T.radius_guide[k + 1], u2);
+      int lo = (int)L.rguide[k];
+      const int hi = (int)L.rguide[k + 1];
+      if (P.radius_span <= 4) {
+        for (int s = 0; s < P.radius_span; ++s) lo += (lo < hi && L.rcdf[lo] < u2) ? 1 : 0;
+      } else {
+        lo = lower_bound_bracket(L.rcdf, lo, hi, u2);
+      }
+      st.r_idx = lo;
     }
-    const double r = (0.0015 + (double)r_idx * 0.0005) * P.sun_radius;
+    const double r = (0.0015 + (double)st.r_idx * 0.0005) * P.sun_radius;
     const double ox = c1 * s2 * r, oy = s1 * s2 * r, oz = c2 * r - P.sun_distance;
     // getRandomPointOnDisk (:412-422)
     double sp, cp;
@@ -230,7 +277,6 @@ __device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T
     const double inv_dz = 1.0 / (P.length_b - oz);
     sx = (ex - ox) * inv_dz;
     sy = (ey - oy) * inv_dz;
-    energy_pending = true;   // getRandomEnergyFromSolarModel (:444-471) is evaluated lazily below
   } else {
     // X-ray test source (:1765-1806)
     double sp, cp;
@@ -250,38 +296,22 @@ __device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T
     const double inv_dz = 1.0 / (P.length_b - oz);
     sx = (ex - ox) * inv_dz;
     sy = (ey - oy) * inv_dz;
-    e_idx = P.n_energies;  // the extra row of the energy tables holds the source energy
     // collimator (:1800): lineIntersectsCircle(origin, exit point, collimator, source radius)
     const double dzc = P.test_collimator_z - P.length_b;
     const double cx = fma(dzc, sx, ex) - P.test_x, cy = fma(dzc, sy, ey) - P.test_y;
-    if (!(fma(cx, cx, cy * cy) < P.test_radius_sq)) return;
+    if (!(fma(cx, cx, cy * cy) < P.test_radius_sq)) return false;
   }
-
-  // Energy index, drawn with u5 from the CDF row of the sampled radius (:462-471).
-  auto sample_energy = [&]() {
-    const double* row = T.diff_flux_cdfs + (size_t)r_idx * (size_t)P.n_energies;
-    const uint16_t* g = T.energy_guide + (size_t)r_idx * (size_t)(kEnergyGuide + 1);
-    const int k = (int)(u5 * (double)kEnergyGuide);
-    const int idx = lower_bound_bracket(row, (int)g[k], (int)g[k + 1], u5);
-    e_idx = min(idx, P.n_energies - 1);
-    energy_pending = false;
-  };
-  if (RECORDS) {
-    if (energy_pending) sample_energy();
-    rec->emratesPre = 1.0;                    // :1818
-    rec->energiesPre = T.energy_tab[e_idx].energy;
-  }
+  sampled = true;
 
   // ---- bore (:1813-1848) ----
   const double A2 = fma(sx, sx, sy * sy);     // slope^2
-  double path_cb;                              // length of the path inside the magnetic field
   {
     // entrance plane z = 0
     const double x0 = fma(-P.length_b, sx, ex), y0 = fma(-P.length_b, sy, ey);
     const bool hits_entrance = fma(x0, x0, y0 * y0) < P.radius_cb_sq;
     const double norm = sqrt(1.0 + A2);
     if (hits_entrance) {
-      path_cb = P.length_b * norm;             // |exit point - entrance-plane point| (:1836-1843)
+      st.path_cb = P.length_b * norm;          // |exit point - entrance-plane point| (:1836-1843)
     } else {
       // lineIntersectsCylinderOnce (:591-604): intersections of the line with the bore wall,
       // t = z - lengthB:  A2 t^2 + 2 Dm t + (Qm - R^2) = 0.  inter1 = larger z, inter2 = smaller z.
@@ -295,29 +325,27 @@ __device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T
       const double z_hi = P.length_b + t_hi, z_lo = P.length_b + t_lo;
       const bool v1 = (z_hi > 0.0) && (z_hi < P.length_coldbore);
       const bool v2 = (z_lo > 0.0) && (z_lo < P.length_coldbore);
-      if (!(v1 != v2)) return;                 // both or none (:598-600, :1825)
+      if (!(v1 != v2)) return false;           // both or none (:598-600, :1825)
       const double t = v1 ? t_hi : t_lo;       // :616
-      path_cb = fabs(t) * norm;
+      st.path_cb = fabs(t) * norm;
     }
   }
-  // exit of the cold bore (:1846)
+  // exit of the cold bore (:1846), pipe CB -> VT3 (:1856), VT3 -> XRT (:1866; same radius — sic)
   const double dz1 = P.length_coldbore - P.length_b;
   const double x1 = fma(dz1, sx, ex), y1 = fma(dz1, sy, ey);
-  if (!(fma(x1, x1, y1 * y1) < P.radius_cb_sq)) return;
-  // pipe CB -> VT3 (:1856) and VT3 -> XRT (:1866; same radius — sic)
   const double dz2 = dz1 + P.pipe1_len;
   const double x2 = fma(dz2, sx, ex), y2 = fma(dz2, sy, ey);
-  if (!(fma(x2, x2, y2 * y2) < P.pipe1_radius_sq)) return;
   const double dz3 = dz2 + P.pipe2_len;
   const double x3 = fma(dz3, sx, ex), y3 = fma(dz3, sy, ey);
-  if (!(fma(x3, x3, y3 * y3) < P.pipe1_radius_sq)) return;
-  S.n_reached++;
+  if (!(fma(x1, x1, y1 * y1) < P.radius_cb_sq)) return false;
+  if (!(fma(x2, x2, y2 * y2) < P.pipe1_radius_sq)) return false;
+  if (!(fma(x3, x3, y3 * y3) < P.pipe1_radius_sq)) return false;
+  reached = true;
 
   // ---- telescope frame (:1878-1899) ----
   // pointExitCB' (z = -Lp before rotation) and pointExitPipeVT3XRT' (z = 0 before rotation)
   const double Lp = P.pipe1_len + P.pipe2_len;
-  double X0, Y0, tsx, tsy;      // ray in the telescope frame: X(z) = X0 + tsx z, X0 = pointEntranceXRT
-  double zcb;                   // z of pointExitCB in the telescope frame (z0 of :2051)
+  double X0, Y0, tsx, tsy, zcb;
   if (!P.rotated) {
     X0 = x3 - P.entrance_x;
     Y0 = y3 - P.entrance_y;
@@ -346,76 +374,85 @@ __device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T
     Y0 = fma(-az, tsy, ay);
     zcb = az;
   }
+  st.X0 = X0; st.Y0 = Y0; st.tsx = tsx; st.tsy = tsy; st.zcb = zcb;
   const double Q0 = fma(X0, X0, Y0 * Y0);
   const double radial = sqrt(Q0);              // radialDist (:1905)
 
   // ---- opaque structures (:1635-1704) ----
   if (P.telescope_kind != SART_TK_LLNL) {      // LLNL: the graphite block never blocks (:1646)
-    bool blocked = false;
+    bool blocked;
     const bool inner = (P.telescope_kind == SART_TK_XMM) ? (radial <= P.inner_radius) : (radial < P.inner_radius);
-    if (inner) {
-      if (P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) {
-        // hole loop (:1675-1688) with lineIntersectsObject (:494-527) on the entrance plane
-        const int nH = P.number_of_holes;
-        const int lim = nH - (int)ceil((double)nH / 2.0);
-        bool res = false;
-        for (int l = -lim; l <= lim; ++l) {
-          double hx = 0.0, hy = 0.0;
-          if (l != 0) {
-            if ((abs(l) & 1) == 0) hy += 2.0 * (double)l * P.hole_in_optics;
-            else hx += 2.0 * ((double)l + ((double)l / (double)abs(l))) * P.hole_in_optics;
-          }
-          const double ix = X0 - hx, iy = Y0 - hy, rad = P.hole_in_optics;
-          const double tx = ix / sqrt(2.0) - iy / sqrt(2.0), ty = ix / sqrt(2.0) + iy / sqrt(2.0);
-          const double axx = fabs(ix), ayy = fabs(iy), atx = fabs(tx), aty = fabs(ty);
-          bool through = false;
-          switch (P.hole_type) {
-            case SART_HT_CIRCLE: through = sqrt(fma(ix, ix, iy * iy)) < rad; break;
-            case SART_HT_CROSS:
-              through = (axx < rad && ayy < rad * 16.0) || (ayy < rad && axx < rad * 16.0); break;
-            case SART_HT_STAR:
-              through = (axx < rad && ayy < rad * 16.0) || (ayy < rad && axx < rad * 16.0) ||
-                        (atx < rad && aty < rad * 16.0) || (aty < rad && atx < rad * 16.0); break;
-            case SART_HT_SQUARE: through = axx < rad && ayy < rad; break;
-            case SART_HT_DIAMOND: through = atx < rad && aty < rad; break;
-            default: through = false;
-          }
-          if (through) { res = false; break; } else res = true;
+    if (inner && P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) {
+      // hole loop (:1675-1688) with lineIntersectsObject (:494-527) on the entrance plane
+      const int nH = P.number_of_holes;
+      const int lim = nH - (int)ceil((double)nH / 2.0);
+      bool res = false;
+      for (int l = -lim; l <= lim; ++l) {
+        double hx = 0.0, hy = 0.0;
+        if (l != 0) {
+          if ((abs(l) & 1) == 0) hy += 2.0 * (double)l * P.hole_in_optics;
+          else hx += 2.0 * ((double)l + ((double)l / (double)abs(l))) * P.hole_in_optics;
         }
-        blocked = res;
-      } else {
-        blocked = true;   // htNone: the hole test is always false => blocked (:1683-1688, :527); Abrixas :1653
+        const double ix = X0 - hx, iy = Y0 - hy, rad = P.hole_in_optics;
+        const double tx = ix / sqrt(2.0) - iy / sqrt(2.0), ty = ix / sqrt(2.0) + iy / sqrt(2.0);
+        const double axx = fabs(ix), ayy = fabs(iy), atx = fabs(tx), aty = fabs(ty);
+        bool through = false;
+        switch (P.hole_type) {
+          case SART_HT_CIRCLE: through = sqrt(fma(ix, ix, iy * iy)) < rad; break;
+          case SART_HT_CROSS:
+            through = (axx < rad && ayy < rad * 16.0) || (ayy < rad && axx < rad * 16.0); break;
+          case SART_HT_STAR:
+            through = (axx < rad && ayy < rad * 16.0) || (ayy < rad && axx < rad * 16.0) ||
+                      (atx < rad && aty < rad * 16.0) || (aty < rad && atx < rad * 16.0); break;
+          case SART_HT_SQUARE: through = axx < rad && ayy < rad; break;
+          case SART_HT_DIAMOND: through = atx < rad && aty < rad; break;
+          default: through = false;
+        }
+        if (through) { res = false; break; } else res = true;
       }
-    } else if (P.telescope_kind == SART_TK_XMM && radial < P.ring_hi && radial > P.ring_lo) {
-      blocked = true;     // :1691
+      blocked = res;
     } else {
-      // spider spokes, tested on phi = acos(x / r) at the entrance plane and at z = spider_z (:1695-1701);
-      // phi in [lo, hi]  <=>  cos(hi) <= x/r <= cos(lo)
+      // htNone: the hole test is always false => inner disc blocked (:1683-1688, :527); Abrixas :1653;
+      // XMM ring :1691; spider spokes tested on phi = acos(x / r) at the entrance plane and at
+      // z = spider_z (:1695-1701): every 360/n degrees, |phi - k 360/n| <= w  <=>  cos(n phi) >= cos(n w)
+      const bool ring = (P.telescope_kind == SART_TK_XMM) && (radial < P.ring_hi) && (radial > P.ring_lo);
       const double c_ent = X0 / radial;
-      // pointEntranceSpider = pointExitCB + ((spider_z - z_cb) / v_z) v: the ray at z = spider_z
       const double xs = fma(P.spider_z, tsx, X0), ys = fma(P.spider_z, tsy, Y0);
       const double c_sp = xs / sqrt(fma(xs, xs, ys * ys));
-      for (int i = 0; i < P.n_spokes; ++i) {
-        const double lo = P.spoke_cos_lo[i], hi = P.spoke_cos_hi[i];
-        if ((c_ent >= lo && c_ent <= hi) || (c_sp >= lo && c_sp <= hi)) { blocked = true; break; }
-      }
+      const bool spoke = (cos_n_phi(P.spoke_n, c_ent) >= P.spoke_cos_thr) || (cos_n_phi(P.spoke_n, c_sp) >= P.spoke_cos_thr);
+      blocked = inner || ring || spoke;
     }
-    if (blocked) return;
+    if (blocked) return false;
   }
 
   // ---- shell selection (:1932-1957) ----
-  const int nS = P.n_shells;
-  if (radial > P.shells[nS - 1].r1) return;
-  int hit_layer = -1;
-  for (int j = 0; j < nS; ++j) {
-    const double r1j = P.shells[j].r1;
-    if (radial > r1j && radial < P.shells[j].r1_outer) return;   // glass front (:1942-1944)
-    if (r1j - radial > 0.0) { hit_layer = j; break; }             // R1 ascending: first positive distance is the minimum
-  }
-  if (hit_layer < 0) return;   // radial == R1[last] exactly (measure zero; the reference then uses a zero shell)
-  S.n_shell++;
-  const ShellDev& sh = P.shells[hit_layer];
-  const double min_dist = sh.r1 - radial;
+  if (radial > P.r1_last) return false;
+  // R1 ascending: the nearest shell above is the first j with R1[j] > radial; the look-up cell (narrower
+  // than any shell spacing) gives it up to one step
+  int j = (int)L.lut[min((int)(radial * P.lut_inv_step), P.lut_n - 1)];
+  if (j < P.n_shells && !(L.shells[j].r1 > radial)) ++j;
+  if (j >= P.n_shells) return false;   // radial == R1[last] exactly (measure zero; the reference uses a zero shell)
+  // glass front (:1942-1944): only the shell just below can contain radial (thickness < spacing, checked on the host)
+  if (j > 0 && radial > L.shells[j - 1].r1 && radial < L.shells[j - 1].r1_outer) return false;
+  st.shell = j;
+  return true;
+}
+
+// Results of phase B for one ray (record mode needs all of them; histogram mode a few).
+struct RayOut {
+  bool hit_nickel = false, till_window = false, finished = false, outside = false;
+  double px = 0.0, py = 0.0, rdet = 0.0, weight = 0.0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// phase B: mirrors -> detector plane -> weights -> window (:1971-2221)
+// ------------------------------------------------------------------------------------------------
+template <bool RECORDS>
+__device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, const DevTables& T, const TraceArgs& A,
+                                        const RayState& st, int e_idx_in, RayOut& out, sart_axion_t* rec) {
+  const ShellDev& sh = L.shells[st.shell];
+  const double X0 = st.X0, Y0 = st.Y0, tsx = st.tsx, tsy = st.tsy, zcb = st.zcb;
+  const double Q0 = fma(X0, X0, Y0 * Y0);
 
   // ---- mirror 1 (:1985-1992 / :2012-2019) ----
   const double D0 = fma(X0, tsx, Y0 * tsy);
@@ -438,14 +475,12 @@ __device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T
 
   // lineHitsNickel (:1706-1734), evaluated before the no-hit test (:2040-2057):
   // tan(a1) > num / (l - z1)  <=>  sin^2(a1) ((l - z1)^2 + num^2) > num^2   (num, l - z1 > 0)
-  bool hit_nickel = false;
-  if (hit_layer > 0) {
+  if (st.shell > 0) {
     const double lz = P.l_mirror - z1, num = sh.nickel_num;
-    if (lz > 0.0 && num >= 0.0) hit_nickel = sin2_a1 * fma(lz, lz, num * num) > num * num;
-    else hit_nickel = sqrt(sin2_a1 / (1.0 - sin2_a1)) > num / lz;
+    if (lz > 0.0 && num >= 0.0) out.hit_nickel = sin2_a1 * fma(lz, lz, num * num) > num * num;
+    else out.hit_nickel = sqrt(sin2_a1 / (1.0 - sin2_a1)) > num / lz;
   }
-  if (hit_nickel) {
-    S.n_nickel++;
+  if (out.hit_nickel) {
     if (RECORDS) rec->hitNickel = 1;
     return;
   }
@@ -491,8 +526,9 @@ __device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T
   }
 
   // ---- weights (:2116-2128) ----
-  if (energy_pending) sample_energy();
+  const int e_idx = (e_idx_in >= 0) ? e_idx_in : sample_energy_index(P, T, st.r_idx, st.u5);
   const EnergyDev en = T.energy_tab[e_idx];
+  const double path_cb = st.path_cb;
   double trans_magnet;
   {
     double prob = 1.0;
@@ -518,13 +554,12 @@ __device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T
   if (!(A.flags & SART_CF_IGNORE_REFLECTION)) {
     // computeReflectivity (:1533-1580): bilinear in (angle, energy); the energy interpolation is folded
     // into the per-energy-index table, leaving a linear interpolation in the angle.
-    const double* tab = T.refl + ((size_t)P.shell_coating[hit_layer] * (size_t)(P.n_energies + 1) + (size_t)e_idx) *
-                                     (size_t)P.refl_n_angles;
+    const double* tab = T.refl + ((size_t)sh.coating * (size_t)(P.n_energies + 1) + (size_t)e_idx) * (size_t)P.refl_n_angles;
     auto refl_at = [&](double sin2a) {
       const double alpha = asin_small(sqrt(sin2a)) * 57.29577951308232;   // getMirrorAngle (:782-795), degrees
       const double t = (alpha - P.refl_angle_min) * P.refl_inv_dangle;
       int i = (int)floor(t);
-      i = min(i, P.refl_n_angles - 2);
+      i = max(min(i, P.refl_n_angles - 2), 0);
       const double xu = (alpha - (P.refl_angle_min + (double)i * P.refl_dangle)) * P.refl_inv_dangle;
       const double g0 = tab[i], g1 = tab[i + 1];
       return fma(xu, g1 - g0, g0);
@@ -538,7 +573,7 @@ __device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T
     rec->reflect = reflectv;
   }
 
-  if (P.test_active && min_dist > 100.0) {    // straight through the hole in the optics (:2130-2132)
+  if (P.test_active && (sh.r1 - sqrt(Q0)) > 100.0) {   // straight through the hole in the optics (:2130-2132)
     pdx = fma(sh.dist_det_raw, tsx, X0);
     pdy = fma(sh.dist_det_raw, tsy, Y0);
     pdz = sh.dist_det_raw;
@@ -546,7 +581,7 @@ __device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T
   pdx -= P.lateral_shift;
   pdy -= P.transversal_shift;
   if (weight != 0.0) {
-    S.n_till_window++;
+    out.till_window = true;
     if (RECORDS) rec->passedTillWindow = 1;
   }
 
@@ -568,8 +603,11 @@ __device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T
   if (!(A.flags & SART_CF_IGNORE_GAS_ABS)) weight *= en.a_gas;       // :2190-2192
   if (!(A.flags & SART_CF_XRAY_TEST)) weight *= P.exposure;           // :2207-2212
 
-  const double rdet = sqrt(rdet2);
-  const double px = -pdx + P.chip_cx, py = pdy + P.chip_cy;          // :2203-2204
+  out.finished = true;
+  out.rdet = sqrt(rdet2);
+  out.px = -pdx + P.chip_cx;                                          // :2203-2204
+  out.py = pdy + P.chip_cy;
+  out.weight = weight;
   if (RECORDS) {
     if (P.n_half_strips > 0) {
       rec->transProbWindow = trans_window;
@@ -581,95 +619,213 @@ __device__ __forceinline__ void trace_one(const DevParams& P, const DevTables& T
     rec->energiesAxAll = en.energy;
     rec->kinds = SART_MK_AR;
     rec->energiesAx = en.energy;
-    rec->shellNumber = hit_layer;
-    rec->pointdataR = rdet;
-    rec->pointdataX = px;
-    rec->pointdataY = py;
+    rec->shellNumber = st.shell;
+    rec->pointdataR = out.rdet;
+    rec->pointdataX = out.px;
+    rec->pointdataY = out.py;
     rec->weights = weight;
     rec->weightsAll = weight;
     rec->passed = (weight != 0.0) ? 1 : 0;
-  } else if (weight != 0.0) {
-    S.n_passed++;
-    S.sum_w += weight;
-    S.sum_w2 = fma(weight, weight, S.sum_w2);
-    S.sum_x += px;
-    S.sum_y += py;
-    S.sum_r += rdet;
-    // prepareHeatmap (:838-842): img[floor(y / step_y), floor(x / step_x)] += w
-    const double fx = floor((px - A.image_x_min) * A.image_inv_step_x);
-    const double fy = floor((py - A.image_y_min) * A.image_inv_step_y);
-    if (fx >= 0.0 && fx < (double)A.image_nx && fy >= 0.0 && fy < (double)A.image_ny) {
-      unsafeAtomicAdd(&acc[(size_t)((int)fy) * (size_t)A.image_nx + (size_t)((int)fx)], weight);
-    } else {
-      S.n_outside++;
-    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-constexpr int kBlock = 256;
+constexpr int kQueue = 128;   // ring capacity per wave: < 64 left over + <= 64 new survivors
 
-// Fused trace + accumulate (traceAxionWrapper + prepareHeatmap + flux sum + counters).
-// Grid-stride over rays: ray i of this launch has the global id ray_id_offset + i.
-__global__ __launch_bounds__(kBlock) void trace_histogram_kernel(DevTables T, TraceArgs A, double* __restrict__ acc) {
-  __shared__ double lds_rcdf[2048];
-  const DevParams& P = *T.params;
-  for (int i = threadIdx.x; i < P.n_radii; i += kBlock) lds_rcdf[i] = T.flux_radius_cdf[i];
-  __syncthreads();
+struct __align__(16) TablesLds {
+  double rcdf[kMaxRadii];
+  ShellDev shells[kMaxShells];
+  uint16_t rguide[kRadiusGuide + 8];
+  uint8_t lut[kShellLutMax];
+};
 
-  Scalars S;
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < A.n_rays; i += stride) {
-    trace_one<false>(P, T, A, lds_rcdf, A.ray_id_offset + i, nullptr, acc, S);
+// per-wave survivor rings (structure of arrays: lane i reads slot (head + i) % 128 -> conflict-free)
+template <int WAVES>
+struct __align__(16) QueueLds {
+  double X0[WAVES][kQueue], Y0[WAVES][kQueue], tsx[WAVES][kQueue], tsy[WAVES][kQueue];
+  double path[WAVES][kQueue], u5[WAVES][kQueue], zcb[WAVES][kQueue];
+  int idx[WAVES][kQueue];   // r_idx | shell << 16
+};
+
+template <int BLOCK>
+__device__ __forceinline__ void stage_tables(TablesLds& S, const DevParams& P, const DevTables& T) {
+  for (int i = threadIdx.x; i < P.n_radii; i += BLOCK) S.rcdf[i] = T.flux_radius_cdf[i];
+  for (int i = threadIdx.x; i <= kRadiusGuide; i += BLOCK) S.rguide[i] = T.radius_guide[i];
+  {
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(T.shells);
+    uint64_t* dst = reinterpret_cast<uint64_t*>(S.shells);
+    const int n = P.n_shells * (int)(sizeof(ShellDev) / 8);
+    for (int i = threadIdx.x; i < n; i += BLOCK) dst[i] = src[i];
   }
+  for (int i = threadIdx.x; i < P.lut_n; i += BLOCK) S.lut[i] = T.shell_lut[i];
+  __syncthreads();
+}
+
+// Fused trace + accumulate (traceAxionWrapper + prepareHeatmap + flux sum + counters) with wavefront
+// compaction between phase A and phase B.  Ray i of this launch has the global id ray_id_offset + i.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(DevParams P, DevTables T, TraceArgs A,
+                                                                double* __restrict__ acc) {
+  __shared__ TablesLds S;
+  __shared__ QueueLds<BLOCK / 64> Q;
+  stage_tables<BLOCK>(S, P, T);
+  const LdsTables L{S.rcdf, S.rguide, S.shells, S.lut};
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const uint64_t waves_total = (uint64_t)gridDim.x * (BLOCK / 64);
+  const uint64_t wave_global = (uint64_t)blockIdx.x * (BLOCK / 64) + wave;
+
+  // wave-uniform counters (ballot + popcount) and per-lane sums
+  uint32_t n_reached = 0, n_shell = 0, n_nickel = 0, n_till = 0, n_passed = 0, n_outside = 0;
+  double sum_w = 0.0, sum_w2 = 0.0, sum_x = 0.0, sum_y = 0.0, sum_r = 0.0;
+  uint32_t head = 0, tail = 0;   // ring positions (monotone; slot = pos % kQueue)
+
+  auto run_phase_b = [&](uint32_t n_valid) {
+    RayState st;
+    const bool valid = (uint32_t)lane < n_valid;
+    const uint32_t slot = (head + (uint32_t)lane) % kQueue;
+    RayOut out;
+    if (valid) {
+      st.X0 = Q.X0[wave][slot]; st.Y0 = Q.Y0[wave][slot];
+      st.tsx = Q.tsx[wave][slot]; st.tsy = Q.tsy[wave][slot];
+      st.path_cb = Q.path[wave][slot]; st.u5 = Q.u5[wave][slot]; st.zcb = Q.zcb[wave][slot];
+      const int packed = Q.idx[wave][slot];
+      st.r_idx = packed & 0xFFFF;
+      st.shell = packed >> 16;
+      phase_b<false>(P, L, T, A, st, P.test_active ? P.n_energies : -1, out, nullptr);
+    }
+    head += n_valid;
+    n_nickel += (uint32_t)__popcll(__ballot(out.hit_nickel));
+    n_till += (uint32_t)__popcll(__ballot(out.till_window));
+    const bool passed = out.finished && out.weight != 0.0;
+    n_passed += (uint32_t)__popcll(__ballot(passed));
+    if (passed) {
+      sum_w += out.weight;
+      sum_w2 = fma(out.weight, out.weight, sum_w2);
+      sum_x += out.px;
+      sum_y += out.py;
+      sum_r += out.rdet;
+      // prepareHeatmap (:838-842): img[floor(y / step_y), floor(x / step_x)] += w
+      const double fx = floor((out.px - A.image_x_min) * A.image_inv_step_x);
+      const double fy = floor((out.py - A.image_y_min) * A.image_inv_step_y);
+      const bool inside = fx >= 0.0 && fx < (double)A.image_nx && fy >= 0.0 && fy < (double)A.image_ny;
+      if (inside) unsafeAtomicAdd(&acc[(size_t)((int)fy) * (size_t)A.image_nx + (size_t)((int)fx)], out.weight);
+      out.outside = !inside;
+    }
+    n_outside += (uint32_t)__popcll(__ballot(out.outside));
+  };
+
+  for (uint64_t base = wave_global * 64; base < A.n_rays; base += waves_total * 64) {
+    const uint64_t i = base + (uint64_t)lane;
+    RayState st;
+    bool sampled = false, reached = false, alive = false;
+    if (i < A.n_rays) alive = phase_a(P, L, A, A.ray_id_offset + i, st, sampled, reached);
+    n_reached += (uint32_t)__popcll(__ballot(reached));
+    const uint64_t mask = __ballot(alive);
+    const uint32_t cnt = (uint32_t)__popcll(mask);
+    n_shell += cnt;
+    if (alive) {
+      // position among the survivors of this wave: number of set mask bits below this lane
+      const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+      const uint32_t slot = (tail + below) % kQueue;
+      Q.X0[wave][slot] = st.X0; Q.Y0[wave][slot] = st.Y0;
+      Q.tsx[wave][slot] = st.tsx; Q.tsy[wave][slot] = st.tsy;
+      Q.path[wave][slot] = st.path_cb; Q.u5[wave][slot] = st.u5; Q.zcb[wave][slot] = st.zcb;
+      Q.idx[wave][slot] = st.r_idx | (st.shell << 16);
+    }
+    tail += cnt;
+    // LDS accesses of one wave execute in order; the fence only keeps the compiler from reordering them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tail - head >= 64u) {
+      run_phase_b(64u);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  if (tail - head > 0u) run_phase_b(tail - head);
 
   // scalars: wave reduction, then one atomic per wave and quantity
   double* sc = acc + (size_t)A.image_nx * (size_t)A.image_ny;
-  const double sw = wave_sum(S.sum_w), sw2 = wave_sum(S.sum_w2), sxx = wave_sum(S.sum_x), syy = wave_sum(S.sum_y),
-               srr = wave_sum(S.sum_r);
-  const uint32_t np = wave_sum_u32(S.n_passed), ntw = wave_sum_u32(S.n_till_window), nn = wave_sum_u32(S.n_nickel),
-                 nr = wave_sum_u32(S.n_reached), ns = wave_sum_u32(S.n_shell), no = wave_sum_u32(S.n_outside);
-  if ((threadIdx.x & 63) == 0) {
+  const double sw = wave_sum(sum_w), sw2 = wave_sum(sum_w2), sxx = wave_sum(sum_x), syy = wave_sum(sum_y),
+               srr = wave_sum(sum_r);
+  if (lane == 0) {
     unsafeAtomicAdd(&sc[SART_ACC_SUM_WEIGHTS], sw);
     unsafeAtomicAdd(&sc[SART_ACC_SUM_WEIGHTS_SQ], sw2);
     unsafeAtomicAdd(&sc[SART_ACC_SUM_X], sxx);
     unsafeAtomicAdd(&sc[SART_ACC_SUM_Y], syy);
     unsafeAtomicAdd(&sc[SART_ACC_SUM_R], srr);
-    unsafeAtomicAdd(&sc[SART_ACC_N_PASSED], (double)np);
-    unsafeAtomicAdd(&sc[SART_ACC_N_PASSED_TILL_WINDOW], (double)ntw);
-    unsafeAtomicAdd(&sc[SART_ACC_N_HIT_NICKEL], (double)nn);
-    unsafeAtomicAdd(&sc[SART_ACC_N_REACHED_TELESCOPE], (double)nr);
-    unsafeAtomicAdd(&sc[SART_ACC_N_SHELL_SELECTED], (double)ns);
-    unsafeAtomicAdd(&sc[SART_ACC_N_OUTSIDE_IMAGE], (double)no);
+    unsafeAtomicAdd(&sc[SART_ACC_N_PASSED], (double)n_passed);
+    unsafeAtomicAdd(&sc[SART_ACC_N_PASSED_TILL_WINDOW], (double)n_till);
+    unsafeAtomicAdd(&sc[SART_ACC_N_HIT_NICKEL], (double)n_nickel);
+    unsafeAtomicAdd(&sc[SART_ACC_N_REACHED_TELESCOPE], (double)n_reached);
+    unsafeAtomicAdd(&sc[SART_ACC_N_SHELL_SELECTED], (double)n_shell);
+    unsafeAtomicAdd(&sc[SART_ACC_N_OUTSIDE_IMAGE], (double)n_outside);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) unsafeAtomicAdd(&sc[SART_ACC_N_RAYS], (double)A.n_rays);
 }
 
-// Literal drop-in for traceAxionWrapper: one Axion record per ray.
-__global__ __launch_bounds__(kBlock) void trace_records_kernel(DevTables T, TraceArgs A, sart_axion_t* __restrict__ out) {
-  __shared__ double lds_rcdf[2048];
-  const DevParams& P = *T.params;
-  for (int i = threadIdx.x; i < P.n_radii; i += kBlock) lds_rcdf[i] = T.flux_radius_cdf[i];
-  __syncthreads();
+// Literal drop-in for traceAxionWrapper: one Axion record per ray, in ray order (no compaction).
+constexpr int kRecBlock = 256;
+__global__ __launch_bounds__(kRecBlock) void trace_records_kernel(DevParams P, DevTables T, TraceArgs A,
+                                                                   sart_axion_t* __restrict__ out) {
+  __shared__ TablesLds S;
+  stage_tables<kRecBlock>(S, P, T);
+  const LdsTables L{S.rcdf, S.rguide, S.shells, S.lut};
 
-  Scalars S;
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < A.n_rays; i += stride) {
+  const uint64_t stride = (uint64_t)gridDim.x * kRecBlock;
+  for (uint64_t i = (uint64_t)blockIdx.x * kRecBlock + threadIdx.x; i < A.n_rays; i += stride) {
     sart_axion_t rec = {};   // newSeq[Axion] zero-initialises (:2760)
-    trace_one<true>(P, T, A, lds_rcdf, A.ray_id_offset + i, &rec, nullptr, S);
+    RayState st;
+    bool sampled, reached;
+    const bool alive = phase_a(P, L, A, A.ray_id_offset + i, st, sampled, reached);
+    int e_idx = -1;
+    if (sampled) {
+      e_idx = P.test_active ? P.n_energies : sample_energy_index(P, T, st.r_idx, st.u5);
+      rec.emratesPre = 1.0;                          // :1818
+      rec.energiesPre = T.energy_tab[e_idx].energy;  // :1819
+    }
+    if (alive) {
+      RayOut ro;
+      phase_b<true>(P, L, T, A, st, e_idx, ro, &rec);
+    }
     out[i] = rec;
   }
 }
 
 // ---- launch wrappers (called from sart_api.hip) ----
-void launch_trace_histogram(const DevTables& T, const TraceArgs& A, double* acc, int n_blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(trace_histogram_kernel, dim3(n_blocks), dim3(kBlock), 0, stream, T, A, acc);
+static int g_hist_block = 512;
+void set_histogram_block(int block) { g_hist_block = block; }
+int histogram_block() { return g_hist_block; }
+int records_block() { return kRecBlock; }
+// resident workgroups per CU for the persistent grid (occupancy API: LDS- and register-limited)
+int histogram_blocks_per_cu(int block) {
+  int n = 0;
+  hipError_t e;
+  switch (block) {
+    case 512: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<512>, 512, 0); break;
+    case 1024: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024>, 1024, 0); break;
+    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<256>, 256, 0); break;
+  }
+  return (e == hipSuccess && n > 0) ? n : 1;
 }
-void launch_trace_records(const DevTables& T, const TraceArgs& A, sart_axion_t* out, int n_blocks, hipStream_t stream) {
-  hipLaunchKernelGGL(trace_records_kernel, dim3(n_blocks), dim3(kBlock), 0, stream, T, A, out);
+
+void launch_trace_histogram(const DevParams& P, const DevTables& T, const TraceArgs& A, double* acc, int n_blocks,
+                            hipStream_t stream) {
+  switch (g_hist_block) {
+    case 512: hipLaunchKernelGGL(trace_histogram_kernel<512>, dim3(n_blocks), dim3(512), 0, stream, P, T, A, acc); break;
+    case 1024: hipLaunchKernelGGL(trace_histogram_kernel<1024>, dim3(n_blocks), dim3(1024), 0, stream, P, T, A, acc); break;
+    default: hipLaunchKernelGGL(trace_histogram_kernel<256>, dim3(n_blocks), dim3(256), 0, stream, P, T, A, acc); break;
+  }
 }
-int trace_block_size() { return kBlock; }
+void launch_trace_records(const DevParams& P, const DevTables& T, const TraceArgs& A, sart_axion_t* out, int n_blocks,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(trace_records_kernel, dim3(n_blocks), dim3(kRecBlock), 0, stream, P, T, A, out);
+}
 
 }  // namespace sart
