@@ -86,7 +86,8 @@ static inline real rad_to_deg(real r) { return r / RAD_PER_DEG; }
 /* ------------------------------------------------------------------------------------------
  * RNG: Philox4x32-10 (Salmon et al., SC'11), key = (seed lo, seed hi),
  * counter = (ray id lo, ray id hi, block, 0).  Uniform k of a ray is built from words
- * (2k, 2k+1) of blocks 0..2 as a 53-bit fraction in [0, 1)  (Nim rand(1.0) is also [0,1)).
+ * (2k, 2k+1) of blocks 0..2 by mantissa fill, exactly as Nim's rand(1.0) turns its 64 random bits
+ * into a float in [0, 1).
  * ---------------------------------------------------------------------------------------- */
 static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                  uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -110,8 +111,11 @@ void sart_oracle_uniforms(uint64_t seed, uint64_t ray_id, double u[6]) {
     philox4x32_10((uint32_t)ray_id, (uint32_t)(ray_id >> 32), b, 0u, (uint32_t)seed,
                   (uint32_t)(seed >> 32), &w[4 * b]);
   for (int k = 0; k < 6; ++k) {
+    /* 52 random mantissa bits under the exponent of 1.0, minus 1.0: Nim's std/random rand(1.0) */
     uint64_t bits = ((uint64_t)w[2 * k] << 32) | (uint64_t)w[2 * k + 1];
-    u[k] = (double)(bits >> 11) * 0x1.0p-53;
+    union { uint64_t i; double d; } cv;
+    cv.i = 0x3FF0000000000000ull | (bits >> 12);
+    u[k] = cv.d - 1.0;
   }
 }
 

@@ -52,15 +52,39 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
   return U4{c0, c1, c2, c3};
 }
 
-// 53-bit uniform in [0, 1) from two words (hi word first) — same construction as the oracle.
-__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+// Uniform in [0, 1) from two words (hi word first): 52 random mantissa bits under the exponent of 1.0,
+// minus 1.0 — the construction of Nim's std/random rand(1.0) (and of the oracle).
+__device__ __forceinline__ double u52(uint32_t hi, uint32_t lo) {
   const uint64_t bits = ((uint64_t)hi << 32) | (uint64_t)lo;
-  return (double)(bits >> 11) * 0x1.0p-53;
+  return __longlong_as_double((long long)(0x3FF0000000000000ull | (bits >> 12))) - 1.0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // small math helpers
 // ------------------------------------------------------------------------------------------------
+// 1/x and sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~26 bits) plus two Newton steps:
+// <= 1 ulp, without the scaling / fix-up sequence of the IEEE-exact expansions (the path never meets
+// denormals or infinities here, and every consumer is tolerance-compared, never bit-compared).
+__device__ __forceinline__ double frcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double frsq(double x) {   // 1/sqrt(x), x > 0
+  double y = __builtin_amdgcn_rsq(x);
+  y = fma(y * fma(-x * y, y, 1.0), 0.5, y);
+  return fma(y * fma(-x * y, y, 1.0), 0.5, y);
+}
+__device__ __forceinline__ double fsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  return (x > 0.0) ? g : ((x == 0.0) ? 0.0 : __builtin_nan(""));   // rsq(0) = inf would give NaN; negative -> NaN
+}
+
 // asin for the grazing angles of the path (|x| < ~0.03): odd Taylor series
 // asin x = x + x^3/6 + 3x^5/40 + 5x^7/112 + 35x^9/1152 + 63x^11/2816 + 231x^13/13312 + 143x^15/10240,
 // truncation error < 1e-19 below 0.06; the library function outside.
@@ -130,17 +154,11 @@ __device__ __forceinline__ int lower_bound_bracket(Ptr a, int lo, int hi, double
 // evaluated without cancellation (q-form); root1 is preferred, then root2, else miss (:651-656).
 __device__ __forceinline__ bool pick_root(double a, double hb, double c, double zlo, double zhi, double& z) {
   const double disc = fma(hb, hb, -a * c);
-  const double sq = sqrt(disc);  // NaN for disc < 0 -> every comparison below is false -> miss
-  double root1, root2;
-  if (hb >= 0.0) {
-    const double q = -hb - sq;
-    root1 = q / a;
-    root2 = c / q;
-  } else {
-    const double q = -hb + sq;
-    root2 = q / a;
-    root1 = c / q;
-  }
+  const double sq = fsqrt(disc);  // NaN for disc < 0 -> every comparison below is false -> miss
+  const double q = (hb >= 0.0) ? (-hb - sq) : (-hb + sq);
+  const double qa = q * frcp(a), cq = c * frcp(q);
+  const double root1 = (hb >= 0.0) ? qa : cq;
+  const double root2 = (hb >= 0.0) ? cq : qa;
   if (root1 > zlo && root1 < zhi) { z = root1; return true; }
   if (root2 > zlo && root2 < zhi) { z = root2; return true; }
   return false;
@@ -153,8 +171,8 @@ __device__ __forceinline__ bool pick_root(double a, double hb, double c, double 
 __device__ __forceinline__ double reflect(double& wx, double& wy, double& wz, double L, double nx, double ny,
                                           double nz, double N2) {
   const double dnw = fma(nx, wx, fma(ny, wy, nz * wz));
-  const double f = dnw / N2;
-  const double c2 = dnw * f / L;
+  const double f = dnw * frcp(N2);
+  const double c2 = dnw * f * frcp(L);
   if (dnw >= 0.0) {
     wx = fma(-2.0 * f, nx, wx);
     wy = fma(-2.0 * f, ny, wy);
@@ -241,10 +259,10 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
   const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, A.seed_lo, A.seed_hi);
   const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, A.seed_lo, A.seed_hi);
   const U4 b2 = philox4x32_10(id_lo, id_hi, 2u, 0u, A.seed_lo, A.seed_hi);
-  const double u0 = u53(b0.x, b0.y), u1 = u53(b0.z, b0.w);
-  const double u2 = u53(b1.x, b1.y), u3 = u53(b1.z, b1.w);
-  const double u4 = u53(b2.x, b2.y);
-  st.u5 = u53(b2.z, b2.w);
+  const double u0 = u52(b0.x, b0.y), u1 = u52(b0.z, b0.w);
+  const double u2 = u52(b1.x, b1.y), u3 = u52(b1.z, b1.w);
+  const double u4 = u52(b2.x, b2.y);
+  st.u5 = u52(b2.z, b2.w);
   st.r_idx = 0;
 
   double ex, ey;            // point on the magnetic-field exit plane z = lengthB
@@ -271,17 +289,17 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
     // getRandomPointOnDisk (:412-422)
     double sp, cp;
     sincospi(2.0 * u4, &sp, &cp);
-    const double rr = P.radius_cb * sqrt(u3);
+    const double rr = P.radius_cb * fsqrt(u3);
     ex = cp * rr;
     ey = sp * rr;
-    const double inv_dz = 1.0 / (P.length_b - oz);
+    const double inv_dz = frcp(P.length_b - oz);
     sx = (ex - ox) * inv_dz;
     sy = (ey - oy) * inv_dz;
   } else {
     // X-ray test source (:1765-1806)
     double sp, cp;
     sincospi(2.0 * u1, &sp, &cp);
-    const double rr = P.test_radius * sqrt(u0);
+    const double rr = P.test_radius * fsqrt(u0);
     const double ox = cp * rr + P.test_x, oy = sp * rr + P.test_y, oz = P.test_z;
     if (P.test_parallel) {
       ex = ox + (u2 * 0.5) - 0.25;
@@ -289,11 +307,11 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
     } else {
       double sq, cq;
       sincospi(2.0 * u3, &sq, &cq);
-      const double r2 = P.radius_cb * sqrt(u2);
+      const double r2 = P.radius_cb * fsqrt(u2);
       ex = cq * r2;
       ey = sq * r2;
     }
-    const double inv_dz = 1.0 / (P.length_b - oz);
+    const double inv_dz = frcp(P.length_b - oz);
     sx = (ex - ox) * inv_dz;
     sy = (ey - oy) * inv_dz;
     // collimator (:1800): lineIntersectsCircle(origin, exit point, collimator, source radius)
@@ -309,7 +327,7 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
     // entrance plane z = 0
     const double x0 = fma(-P.length_b, sx, ex), y0 = fma(-P.length_b, sy, ey);
     const bool hits_entrance = fma(x0, x0, y0 * y0) < P.radius_cb_sq;
-    const double norm = sqrt(1.0 + A2);
+    const double norm = fsqrt(1.0 + A2);
     if (hits_entrance) {
       st.path_cb = P.length_b * norm;          // |exit point - entrance-plane point| (:1836-1843)
     } else {
@@ -318,10 +336,10 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
       const double Dm = fma(ex, sx, ey * sy);
       const double c = fma(ex, ex, ey * ey) - P.radius_cb_sq;
       const double disc = fma(Dm, Dm, -A2 * c);
-      const double sq = sqrt(disc);
+      const double sq = fsqrt(disc);
       double t_hi, t_lo;
-      if (Dm >= 0.0) { const double q = -Dm - sq; t_lo = q / A2; t_hi = c / q; }
-      else           { const double q = -Dm + sq; t_hi = q / A2; t_lo = c / q; }
+      if (Dm >= 0.0) { const double q = -Dm - sq; t_lo = q * frcp(A2); t_hi = c * frcp(q); }
+      else           { const double q = -Dm + sq; t_hi = q * frcp(A2); t_lo = c * frcp(q); }
       const double z_hi = P.length_b + t_hi, z_lo = P.length_b + t_lo;
       const bool v1 = (z_hi > 0.0) && (z_hi < P.length_coldbore);
       const bool v2 = (z_lo > 0.0) && (z_lo < P.length_coldbore);
@@ -367,7 +385,7 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
     rot(x3, y3, 0.0, bx, by, bz);
     ax -= P.entrance_x; ay -= P.entrance_y;
     bx -= P.entrance_x; by -= P.entrance_y;
-    const double inv = 1.0 / (bz - az);
+    const double inv = frcp(bz - az);
     tsx = (bx - ax) * inv;
     tsy = (by - ay) * inv;
     X0 = fma(-az, tsx, ax);     // pointEntranceXRT: z = 0 (:1897-1898)
@@ -376,7 +394,7 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
   }
   st.X0 = X0; st.Y0 = Y0; st.tsx = tsx; st.tsy = tsy; st.zcb = zcb;
   const double Q0 = fma(X0, X0, Y0 * Y0);
-  const double radial = sqrt(Q0);              // radialDist (:1905)
+  const double radial = fsqrt(Q0);             // radialDist (:1905)
 
   // ---- opaque structures (:1635-1704) ----
   if (P.telescope_kind != SART_TK_LLNL) {      // LLNL: the graphite block never blocks (:1646)
@@ -416,9 +434,9 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
       // XMM ring :1691; spider spokes tested on phi = acos(x / r) at the entrance plane and at
       // z = spider_z (:1695-1701): every 360/n degrees, |phi - k 360/n| <= w  <=>  cos(n phi) >= cos(n w)
       const bool ring = (P.telescope_kind == SART_TK_XMM) && (radial < P.ring_hi) && (radial > P.ring_lo);
-      const double c_ent = X0 / radial;
+      const double c_ent = X0 * frcp(radial);
       const double xs = fma(P.spider_z, tsx, X0), ys = fma(P.spider_z, tsy, Y0);
-      const double c_sp = xs / sqrt(fma(xs, xs, ys * ys));
+      const double c_sp = xs * frsq(fma(xs, xs, ys * ys));
       const bool spoke = (cos_n_phi(P.spoke_n, c_ent) >= P.spoke_cos_thr) || (cos_n_phi(P.spoke_n, c_sp) >= P.spoke_cos_thr);
       blocked = inner || ring || spoke;
     }
@@ -451,6 +469,12 @@ template <bool RECORDS>
 __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, const DevTables& T, const TraceArgs& A,
                                         const RayState& st, int e_idx_in, RayOut& out, sart_axion_t* rec) {
   const ShellDev& sh = L.shells[st.shell];
+  // P / A may live in LDS: branch conditions are made wave-uniform (scalar branches) explicitly
+  const int wolter = __builtin_amdgcn_readfirstlane(P.telescope_wolter);
+  const int stage_gas = __builtin_amdgcn_readfirstlane(P.stage_gas);
+  const int test_active = __builtin_amdgcn_readfirstlane(P.test_active);
+  const int n_half_strips = __builtin_amdgcn_readfirstlane(P.n_half_strips);
+  const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.flags);
   const double X0 = st.X0, Y0 = st.Y0, tsx = st.tsx, tsy = st.tsy, zcb = st.zcb;
   const double Q0 = fma(X0, X0, Y0 * Y0);
 
@@ -465,7 +489,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   double n1z;
   if (hit1) {
     // on the surface the normal's z-component is closed-form: cone tan(b) rho(z); paraboloid r3 tan(b)
-    n1z = P.telescope_wolter ? sh.n1_r3t : sh.n1_tan * fma(-sh.n1_tan, z1, sh.r1);
+    n1z = wolter ? sh.n1_r3t : sh.n1_tan * fma(-sh.n1_tan, z1, sh.r1);
   } else {
     n1z = normal_z_general(P, sh, 1, m1x, m1y, z1);
   }
@@ -487,7 +511,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   if (!hit1) return;                          // almostEqual(z1, z0) (:2055)
 
   // ---- mirror 2 (:1994-2001 / :2021-2028): ray through (m1x, m1y, z1) along w ----
-  const double inv_wz = 1.0 / wz;
+  const double inv_wz = frcp(wz);
   const double s2x = wx * inv_wz, s2y = wy * inv_wz;
   const double X1 = fma(-z1, s2x, m1x), Y1 = fma(-z1, s2y, m1y);   // extrapolated to z = 0
   const double A1 = fma(s2x, s2x, s2y * s2y);
@@ -498,7 +522,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   if (!hit2) return;                          // almostEqual(z1, z2) (:2055)
   const double m2x = fma(z2, s2x, X1), m2y = fma(z2, s2y, Y1);
   double n2z;
-  if (P.telescope_wolter) n2z = sh.n2_r3t * fma(2.0 * (P.l_mirror - z2), sh.n2_invF, 1.0);
+  if (wolter) n2z = sh.n2_r3t * fma(2.0 * (P.l_mirror - z2), sh.n2_invF, 1.0);
   else n2z = sh.n2_tan * fma(-sh.n2_tan, z2 - sh.m2_zlo, sh.m2_rc);
   const double N2 = fma(m2x, m2x, fma(m2y, m2y, n2z * n2z));
   const double sin2_a2 = reflect(wx, wy, wz, L0, m2x, m2y, n2z, N2);
@@ -508,7 +532,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const double pmz = fma(z2, P.pipe_c, -m2x * P.pipe_s);
   const double vx = fma(wx, P.pipe_c, wz * P.pipe_s);
   const double vz = fma(wz, P.pipe_c, -wx * P.pipe_s);
-  const double inv_vz = 1.0 / vz;
+  const double inv_vz = frcp(vz);
   const double nwin = (sh.dist_det - pmz) * inv_vz;
   double pdx = fma(nwin, vx, pmx), pdy = fma(nwin, wy, m2y), pdz = sh.dist_det;
 
@@ -533,12 +557,12 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   {
     double prob = 1.0;
     double absorb = 1.0;
-    if (!P.stage_gas) {
-      if (!(A.flags & SART_CF_IGNORE_CONV_PROB)) prob = P.conv_k * path_cb * path_cb;   // conversionProb (:363-365)
+    if (!stage_gas) {
+      if (!(flags & SART_CF_IGNORE_CONV_PROB)) prob = P.conv_k * path_cb * path_cb;   // conversionProb (:363-365)
     } else {
       // axionConversionProb2 / intensitySuppression2 (axionMassforMagnet.nim:75-113) with pathCB as length
       const double Lnat = path_cb * P.gas_inv_hbarc_m;               // length / 1.97e-7, length in m
-      if (!(A.flags & SART_CF_IGNORE_CONV_PROB)) {
+      if (!(flags & SART_CF_IGNORE_CONV_PROB)) {
         const double q = fabs((P.gas_m_gamma_sq - P.m_axion_sq) / en.two_e_ev);
         const double g = en.gamma;
         const double term2 = 1.0 / fma(q, q, g * g * 0.25);
@@ -551,12 +575,12 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     trans_magnet = cos_small(ya) * prob * absorb;   // cos of a degree value taken as radians — sic (:1598)
   }
   double reflectv = 1.0, weight = trans_magnet;
-  if (!(A.flags & SART_CF_IGNORE_REFLECTION)) {
+  if (!(flags & SART_CF_IGNORE_REFLECTION)) {
     // computeReflectivity (:1533-1580): bilinear in (angle, energy); the energy interpolation is folded
     // into the per-energy-index table, leaving a linear interpolation in the angle.
     const double* tab = T.refl + ((size_t)sh.coating * (size_t)(P.n_energies + 1) + (size_t)e_idx) * (size_t)P.refl_n_angles;
     auto refl_at = [&](double sin2a) {
-      const double alpha = asin_small(sqrt(sin2a)) * 57.29577951308232;   // getMirrorAngle (:782-795), degrees
+      const double alpha = asin_small(fsqrt(sin2a)) * 57.29577951308232;   // getMirrorAngle (:782-795), degrees
       const double t = (alpha - P.refl_angle_min) * P.refl_inv_dangle;
       int i = (int)floor(t);
       i = max(min(i, P.refl_n_angles - 2), 0);
@@ -573,7 +597,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     rec->reflect = reflectv;
   }
 
-  if (P.test_active && (sh.r1 - sqrt(Q0)) > 100.0) {   // straight through the hole in the optics (:2130-2132)
+  if (test_active && (sh.r1 - fsqrt(Q0)) > 100.0) {   // straight through the hole in the optics (:2130-2132)
     pdx = fma(sh.dist_det_raw, tsx, X0);
     pdy = fma(sh.dist_det_raw, tsy, Y0);
     pdz = sh.dist_det_raw;
@@ -587,29 +611,29 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
 
   // ---- detector window / chip (:2138-2147) ----
   const double rdet2 = fma(pdx, pdx, pdy * pdy);
-  if (!(A.flags & SART_CF_IGNORE_DET_WINDOW) && rdet2 > P.radius_window_sq) return;
+  if (!(flags & SART_CF_IGNORE_DET_WINDOW) && rdet2 > P.radius_window_sq) return;
   if (fabs(pdx) > P.chip_cx || fabs(pdy) > P.chip_cy) return;
 
   // window strips (:2149-2187): rotateAroundZ by theta, strips along x
   const double yt = fabs(fma(pdy, P.theta_c, -pdx * P.theta_s));
   double trans_window = 0.0;
   uint8_t kind_w = 0;
-  for (int i = 0; i < P.n_half_strips; ++i) {
+  for (int i = 0; i < n_half_strips; ++i) {
     if (yt > P.strip_lo[i] && yt < P.strip_hi[i]) { trans_window = en.t_strongback; kind_w = SART_MK_SI; break; }
     trans_window = en.t_window;
     kind_w = SART_MK_SI3N4;
   }
-  if (!(A.flags & SART_CF_IGNORE_DET_WINDOW)) weight *= trans_window;
-  if (!(A.flags & SART_CF_IGNORE_GAS_ABS)) weight *= en.a_gas;       // :2190-2192
-  if (!(A.flags & SART_CF_XRAY_TEST)) weight *= P.exposure;           // :2207-2212
+  if (!(flags & SART_CF_IGNORE_DET_WINDOW)) weight *= trans_window;
+  if (!(flags & SART_CF_IGNORE_GAS_ABS)) weight *= en.a_gas;       // :2190-2192
+  if (!(flags & SART_CF_XRAY_TEST)) weight *= P.exposure;           // :2207-2212
 
   out.finished = true;
-  out.rdet = sqrt(rdet2);
+  out.rdet = fsqrt(rdet2);
   out.px = -pdx + P.chip_cx;                                          // :2203-2204
   out.py = pdy + P.chip_cy;
   out.weight = weight;
   if (RECORDS) {
-    if (P.n_half_strips > 0) {
+    if (n_half_strips > 0) {
       rec->transProbWindow = trans_window;
       rec->energiesAxWindow = en.energy;
       rec->kindsWindow = kind_w;
@@ -670,6 +694,12 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(DevParams P, Dev
                                                                 double* __restrict__ acc) {
   __shared__ TablesLds S;
   __shared__ QueueLds<BLOCK / 64> Q;
+  // Phase B reads its ~60 loop-invariant scalars from an LDS copy (broadcast ds_read): together with
+  // phase A's they do not fit the 102 SGPRs of a wave and would be spilled through VGPR lanes.
+  __shared__ DevParams Pb;
+  __shared__ DevTables Tb;
+  __shared__ TraceArgs Ab;
+  if (threadIdx.x == 0) { Pb = P; Tb = T; Ab = A; }
   stage_tables<BLOCK>(S, P, T);
   const LdsTables L{S.rcdf, S.rguide, S.shells, S.lut};
 
@@ -695,7 +725,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(DevParams P, Dev
       const int packed = Q.idx[wave][slot];
       st.r_idx = packed & 0xFFFF;
       st.shell = packed >> 16;
-      phase_b<false>(P, L, T, A, st, P.test_active ? P.n_energies : -1, out, nullptr);
+      phase_b<false>(Pb, L, Tb, Ab, st, P.test_active ? P.n_energies : -1, out, nullptr);
     }
     head += n_valid;
     n_nickel += (uint32_t)__popcll(__ballot(out.hit_nickel));
@@ -709,10 +739,11 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(DevParams P, Dev
       sum_y += out.py;
       sum_r += out.rdet;
       // prepareHeatmap (:838-842): img[floor(y / step_y), floor(x / step_x)] += w
-      const double fx = floor((out.px - A.image_x_min) * A.image_inv_step_x);
-      const double fy = floor((out.py - A.image_y_min) * A.image_inv_step_y);
-      const bool inside = fx >= 0.0 && fx < (double)A.image_nx && fy >= 0.0 && fy < (double)A.image_ny;
-      if (inside) unsafeAtomicAdd(&acc[(size_t)((int)fy) * (size_t)A.image_nx + (size_t)((int)fx)], out.weight);
+      const double fx = floor((out.px - Ab.image_x_min) * Ab.image_inv_step_x);
+      const double fy = floor((out.py - Ab.image_y_min) * Ab.image_inv_step_y);
+      const int nx = A.image_nx, ny = A.image_ny;
+      const bool inside = fx >= 0.0 && fx < (double)nx && fy >= 0.0 && fy < (double)ny;
+      if (inside) unsafeAtomicAdd(&acc[(size_t)((int)fy) * (size_t)nx + (size_t)((int)fx)], out.weight);
       out.outside = !inside;
     }
     n_outside += (uint32_t)__popcll(__ballot(out.outside));
