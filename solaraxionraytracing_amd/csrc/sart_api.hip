@@ -17,14 +17,14 @@
 #include "sart_device.h"
 
 namespace sart {
-void launch_trace_histogram(const DevParams& P, const DevTables& T, const TraceArgs& A, double* acc, int n_blocks,
-                            hipStream_t stream);
-void launch_trace_records(const DevParams& P, const DevTables& T, const TraceArgs& A, sart_axion_t* out, int n_blocks,
+void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
+                            hipStream_t stream, bool fast);
+void launch_trace_records(const HotA& H, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream);
 void set_histogram_block(int block);
 int histogram_block();
 int records_block();
-int histogram_blocks_per_cu(int block);
+int histogram_blocks_per_cu(int block, bool fast);
 }  // namespace sart
 
 using namespace sart;
@@ -108,7 +108,10 @@ struct sart_context {
   std::vector<double> sb_x, sb_y, win_x, win_y, gas_x, gas_y;
 
   // device state
-  DevParams params;  // passed by value to every launch
+  DevParams params;  // host mirror of the blob's parameter block
+  HotA hot;          // passed by value to every launch
+  DevBuf<DevBlob> d_blob;
+  bool blob_dirty = true;
   std::vector<ShellDev> shells;
   std::vector<uint8_t> shell_lut;
   int radius_span = 0;
@@ -379,6 +382,7 @@ int refresh_derived(sart_context* c) {
   if (int rc = hoist_energy_tables(c)) return rc;
   if (int rc = hoist_reflectivity(c)) return rc;
   c->derived_dirty = false;
+  c->blob_dirty = true;
   return 0;
 }
 
@@ -398,6 +402,41 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   a.image_inv_step_x = 1.0 / ((p->image_x_max - p->image_x_min) / static_cast<double>(p->image_nx));  // :828-830
   a.image_inv_step_y = 1.0 / ((p->image_y_max - p->image_y_min) / static_cast<double>(p->image_ny));
   (void)c;
+  return 0;
+}
+
+HotA hot_of(const DevParams& P) {
+  HotA h;
+  std::memset(&h, 0, sizeof h);
+  h.sun_distance = P.sun_distance; h.sun_radius = P.sun_radius;
+  h.radius_cb = P.radius_cb; h.radius_cb_sq = P.radius_cb_sq; h.length_b = P.length_b; h.length_coldbore = P.length_coldbore;
+  h.dz1 = P.length_coldbore - P.length_b;
+  h.dz2 = h.dz1 + P.pipe1_len;
+  h.dz3 = h.dz2 + P.pipe2_len;
+  h.pipe1_radius_sq = P.pipe1_radius_sq;
+  h.entrance_x = P.entrance_x; h.entrance_y = P.entrance_y;
+  h.r1_last = P.r1_last; h.lut_inv_step = P.lut_inv_step;
+  h.spider_z = P.spider_z; h.spoke_cos_thr = P.spoke_cos_thr; h.inner_radius = P.inner_radius;
+  h.ring_lo = P.ring_lo; h.ring_hi = P.ring_hi;
+  h.test_active = P.test_active; h.rotated = P.rotated; h.telescope_kind = P.telescope_kind; h.spoke_n = P.spoke_n;
+  h.n_shells = P.n_shells; h.lut_n = P.lut_n; h.radius_span = P.radius_span; h.inner_blocks = P.inner_blocks;
+  return h;
+}
+
+DevTables tables_of(sart_context* c);
+
+// (Re)uploads the parameter blob if the host mirror changed.  Ordered after all work already queued on
+// the stream: the previous launches read the old blob.
+int sync_blob(sart_context* c) {
+  if (!c->blob_dirty) return 0;
+  SART_HIP(hipStreamSynchronize(c->stream));
+  DevBlob b;
+  std::memset(&b, 0, sizeof b);
+  b.P = c->params;
+  b.T = tables_of(c);
+  if (int rc = c->d_blob.upload(&b, 1)) return rc;
+  c->hot = hot_of(c->params);
+  c->blob_dirty = false;
   return 0;
 }
 
@@ -533,7 +572,8 @@ int sart_set_telescope_angles(sart_context* c, double tx, double ty) {
   if (!std::isnan(tx)) c->setup.telescope_turned_x_deg = tx;
   if (!std::isnan(ty)) c->setup.telescope_turned_y_deg = ty;
   if (c->derived_dirty) return 0;
-  // cheap path: only the kernel-argument block changes (the shell table does not depend on the angles)
+  // cheap path: only the parameter blob changes (the shell table does not depend on the angles)
+  c->blob_dirty = true;
   return hoist_setup(c);
 }
 
@@ -542,7 +582,8 @@ int sart_set_axion_mass(sart_context* c, double m) {
   if (!c->have_setup) return fail(SART_ERR_NOT_READY, "no setup");
   c->setup.m_axion = m;
   if (c->derived_dirty) return 0;
-  c->params.m_axion_sq = m * m;   // travels with the next launch's kernel arguments
+  c->params.m_axion_sq = m * m;
+  c->blob_dirty = true;
   return 0;
 }
 
@@ -617,13 +658,14 @@ int sart_trace_records_device(sart_context* c, const sart_trace_params_t* p, sar
   if (!c || !out_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
   SART_HIP(hipSetDevice(c->device));
   if (int rc = refresh_derived(c)) return rc;
+  if (int rc = sync_blob(c)) return rc;
   TraceArgs a;
   if (int rc = make_args(c, p, a)) return rc;
   if (a.n_rays == 0) return 0;
   if (c->blocks_per_cu_rec == 0) c->blocks_per_cu_rec = 4;
   {
     TimedLaunch tl(c);
-    launch_trace_records(c->params, tables_of(c), a, out_dev,
+    launch_trace_records(c->hot, c->d_blob.p, a, out_dev,
                          grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_rec, records_block()), c->stream);
   }
   SART_HIP(hipGetLastError());
@@ -645,6 +687,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   if (!c || !acc_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
   SART_HIP(hipSetDevice(c->device));
   if (int rc = refresh_derived(c)) return rc;
+  if (int rc = sync_blob(c)) return rc;
   TraceArgs a;
   if (int rc = make_args(c, p, a)) return rc;
   if (!p->accumulate)
@@ -652,13 +695,18 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   if (a.n_rays == 0) return 0;
   if (c->blocks_per_cu_hist == 0) {
     if (const char* e = std::getenv("SART_HIST_BLOCK")) set_histogram_block(std::atoi(e));   // tuning knob
-    c->blocks_per_cu_hist = std::max(1, histogram_blocks_per_cu(histogram_block()));
+    c->blocks_per_cu_hist = std::max(1, histogram_blocks_per_cu(histogram_block(), true));
     if (const char* e = std::getenv("SART_HIST_BLOCKS_PER_CU")) c->blocks_per_cu_hist = std::max(1, std::atoi(e));
   }
   {
     TimedLaunch tl(c);
-    launch_trace_histogram(c->params, tables_of(c), a, acc_dev,
-                           grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_hist, histogram_block()), c->stream);
+    // specialised instantiation for the common configuration (solar source, telescope not rotated, vacuum,
+    // no hole loop); anything else runs the generic one
+    const DevParams& P = c->params;
+    const bool fast = !P.test_active && !P.rotated && !P.stage_gas && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) &&
+                      !std::getenv("SART_FORCE_GENERIC");
+    launch_trace_histogram(c->hot, c->d_blob.p, a, acc_dev,
+                           grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_hist, histogram_block()), c->stream, fast);
   }
   SART_HIP(hipGetLastError());
   return 0;

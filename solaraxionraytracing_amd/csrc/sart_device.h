@@ -118,6 +118,19 @@ struct DevParams {
 };
 static_assert(sizeof(DevParams) < 2048, "DevParams travels in the kernel-argument segment");
 
+// The few scalars phase A touches for every ray: by value in the kernel arguments (SGPRs).
+struct HotA {
+  double sun_distance, sun_radius;
+  double radius_cb, radius_cb_sq, length_b, length_coldbore;
+  double dz1, dz2, dz3;        // z of cold-bore exit / pipe exits relative to the magnetic-field exit plane
+  double pipe1_radius_sq;
+  double entrance_x, entrance_y;
+  double r1_last, lut_inv_step;
+  double spider_z, spoke_cos_thr, inner_radius, ring_lo, ring_hi;
+  int32_t test_active, rotated, telescope_kind, spoke_n;
+  int32_t n_shells, lut_n, radius_span, inner_blocks;
+};
+
 // Device pointers of one context.
 struct DevTables {
   const ShellDev* shells;             // [n_shells]
@@ -130,6 +143,13 @@ struct DevTables {
   // reflectivity re-tabulated per energy index: refl[coating][e_idx][angle] (see hoist_reflectivity)
   const double* refl;                 // [n_coatings][n_energies + 1][n_angles]
 };
+
+// DevParams + DevTables as one blob in HBM; staged into LDS by every workgroup.
+struct DevBlob {
+  DevParams P;
+  DevTables T;
+};
+static_assert(sizeof(DevBlob) % 8 == 0, "DevBlob is staged into LDS as 8-byte words");
 
 struct TraceArgs {
   uint64_t n_rays, ray_id_offset;

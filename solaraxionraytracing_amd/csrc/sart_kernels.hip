@@ -250,24 +250,35 @@ __device__ __forceinline__ double cos_n_phi(int n, double c) {
 // phase A: sample -> bore -> pipes -> telescope frame -> opaque structures -> shell selection
 // (:1746-1957).  Returns true if the ray goes on to the mirrors; `reached` = survived bore + pipes.
 // st.r_idx / st.u5 are valid whenever the collimator cut (X-ray test source) was passed (`sampled`).
+//
+// Written in predicated form: every cut of the reference is an `ok &= ...` instead of an early return.
+// A wave of 64 rays practically always has survivors up to the shell selection, so an early return
+// saves no issue slots - it only costs exec-mask bookkeeping (SALU + SGPRs).  Lanes whose ray is dead
+// keep computing on finite values; their results are discarded.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, const TraceArgs& A, uint64_t ray_id,
-                                        RayState& st, bool& sampled, bool& reached) {
-  sampled = false;
-  reached = false;
+//
+// FAST = the configuration known at compile time to be: solar source (no X-ray test source), telescope
+// not rotated, no hole loop in the optics.  The generic instantiation reads those switches at run time.
+template <bool FAST>
+__device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const LdsTables& L, uint32_t seed_lo,
+                                        uint32_t seed_hi, uint64_t ray_id, RayState& st, bool& sampled, bool& reached) {
+  const bool cfg_test = FAST ? false : (H.test_active != 0);
+  const bool cfg_rotated = FAST ? false : (H.rotated != 0);
+  const bool cfg_holes = FAST ? false : (H.telescope_kind == SART_TK_XMM && H.inner_blocks < 0);
   const uint32_t id_lo = (uint32_t)ray_id, id_hi = (uint32_t)(ray_id >> 32);
-  const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, A.seed_lo, A.seed_hi);
-  const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, A.seed_lo, A.seed_hi);
-  const U4 b2 = philox4x32_10(id_lo, id_hi, 2u, 0u, A.seed_lo, A.seed_hi);
+  const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, seed_lo, seed_hi);
+  const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, seed_lo, seed_hi);
+  const U4 b2 = philox4x32_10(id_lo, id_hi, 2u, 0u, seed_lo, seed_hi);
   const double u0 = u52(b0.x, b0.y), u1 = u52(b0.z, b0.w);
   const double u2 = u52(b1.x, b1.y), u3 = u52(b1.z, b1.w);
   const double u4 = u52(b2.x, b2.y);
   st.u5 = u52(b2.z, b2.w);
   st.r_idx = 0;
 
+  bool ok = true;
   double ex, ey;            // point on the magnetic-field exit plane z = lengthB
   double sx, sy;            // ray slopes dx/dz, dy/dz in the magnet frame
-  if (!P.test_active) {
+  if (!cfg_test) {
     // getRandomPointFromSolarModel (:425-442): theta1 = 360 u0 deg, theta2 = 180 u1 deg (uniform in theta)
     double s1, c1, s2, c2;
     sincospi(2.0 * u0, &s1, &c1);
@@ -277,22 +288,22 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
       const int k = (int)(u2 * (double)kRadiusGuide);
       int lo = (int)L.rguide[k];
       const int hi = (int)L.rguide[k + 1];
-      if (P.radius_span <= 4) {
-        for (int s = 0; s < P.radius_span; ++s) lo += (lo < hi && L.rcdf[lo] < u2) ? 1 : 0;
+      if (H.radius_span <= 4) {
+        for (int s = 0; s < H.radius_span; ++s) lo += (lo < hi && L.rcdf[lo] < u2) ? 1 : 0;
       } else {
         lo = lower_bound_bracket(L.rcdf, lo, hi, u2);
       }
       st.r_idx = lo;
     }
-    const double r = (0.0015 + (double)st.r_idx * 0.0005) * P.sun_radius;
-    const double ox = c1 * s2 * r, oy = s1 * s2 * r, oz = c2 * r - P.sun_distance;
+    const double r = (0.0015 + (double)st.r_idx * 0.0005) * H.sun_radius;
+    const double ox = c1 * s2 * r, oy = s1 * s2 * r, oz = c2 * r - H.sun_distance;
     // getRandomPointOnDisk (:412-422)
     double sp, cp;
     sincospi(2.0 * u4, &sp, &cp);
-    const double rr = P.radius_cb * fsqrt(u3);
+    const double rr = H.radius_cb * fsqrt(u3);
     ex = cp * rr;
     ey = sp * rr;
-    const double inv_dz = frcp(P.length_b - oz);
+    const double inv_dz = frcp(H.length_b - oz);
     sx = (ex - ox) * inv_dz;
     sy = (ey - oy) * inv_dz;
   } else {
@@ -307,66 +318,61 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
     } else {
       double sq, cq;
       sincospi(2.0 * u3, &sq, &cq);
-      const double r2 = P.radius_cb * fsqrt(u2);
+      const double r2 = H.radius_cb * fsqrt(u2);
       ex = cq * r2;
       ey = sq * r2;
     }
-    const double inv_dz = frcp(P.length_b - oz);
+    const double inv_dz = frcp(H.length_b - oz);
     sx = (ex - ox) * inv_dz;
     sy = (ey - oy) * inv_dz;
     // collimator (:1800): lineIntersectsCircle(origin, exit point, collimator, source radius)
-    const double dzc = P.test_collimator_z - P.length_b;
+    const double dzc = P.test_collimator_z - H.length_b;
     const double cx = fma(dzc, sx, ex) - P.test_x, cy = fma(dzc, sy, ey) - P.test_y;
-    if (!(fma(cx, cx, cy * cy) < P.test_radius_sq)) return false;
+    ok = fma(cx, cx, cy * cy) < P.test_radius_sq;
   }
-  sampled = true;
+  sampled = ok;
 
   // ---- bore (:1813-1848) ----
   const double A2 = fma(sx, sx, sy * sy);     // slope^2
-  {
-    // entrance plane z = 0
-    const double x0 = fma(-P.length_b, sx, ex), y0 = fma(-P.length_b, sy, ey);
-    const bool hits_entrance = fma(x0, x0, y0 * y0) < P.radius_cb_sq;
-    const double norm = fsqrt(1.0 + A2);
-    if (hits_entrance) {
-      st.path_cb = P.length_b * norm;          // |exit point - entrance-plane point| (:1836-1843)
-    } else {
-      // lineIntersectsCylinderOnce (:591-604): intersections of the line with the bore wall,
-      // t = z - lengthB:  A2 t^2 + 2 Dm t + (Qm - R^2) = 0.  inter1 = larger z, inter2 = smaller z.
-      const double Dm = fma(ex, sx, ey * sy);
-      const double c = fma(ex, ex, ey * ey) - P.radius_cb_sq;
-      const double disc = fma(Dm, Dm, -A2 * c);
-      const double sq = fsqrt(disc);
-      double t_hi, t_lo;
-      if (Dm >= 0.0) { const double q = -Dm - sq; t_lo = q * frcp(A2); t_hi = c * frcp(q); }
-      else           { const double q = -Dm + sq; t_hi = q * frcp(A2); t_lo = c * frcp(q); }
-      const double z_hi = P.length_b + t_hi, z_lo = P.length_b + t_lo;
-      const bool v1 = (z_hi > 0.0) && (z_hi < P.length_coldbore);
-      const bool v2 = (z_lo > 0.0) && (z_lo < P.length_coldbore);
-      if (!(v1 != v2)) return false;           // both or none (:598-600, :1825)
-      const double t = v1 ? t_hi : t_lo;       // :616
-      st.path_cb = fabs(t) * norm;
+  const double norm = fsqrt(1.0 + A2);
+  // entrance plane z = 0
+  const double x0 = fma(-H.length_b, sx, ex), y0 = fma(-H.length_b, sy, ey);
+  const bool hits_entrance = fma(x0, x0, y0 * y0) < H.radius_cb_sq;
+  double path_cb = H.length_b * norm;          // |exit point - entrance-plane point| (:1836-1843)
+  if (__ballot(ok && !hits_entrance)) {        // wave-uniform: some ray entered through the bore wall
+    // lineIntersectsCylinderOnce (:591-604): intersections of the line with the bore wall,
+    // t = z - lengthB:  A2 t^2 + 2 Dm t + (Qm - R^2) = 0.  inter1 = larger z, inter2 = smaller z.
+    const double Dm = fma(ex, sx, ey * sy);
+    const double c = fma(ex, ex, ey * ey) - H.radius_cb_sq;
+    const double sq = fsqrt(fma(Dm, Dm, -A2 * c));
+    const double q = (Dm >= 0.0) ? (-Dm - sq) : (-Dm + sq);
+    const double qa = q * frcp(A2), cq = c * frcp(q);
+    const double t_lo = (Dm >= 0.0) ? qa : cq, t_hi = (Dm >= 0.0) ? cq : qa;
+    const double z_hi = H.length_b + t_hi, z_lo = H.length_b + t_lo;
+    const bool v1 = (z_hi > 0.0) && (z_hi < H.length_coldbore);
+    const bool v2 = (z_lo > 0.0) && (z_lo < H.length_coldbore);
+    const double t = v1 ? t_hi : t_lo;         // :616
+    if (!hits_entrance) {
+      ok = ok && (v1 != v2);                   // exactly one valid intersection (:598-600, :1825)
+      path_cb = fabs(t) * norm;
     }
   }
+  st.path_cb = path_cb;
   // exit of the cold bore (:1846), pipe CB -> VT3 (:1856), VT3 -> XRT (:1866; same radius — sic)
-  const double dz1 = P.length_coldbore - P.length_b;
-  const double x1 = fma(dz1, sx, ex), y1 = fma(dz1, sy, ey);
-  const double dz2 = dz1 + P.pipe1_len;
-  const double x2 = fma(dz2, sx, ex), y2 = fma(dz2, sy, ey);
-  const double dz3 = dz2 + P.pipe2_len;
-  const double x3 = fma(dz3, sx, ex), y3 = fma(dz3, sy, ey);
-  if (!(fma(x1, x1, y1 * y1) < P.radius_cb_sq)) return false;
-  if (!(fma(x2, x2, y2 * y2) < P.pipe1_radius_sq)) return false;
-  if (!(fma(x3, x3, y3 * y3) < P.pipe1_radius_sq)) return false;
-  reached = true;
+  const double x1 = fma(H.dz1, sx, ex), y1 = fma(H.dz1, sy, ey);
+  const double x2 = fma(H.dz2, sx, ex), y2 = fma(H.dz2, sy, ey);
+  const double x3 = fma(H.dz3, sx, ex), y3 = fma(H.dz3, sy, ey);
+  ok = ok && (fma(x1, x1, y1 * y1) < H.radius_cb_sq) && (fma(x2, x2, y2 * y2) < H.pipe1_radius_sq) &&
+       (fma(x3, x3, y3 * y3) < H.pipe1_radius_sq);
+  reached = ok;
 
   // ---- telescope frame (:1878-1899) ----
   // pointExitCB' (z = -Lp before rotation) and pointExitPipeVT3XRT' (z = 0 before rotation)
-  const double Lp = P.pipe1_len + P.pipe2_len;
+  const double Lp = H.dz3 - H.dz1;
   double X0, Y0, tsx, tsy, zcb;
-  if (!P.rotated) {
-    X0 = x3 - P.entrance_x;
-    Y0 = y3 - P.entrance_y;
+  if (!cfg_rotated) {
+    X0 = x3 - H.entrance_x;
+    Y0 = y3 - H.entrance_y;
     tsx = sx;
     tsy = sy;
     zcb = -Lp;
@@ -383,8 +389,8 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
     double ax, ay, az, bx, by, bz;
     rot(x1, y1, -Lp, ax, ay, az);
     rot(x3, y3, 0.0, bx, by, bz);
-    ax -= P.entrance_x; ay -= P.entrance_y;
-    bx -= P.entrance_x; by -= P.entrance_y;
+    ax -= H.entrance_x; ay -= H.entrance_y;
+    bx -= H.entrance_x; by -= H.entrance_y;
     const double inv = frcp(bz - az);
     tsx = (bx - ax) * inv;
     tsy = (by - ay) * inv;
@@ -394,17 +400,27 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
   }
   st.X0 = X0; st.Y0 = Y0; st.tsx = tsx; st.tsy = tsy; st.zcb = zcb;
   const double Q0 = fma(X0, X0, Y0 * Y0);
-  const double radial = fsqrt(Q0);             // radialDist (:1905)
+  const double inv_radial = frsq(Q0);
+  const double radial = Q0 * inv_radial;       // radialDist (:1905)
 
   // ---- opaque structures (:1635-1704) ----
-  if (P.telescope_kind != SART_TK_LLNL) {      // LLNL: the graphite block never blocks (:1646)
-    bool blocked;
-    const bool inner = (P.telescope_kind == SART_TK_XMM) ? (radial <= P.inner_radius) : (radial < P.inner_radius);
-    if (inner && P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) {
-      // hole loop (:1675-1688) with lineIntersectsObject (:494-527) on the entrance plane
+  if (H.telescope_kind != SART_TK_LLNL) {      // LLNL: the graphite block never blocks (:1646)
+    const bool inner = (H.telescope_kind == SART_TK_XMM) ? (radial <= H.inner_radius) : (radial < H.inner_radius);
+    // htNone: the hole test is always false => inner disc blocked (:1683-1688, :527); Abrixas :1653;
+    // XMM ring :1691; spider spokes tested on phi = acos(x / r) at the entrance plane and at
+    // z = spider_z (:1695-1701): every 360/n degrees, |phi - k 360/n| <= w  <=>  cos(n phi) >= cos(n w)
+    const bool ring = (H.telescope_kind == SART_TK_XMM) && (radial < H.ring_hi) && (radial > H.ring_lo);
+    const double c_ent = X0 * inv_radial;
+    const double xs = fma(H.spider_z, tsx, X0), ys = fma(H.spider_z, tsy, Y0);
+    const double c_sp = xs * frsq(fma(xs, xs, ys * ys));
+    const bool spoke = (cos_n_phi(H.spoke_n, c_ent) >= H.spoke_cos_thr) || (cos_n_phi(H.spoke_n, c_sp) >= H.spoke_cos_thr);
+    bool blocked = inner || ring || spoke;
+    if (cfg_holes) {
+      // hole loop (:1675-1688) with lineIntersectsObject (:494-527) on the entrance plane; replaces the
+      // verdict for rays inside the inner disc
       const int nH = P.number_of_holes;
       const int lim = nH - (int)ceil((double)nH / 2.0);
-      bool res = false;
+      bool res = false, done = false;
       for (int l = -lim; l <= lim; ++l) {
         double hx = 0.0, hy = 0.0;
         if (l != 0) {
@@ -426,34 +442,26 @@ __device__ __forceinline__ bool phase_a(const DevParams& P, const LdsTables& L, 
           case SART_HT_DIAMOND: through = atx < rad && aty < rad; break;
           default: through = false;
         }
-        if (through) { res = false; break; } else res = true;
+        if (!done) { res = !through; done = through; }   // `break` at the first hole the ray passes through
       }
-      blocked = res;
-    } else {
-      // htNone: the hole test is always false => inner disc blocked (:1683-1688, :527); Abrixas :1653;
-      // XMM ring :1691; spider spokes tested on phi = acos(x / r) at the entrance plane and at
-      // z = spider_z (:1695-1701): every 360/n degrees, |phi - k 360/n| <= w  <=>  cos(n phi) >= cos(n w)
-      const bool ring = (P.telescope_kind == SART_TK_XMM) && (radial < P.ring_hi) && (radial > P.ring_lo);
-      const double c_ent = X0 * frcp(radial);
-      const double xs = fma(P.spider_z, tsx, X0), ys = fma(P.spider_z, tsy, Y0);
-      const double c_sp = xs * frsq(fma(xs, xs, ys * ys));
-      const bool spoke = (cos_n_phi(P.spoke_n, c_ent) >= P.spoke_cos_thr) || (cos_n_phi(P.spoke_n, c_sp) >= P.spoke_cos_thr);
-      blocked = inner || ring || spoke;
+      if (inner) blocked = res;
     }
-    if (blocked) return false;
+    ok = ok && !blocked;
   }
 
   // ---- shell selection (:1932-1957) ----
-  if (radial > P.r1_last) return false;
+  ok = ok && !(radial > H.r1_last);
   // R1 ascending: the nearest shell above is the first j with R1[j] > radial; the look-up cell (narrower
   // than any shell spacing) gives it up to one step
-  int j = (int)L.lut[min((int)(radial * P.lut_inv_step), P.lut_n - 1)];
-  if (j < P.n_shells && !(L.shells[j].r1 > radial)) ++j;
-  if (j >= P.n_shells) return false;   // radial == R1[last] exactly (measure zero; the reference uses a zero shell)
+  const int nS = H.n_shells;
+  int j = (int)L.lut[max(min((int)(radial * H.lut_inv_step), H.lut_n - 1), 0)];
+  j += (j < nS && !(L.shells[min(j, nS - 1)].r1 > radial)) ? 1 : 0;
+  ok = ok && (j < nS);   // radial == R1[last] exactly (measure zero; the reference then uses a zero shell)
   // glass front (:1942-1944): only the shell just below can contain radial (thickness < spacing, checked on the host)
-  if (j > 0 && radial > L.shells[j - 1].r1 && radial < L.shells[j - 1].r1_outer) return false;
-  st.shell = j;
-  return true;
+  const int jm = min(max(j - 1, 0), nS - 1);
+  ok = ok && !(j > 0 && radial > L.shells[jm].r1 && radial < L.shells[jm].r1_outer);
+  st.shell = min(j, nS - 1);
+  return ok;
 }
 
 // Results of phase B for one ray (record mode needs all of them; histogram mode a few).
@@ -463,16 +471,19 @@ struct RayOut {
 };
 
 // ------------------------------------------------------------------------------------------------
-// phase B: mirrors -> detector plane -> weights -> window (:1971-2221)
+// phase B: mirrors -> detector plane -> weights -> window (:1971-2221), predicated like phase A:
+// `live` carries the reference's early returns.  Dead lanes keep computing (indices are clamped so that
+// every table access stays in range); only record fields and the final outputs look at `live`.
 // ------------------------------------------------------------------------------------------------
-template <bool RECORDS>
+template <bool RECORDS, bool FAST>
 __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, const DevTables& T, const TraceArgs& A,
-                                        const RayState& st, int e_idx_in, RayOut& out, sart_axion_t* rec) {
+                                        const RayState& st, int e_idx_in, bool live, RayOut& out, sart_axion_t* rec) {
   const ShellDev& sh = L.shells[st.shell];
-  // P / A may live in LDS: branch conditions are made wave-uniform (scalar branches) explicitly
+  // P / A may live in LDS: branch conditions are made wave-uniform (scalar branches) explicitly.
+  // FAST: vacuum stage, solar source (known at compile time).
   const int wolter = __builtin_amdgcn_readfirstlane(P.telescope_wolter);
-  const int stage_gas = __builtin_amdgcn_readfirstlane(P.stage_gas);
-  const int test_active = __builtin_amdgcn_readfirstlane(P.test_active);
+  const int stage_gas = FAST ? 0 : __builtin_amdgcn_readfirstlane(P.stage_gas);
+  const int test_active = FAST ? 0 : __builtin_amdgcn_readfirstlane(P.test_active);
   const int n_half_strips = __builtin_amdgcn_readfirstlane(P.n_half_strips);
   const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.flags);
   const double X0 = st.X0, Y0 = st.Y0, tsx = st.tsx, tsy = st.tsy, zcb = st.zcb;
@@ -486,29 +497,26 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const bool hit1 = pick_root(A0 - sh.m1_k, D0 + sh.m1_hb, Q0 - sh.m1_cc, 0.0, sh.m1_zhi, z1);
   if (!hit1) z1 = zcb;                        // the reference returns its input point (:656-658)
   const double m1x = fma(z1, tsx, X0), m1y = fma(z1, tsy, Y0);
-  double n1z;
-  if (hit1) {
-    // on the surface the normal's z-component is closed-form: cone tan(b) rho(z); paraboloid r3 tan(b)
-    n1z = wolter ? sh.n1_r3t : sh.n1_tan * fma(-sh.n1_tan, z1, sh.r1);
-  } else {
-    n1z = normal_z_general(P, sh, 1, m1x, m1y, z1);
+  // on the surface the normal's z-component is closed-form: cone tan(b) rho(z); paraboloid r3 tan(b)
+  double n1z = wolter ? sh.n1_r3t : sh.n1_tan * fma(-sh.n1_tan, z1, sh.r1);
+  if (__ballot(live && !hit1)) {              // wave-uniform: the normal at the (off-surface) input point
+    const double g = normal_z_general(P, sh, 1, m1x, m1y, z1);
+    n1z = hit1 ? n1z : g;
   }
   double wx = tsx, wy = tsy, wz = 1.0;
   const double N1 = fma(m1x, m1x, fma(m1y, m1y, n1z * n1z));
   const double sin2_a1 = reflect(wx, wy, wz, L0, m1x, m1y, n1z, N1);
 
   // lineHitsNickel (:1706-1734), evaluated before the no-hit test (:2040-2057):
-  // tan(a1) > num / (l - z1)  <=>  sin^2(a1) ((l - z1)^2 + num^2) > num^2   (num, l - z1 > 0)
-  if (st.shell > 0) {
+  // tan(a1) > num / (l - z1)  <=>  sin^2(a1) ((l - z1)^2 + num^2) > num^2   (num >= 0, l - z1 > 0)
+  {
     const double lz = P.l_mirror - z1, num = sh.nickel_num;
-    if (lz > 0.0 && num >= 0.0) out.hit_nickel = sin2_a1 * fma(lz, lz, num * num) > num * num;
-    else out.hit_nickel = sqrt(sin2_a1 / (1.0 - sin2_a1)) > num / lz;
+    const bool nick = (lz > 0.0) ? (sin2_a1 * fma(lz, lz, num * num) > num * num)
+                                 : (fsqrt(sin2_a1 / (1.0 - sin2_a1)) > num / lz);
+    out.hit_nickel = live && (st.shell > 0) && nick;
   }
-  if (out.hit_nickel) {
-    if (RECORDS) rec->hitNickel = 1;
-    return;
-  }
-  if (!hit1) return;                          // almostEqual(z1, z0) (:2055)
+  if (RECORDS && out.hit_nickel) rec->hitNickel = 1;
+  live = live && !out.hit_nickel && hit1;     // nickel (:2045), almostEqual(z1, z0) (:2055)
 
   // ---- mirror 2 (:1994-2001 / :2021-2028): ray through (m1x, m1y, z1) along w ----
   const double inv_wz = frcp(wz);
@@ -519,11 +527,11 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const double Q1 = fma(X1, X1, Y1 * Y1);
   double z2;
   const bool hit2 = pick_root(A1 - sh.m2_k, D1 + sh.m2_hb, Q1 - sh.m2_cc, sh.m2_zlo, sh.m2_zhi, z2);
-  if (!hit2) return;                          // almostEqual(z1, z2) (:2055)
+  live = live && hit2;                        // almostEqual(z1, z2) (:2055)
+  if (!hit2) z2 = sh.m2_zlo;
   const double m2x = fma(z2, s2x, X1), m2y = fma(z2, s2y, Y1);
-  double n2z;
-  if (wolter) n2z = sh.n2_r3t * fma(2.0 * (P.l_mirror - z2), sh.n2_invF, 1.0);
-  else n2z = sh.n2_tan * fma(-sh.n2_tan, z2 - sh.m2_zlo, sh.m2_rc);
+  const double n2z = wolter ? sh.n2_r3t * fma(2.0 * (P.l_mirror - z2), sh.n2_invF, 1.0)
+                            : sh.n2_tan * fma(-sh.n2_tan, z2 - sh.m2_zlo, sh.m2_rc);
   const double N2 = fma(m2x, m2x, fma(m2y, m2y, n2z * n2z));
   const double sin2_a2 = reflect(wx, wy, wz, L0, m2x, m2y, n2z, N2);
 
@@ -539,7 +547,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   // yaw angle (:2101-2115): ya = deg(atan2(-v_z, -v_y)) + 90 = -deg(atan(v_y / v_z))
   const double ya = -atan_small(tsy) * 57.29577951308232;
 
-  if (RECORDS) {
+  if (RECORDS && live) {
     const double nend = (sh.dist_det_end - pmz) * inv_vz;
     const double ddx = (nend - nwin) * vx, ddy = (nend - nwin) * wy;
     rec->deviationDet = sqrt(fma(ddx, ddx, ddy * ddy));           // :2085-2088
@@ -579,60 +587,58 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     // computeReflectivity (:1533-1580): bilinear in (angle, energy); the energy interpolation is folded
     // into the per-energy-index table, leaving a linear interpolation in the angle.
     const double* tab = T.refl + ((size_t)sh.coating * (size_t)(P.n_energies + 1) + (size_t)e_idx) * (size_t)P.refl_n_angles;
+    const int na2 = P.refl_n_angles - 2;
+    const double amin = P.refl_angle_min, inv_da = P.refl_inv_dangle, da = P.refl_dangle;
     auto refl_at = [&](double sin2a) {
       const double alpha = asin_small(fsqrt(sin2a)) * 57.29577951308232;   // getMirrorAngle (:782-795), degrees
-      const double t = (alpha - P.refl_angle_min) * P.refl_inv_dangle;
-      int i = (int)floor(t);
-      i = max(min(i, P.refl_n_angles - 2), 0);
-      const double xu = (alpha - (P.refl_angle_min + (double)i * P.refl_dangle)) * P.refl_inv_dangle;
+      const double t = (alpha - amin) * inv_da;
+      int i = (int)floor(t);          // NaN -> 0
+      i = max(min(i, na2), 0);
+      const double xu = (alpha - (amin + (double)i * da)) * inv_da;
       const double g0 = tab[i], g1 = tab[i + 1];
       return fma(xu, g1 - g0, g0);
     };
     reflectv = refl_at(sin2_a1) * refl_at(sin2_a2);
     weight = reflectv * trans_magnet;
   }
-  if (RECORDS) {
+  if (RECORDS && live) {
     rec->transmissionMagnet = trans_magnet;
     rec->yawAngles = ya;
     rec->reflect = reflectv;
   }
 
-  if (test_active && (sh.r1 - fsqrt(Q0)) > 100.0) {   // straight through the hole in the optics (:2130-2132)
-    pdx = fma(sh.dist_det_raw, tsx, X0);
-    pdy = fma(sh.dist_det_raw, tsy, Y0);
-    pdz = sh.dist_det_raw;
+  if (test_active) {   // straight through the hole in the optics (:2130-2132)
+    const bool through = (sh.r1 - fsqrt(Q0)) > 100.0;
+    pdx = through ? fma(sh.dist_det_raw, tsx, X0) : pdx;
+    pdy = through ? fma(sh.dist_det_raw, tsy, Y0) : pdy;
+    pdz = through ? sh.dist_det_raw : pdz;
   }
   pdx -= P.lateral_shift;
   pdy -= P.transversal_shift;
-  if (weight != 0.0) {
-    out.till_window = true;
-    if (RECORDS) rec->passedTillWindow = 1;
-  }
+  out.till_window = live && (weight != 0.0);
+  if (RECORDS && out.till_window) rec->passedTillWindow = 1;
 
   // ---- detector window / chip (:2138-2147) ----
   const double rdet2 = fma(pdx, pdx, pdy * pdy);
-  if (!(flags & SART_CF_IGNORE_DET_WINDOW) && rdet2 > P.radius_window_sq) return;
-  if (fabs(pdx) > P.chip_cx || fabs(pdy) > P.chip_cy) return;
+  live = live && !(!(flags & SART_CF_IGNORE_DET_WINDOW) && rdet2 > P.radius_window_sq);
+  live = live && !(fabs(pdx) > P.chip_cx || fabs(pdy) > P.chip_cy);
 
   // window strips (:2149-2187): rotateAroundZ by theta, strips along x
   const double yt = fabs(fma(pdy, P.theta_c, -pdx * P.theta_s));
-  double trans_window = 0.0;
-  uint8_t kind_w = 0;
-  for (int i = 0; i < n_half_strips; ++i) {
-    if (yt > P.strip_lo[i] && yt < P.strip_hi[i]) { trans_window = en.t_strongback; kind_w = SART_MK_SI; break; }
-    trans_window = en.t_window;
-    kind_w = SART_MK_SI3N4;
-  }
+  bool in_strip = false;
+  for (int i = 0; i < n_half_strips; ++i) in_strip = in_strip || (yt > P.strip_lo[i] && yt < P.strip_hi[i]);
+  const double trans_window = (n_half_strips > 0) ? (in_strip ? en.t_strongback : en.t_window) : 0.0;
+  const uint8_t kind_w = in_strip ? SART_MK_SI : SART_MK_SI3N4;
   if (!(flags & SART_CF_IGNORE_DET_WINDOW)) weight *= trans_window;
-  if (!(flags & SART_CF_IGNORE_GAS_ABS)) weight *= en.a_gas;       // :2190-2192
-  if (!(flags & SART_CF_XRAY_TEST)) weight *= P.exposure;           // :2207-2212
+  if (!(flags & SART_CF_IGNORE_GAS_ABS)) weight *= en.a_gas;         // :2190-2192
+  if (!(flags & SART_CF_XRAY_TEST)) weight *= P.exposure;             // :2207-2212
 
-  out.finished = true;
+  out.finished = live;
   out.rdet = fsqrt(rdet2);
   out.px = -pdx + P.chip_cx;                                          // :2203-2204
   out.py = pdy + P.chip_cy;
   out.weight = weight;
-  if (RECORDS) {
+  if (RECORDS && live) {
     if (n_half_strips > 0) {
       rec->transProbWindow = trans_window;
       rec->energiesAxWindow = en.energy;
@@ -689,18 +695,26 @@ __device__ __forceinline__ void stage_tables(TablesLds& S, const DevParams& P, c
 
 // Fused trace + accumulate (traceAxionWrapper + prepareHeatmap + flux sum + counters) with wavefront
 // compaction between phase A and phase B.  Ray i of this launch has the global id ray_id_offset + i.
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(DevParams P, DevTables T, TraceArgs A,
+template <int BLOCK, bool FAST>
+__global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
                                                                 double* __restrict__ acc) {
   __shared__ TablesLds S;
   __shared__ QueueLds<BLOCK / 64> Q;
-  // Phase B reads its ~60 loop-invariant scalars from an LDS copy (broadcast ds_read): together with
-  // phase A's they do not fit the 102 SGPRs of a wave and would be spilled through VGPR lanes.
-  __shared__ DevParams Pb;
-  __shared__ DevTables Tb;
+  // Only the ~20 scalars phase A needs for every ray travel in the kernel arguments (SGPRs); everything
+  // else is read from an LDS copy of the parameter blob (broadcast ds_read).  All of them together do not
+  // fit the 102 SGPRs of a wave and would be spilled through VGPR lanes (v_readlane = VALU slots).
+  __shared__ DevBlob B;
   __shared__ TraceArgs Ab;
-  if (threadIdx.x == 0) { Pb = P; Tb = T; Ab = A; }
-  stage_tables<BLOCK>(S, P, T);
+  {
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(blob);
+    uint64_t* dst = reinterpret_cast<uint64_t*>(&B);
+    for (int i = threadIdx.x; i < (int)(sizeof(DevBlob) / 8); i += BLOCK) dst[i] = src[i];
+    if (threadIdx.x == 0) Ab = A;
+    __syncthreads();
+  }
+  const DevParams& Pb = B.P;
+  const DevTables& Tb = B.T;
+  stage_tables<BLOCK>(S, Pb, Tb);
   const LdsTables L{S.rcdf, S.rguide, S.shells, S.lut};
 
   const int lane = threadIdx.x & 63;
@@ -718,14 +732,17 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(DevParams P, Dev
     const bool valid = (uint32_t)lane < n_valid;
     const uint32_t slot = (head + (uint32_t)lane) % kQueue;
     RayOut out;
-    if (valid) {
+    {
+      // slots beyond n_valid hold stale (or never written) data: lanes compute on them predicated off,
+      // with their indices clamped into range
       st.X0 = Q.X0[wave][slot]; st.Y0 = Q.Y0[wave][slot];
       st.tsx = Q.tsx[wave][slot]; st.tsy = Q.tsy[wave][slot];
       st.path_cb = Q.path[wave][slot]; st.u5 = Q.u5[wave][slot]; st.zcb = Q.zcb[wave][slot];
-      const int packed = Q.idx[wave][slot];
-      st.r_idx = packed & 0xFFFF;
-      st.shell = packed >> 16;
-      phase_b<false>(Pb, L, Tb, Ab, st, P.test_active ? P.n_energies : -1, out, nullptr);
+      const int packed = valid ? Q.idx[wave][slot] : 0;
+      st.r_idx = min(packed & 0xFFFF, Pb.n_radii - 1);
+      st.shell = min(packed >> 16, H.n_shells - 1);
+      st.u5 = valid ? st.u5 : 0.0;
+      phase_b<false, FAST>(Pb, L, Tb, Ab, st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
     }
     head += n_valid;
     n_nickel += (uint32_t)__popcll(__ballot(out.hit_nickel));
@@ -753,7 +770,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(DevParams P, Dev
     const uint64_t i = base + (uint64_t)lane;
     RayState st;
     bool sampled = false, reached = false, alive = false;
-    if (i < A.n_rays) alive = phase_a(P, L, A, A.ray_id_offset + i, st, sampled, reached);
+    if (i < A.n_rays) alive = phase_a<FAST>(H, Pb, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
     n_reached += (uint32_t)__popcll(__ballot(reached));
     const uint64_t mask = __ballot(alive);
     const uint32_t cnt = (uint32_t)__popcll(mask);
@@ -803,9 +820,18 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(DevParams P, Dev
 
 // Literal drop-in for traceAxionWrapper: one Axion record per ray, in ray order (no compaction).
 constexpr int kRecBlock = 256;
-__global__ __launch_bounds__(kRecBlock) void trace_records_kernel(DevParams P, DevTables T, TraceArgs A,
+__global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
                                                                    sart_axion_t* __restrict__ out) {
   __shared__ TablesLds S;
+  __shared__ DevBlob B;
+  {
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(blob);
+    uint64_t* dst = reinterpret_cast<uint64_t*>(&B);
+    for (int i = threadIdx.x; i < (int)(sizeof(DevBlob) / 8); i += kRecBlock) dst[i] = src[i];
+    __syncthreads();
+  }
+  const DevParams& P = B.P;
+  const DevTables& T = B.T;
   stage_tables<kRecBlock>(S, P, T);
   const LdsTables L{S.rcdf, S.rguide, S.shells, S.lut};
 
@@ -814,49 +840,60 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(DevParams P, D
     sart_axion_t rec = {};   // newSeq[Axion] zero-initialises (:2760)
     RayState st;
     bool sampled, reached;
-    const bool alive = phase_a(P, L, A, A.ray_id_offset + i, st, sampled, reached);
+    const bool alive = phase_a<false>(H, P, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
     int e_idx = -1;
     if (sampled) {
-      e_idx = P.test_active ? P.n_energies : sample_energy_index(P, T, st.r_idx, st.u5);
+      e_idx = H.test_active ? P.n_energies : sample_energy_index(P, T, st.r_idx, st.u5);
       rec.emratesPre = 1.0;                          // :1818
       rec.energiesPre = T.energy_tab[e_idx].energy;  // :1819
     }
-    if (alive) {
+    if (__ballot(alive)) {
       RayOut ro;
-      phase_b<true>(P, L, T, A, st, e_idx, ro, &rec);
+      if (!sampled) { st.u5 = 0.0; st.r_idx = 0; }
+      phase_b<true, false>(P, L, T, A, st, e_idx >= 0 ? e_idx : 0, alive, ro, &rec);
     }
     out[i] = rec;
   }
 }
 
 // ---- launch wrappers (called from sart_api.hip) ----
-static int g_hist_block = 512;
+static int g_hist_block = 1024;
 void set_histogram_block(int block) { g_hist_block = block; }
 int histogram_block() { return g_hist_block; }
 int records_block() { return kRecBlock; }
-// resident workgroups per CU for the persistent grid (occupancy API: LDS- and register-limited)
-int histogram_blocks_per_cu(int block) {
-  int n = 0;
-  hipError_t e;
+template <bool FAST>
+static hipError_t occupancy_of(int block, int* n) {
   switch (block) {
-    case 512: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<512>, 512, 0); break;
-    case 1024: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024>, 1024, 0); break;
-    default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<256>, 256, 0); break;
+    case 512: return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, trace_histogram_kernel<512, FAST>, 512, 0);
+    case 768: return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, trace_histogram_kernel<768, FAST>, 768, 0);
+    case 1024: return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, trace_histogram_kernel<1024, FAST>, 1024, 0);
+    default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, trace_histogram_kernel<256, FAST>, 256, 0);
   }
+}
+// resident workgroups per CU for the persistent grid (occupancy API: LDS- and register-limited)
+int histogram_blocks_per_cu(int block, bool fast) {
+  int n = 0;
+  const hipError_t e = fast ? occupancy_of<true>(block, &n) : occupancy_of<false>(block, &n);
   return (e == hipSuccess && n > 0) ? n : 1;
 }
 
-void launch_trace_histogram(const DevParams& P, const DevTables& T, const TraceArgs& A, double* acc, int n_blocks,
-                            hipStream_t stream) {
+template <bool FAST>
+static void launch_hist(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks, hipStream_t stream) {
   switch (g_hist_block) {
-    case 512: hipLaunchKernelGGL(trace_histogram_kernel<512>, dim3(n_blocks), dim3(512), 0, stream, P, T, A, acc); break;
-    case 1024: hipLaunchKernelGGL(trace_histogram_kernel<1024>, dim3(n_blocks), dim3(1024), 0, stream, P, T, A, acc); break;
-    default: hipLaunchKernelGGL(trace_histogram_kernel<256>, dim3(n_blocks), dim3(256), 0, stream, P, T, A, acc); break;
+    case 512: hipLaunchKernelGGL((trace_histogram_kernel<512, FAST>), dim3(n_blocks), dim3(512), 0, stream, H, blob, A, acc); break;
+    case 768: hipLaunchKernelGGL((trace_histogram_kernel<768, FAST>), dim3(n_blocks), dim3(768), 0, stream, H, blob, A, acc); break;
+    case 1024: hipLaunchKernelGGL((trace_histogram_kernel<1024, FAST>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc); break;
+    default: hipLaunchKernelGGL((trace_histogram_kernel<256, FAST>), dim3(n_blocks), dim3(256), 0, stream, H, blob, A, acc); break;
   }
 }
-void launch_trace_records(const DevParams& P, const DevTables& T, const TraceArgs& A, sart_axion_t* out, int n_blocks,
+void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
+                            hipStream_t stream, bool fast) {
+  if (fast) launch_hist<true>(H, blob, A, acc, n_blocks, stream);
+  else launch_hist<false>(H, blob, A, acc, n_blocks, stream);
+}
+void launch_trace_records(const HotA& H, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream) {
-  hipLaunchKernelGGL(trace_records_kernel, dim3(n_blocks), dim3(kRecBlock), 0, stream, P, T, A, out);
+  hipLaunchKernelGGL(trace_records_kernel, dim3(n_blocks), dim3(kRecBlock), 0, stream, H, blob, A, out);
 }
 
 }  // namespace sart
