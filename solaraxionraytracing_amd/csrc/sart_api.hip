@@ -423,6 +423,57 @@ HotA hot_of(const DevParams& P) {
   return h;
 }
 
+// Stage A0 zones (see HotA).  With r = R sqrt(u3) the distance of the point on the bore exit from the axis and
+// |slope| <= s_max for every ray from the Sun, the ray's distance from the axis at a plane dz further on lies in
+// [r - dz s_max, r + dz s_max].  From that: (a) r - dz_k s_max >= R_k for one of the three cuts behind the
+// magnetic field (cold-bore exit, two pipe cuts; raytracer.nim:1846-1868) => dead, not "reached";
+// (b) telescopes on the magnet axis (entrance offset 0, not rotated): r certainly inside bore + pipes and
+// certainly inside the inner disc / the XMM ring / beyond the outermost shell (:1653, :1674-1692, :1934) => dead,
+// "reached".  Every bound carries a safety margin far above f64 rounding, so the verdict equals the reference's.
+void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h) {
+  h.n_zones = 0;
+  h.zone_reached = 0;
+  if (P.test_active || P.rotated || n_radii < 1) return;
+  const double R = P.radius_cb;
+  const double r_sun_max = (0.0015 + (n_radii - 1) * 0.0005) * P.sun_radius;
+  const double s_max = (r_sun_max + R) / (P.sun_distance + P.length_b - r_sun_max) * (1.0 + 1e-6);
+  const double eps = 1e-6;  // mm
+  const double dz[3] = {h.dz1, h.dz2, h.dz3};
+  const double Rk[3] = {R, std::sqrt(P.pipe1_radius_sq), std::sqrt(P.pipe1_radius_sq)};
+  // (a) r >= K_dead => dead
+  double K_dead = 1e300;
+  for (int k = 0; k < 3; ++k) K_dead = std::min(K_dead, Rk[k] + dz[k] * s_max + eps);
+  // r <= K_in => certainly through entrance plane, cold-bore exit and both pipes
+  double K_in = R - P.length_b * s_max - eps;
+  for (int k = 0; k < 3; ++k) K_in = std::min(K_in, Rk[k] - dz[k] * s_max - eps);
+  const double spread = dz[2] * s_max + eps;   // radial uncertainty at the telescope entrance
+  struct Z { double lo, hi; bool reached; };
+  std::vector<Z> zones;
+  if (K_dead < R) zones.push_back({K_dead, 1e300, false});
+  const bool on_axis = (P.entrance_x == 0.0 && P.entrance_y == 0.0);
+  if (on_axis && K_in > 0) {
+    auto add_reached = [&](double lo, double hi) {   // radial in [lo, hi] certainly => blocked; clip to r <= K_in
+      hi = std::min(hi, K_in);
+      if (hi > lo) zones.push_back({lo, hi, true});
+    };
+    if (s.telescope_kind == SART_TK_XMM && P.inner_blocks > 0) add_reached(0.0, P.inner_radius - spread);       // r <= 64.7
+    if (s.telescope_kind == SART_TK_ABRIXAS) add_reached(0.0, P.inner_radius - spread);                          // r < 37.5
+    if (s.telescope_kind == SART_TK_XMM) add_reached(P.ring_lo + spread, P.ring_hi - spread);                    // ring
+    add_reached(P.r1_last + spread, std::min(K_in, K_dead));                                                      // beyond the last shell
+  }
+  for (const Z& z : zones) {
+    if (h.n_zones >= kMaxZones) break;
+    // u3 = (r/R)^2; hi word w covers u3 in [w, w+1) / 2^32: keep only words entirely inside the zone
+    const double ulo = std::min(1.0, (z.lo / R) * (z.lo / R)), uhi = std::min(1.0, (z.hi / R) * (z.hi / R));
+    const double wlo = std::ceil(ulo * 4294967296.0) + 1.0, whi = std::floor(uhi * 4294967296.0) - 2.0;
+    if (!(whi >= wlo)) continue;
+    h.zone_lo[h.n_zones] = static_cast<uint32_t>(std::min(wlo, 4294967295.0));
+    h.zone_hi[h.n_zones] = static_cast<uint32_t>(std::min(whi, 4294967295.0));
+    if (z.reached) h.zone_reached |= (1u << h.n_zones);
+    h.n_zones++;
+  }
+}
+
 DevTables tables_of(sart_context* c);
 
 // (Re)uploads the parameter blob if the host mirror changed.  Ordered after all work already queued on
@@ -436,6 +487,7 @@ int sync_blob(sart_context* c) {
   b.T = tables_of(c);
   if (int rc = c->d_blob.upload(&b, 1)) return rc;
   c->hot = hot_of(c->params);
+  if (!std::getenv("SART_NO_EARLY_REJECT")) build_zones(c->setup, c->params, c->n_radii, c->hot);
   c->blob_dirty = false;
   return 0;
 }
@@ -693,6 +745,18 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   if (!p->accumulate)
     SART_HIP(hipMemsetAsync(acc_dev, 0, sart_accumulator_len(p->image_nx, p->image_ny) * sizeof(double), c->stream));
   if (a.n_rays == 0) return 0;
+  if (a.n_rays > (1ull << 31)) {   // ray indices inside one launch are 32-bit (stage A0 ring): split
+    sart_trace_params_t q = *p;
+    q.accumulate = 1;
+    for (uint64_t done = 0; done < p->n_rays;) {
+      const uint64_t n = std::min<uint64_t>(p->n_rays - done, 1ull << 31);
+      q.n_rays = n;
+      q.ray_id_offset = p->ray_id_offset + done;
+      if (int rc = sart_trace_histogram_device(c, &q, acc_dev)) return rc;
+      done += n;
+    }
+    return 0;
+  }
   if (c->blocks_per_cu_hist == 0) {
     if (const char* e = std::getenv("SART_HIST_BLOCK")) set_histogram_block(std::atoi(e));   // tuning knob
     c->blocks_per_cu_hist = std::max(1, histogram_blocks_per_cu(histogram_block(), true));

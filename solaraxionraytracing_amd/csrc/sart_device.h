@@ -129,7 +129,15 @@ struct HotA {
   double spider_z, spoke_cos_thr, inner_radius, ring_lo, ring_hi;
   int32_t test_active, rotated, telescope_kind, spoke_n;
   int32_t n_shells, lut_n, radius_span, inner_blocks;
+  // Stage A0 (early rejection on the bore-exit radius alone): the hi word w of the uniform u3 that sets the
+  // radius of the point on the bore exit (r = R sqrt(u3), raytracer.nim:418) lies in zone z if
+  // zone_lo[z] <= w <= zone_hi[z]; rays in a zone provably die before the mirrors.  Bit z of zone_reached:
+  // they provably pass bore + pipes first (they still count as "reached the telescope").  0 zones: stage off.
+  int32_t n_zones;
+  uint32_t zone_reached;
+  uint32_t zone_lo[4], zone_hi[4];
 };
+constexpr int kMaxZones = 4;
 
 // Device pointers of one context.
 struct DevTables {

@@ -672,11 +672,13 @@ struct __align__(16) TablesLds {
 };
 
 // per-wave survivor rings (structure of arrays: lane i reads slot (head + i) % 128 -> conflict-free)
-template <int WAVES>
+template <int WAVES, bool FAST>
 struct __align__(16) QueueLds {
   double X0[WAVES][kQueue], Y0[WAVES][kQueue], tsx[WAVES][kQueue], tsy[WAVES][kQueue];
-  double path[WAVES][kQueue], u5[WAVES][kQueue], zcb[WAVES][kQueue];
-  int idx[WAVES][kQueue];   // r_idx | shell << 16
+  double path[WAVES][kQueue], u5[WAVES][kQueue];
+  double zcb[FAST ? 1 : WAVES][kQueue];   // z of pointExitCB: constant unless the telescope is rotated
+  int idx[WAVES][kQueue];                 // r_idx | shell << 16
+  uint32_t ray[FAST ? WAVES : 1][kQueue]; // ring 0 (FAST only): launch indices of rays that passed stage A0
 };
 
 template <int BLOCK>
@@ -693,13 +695,18 @@ __device__ __forceinline__ void stage_tables(TablesLds& S, const DevParams& P, c
   __syncthreads();
 }
 
-// Fused trace + accumulate (traceAxionWrapper + prepareHeatmap + flux sum + counters) with wavefront
-// compaction between phase A and phase B.  Ray i of this launch has the global id ray_id_offset + i.
+// Fused trace + accumulate (traceAxionWrapper + prepareHeatmap + flux sum + counters) as a three-stage
+// pipeline inside one persistent wave, with wavefront compaction (ballot + prefix count into per-wave LDS
+// rings) between the stages:
+//   A0  one Philox block -> radius of the point on the bore exit -> provably dead rays leave (HotA zones)
+//   A1  phase A (full sampling + cuts + shell selection) on full waves of A0 survivors
+//   B   phase B (mirrors + weights + accumulation) on full waves of A1 survivors
+// Ray i of this launch has the global id ray_id_offset + i; n_rays < 2^32 per launch.
 template <int BLOCK, bool FAST>
 __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
                                                                 double* __restrict__ acc) {
   __shared__ TablesLds S;
-  __shared__ QueueLds<BLOCK / 64> Q;
+  __shared__ QueueLds<BLOCK / 64, FAST> Q;
   // Only the ~20 scalars phase A needs for every ray travel in the kernel arguments (SGPRs); everything
   // else is read from an LDS copy of the parameter blob (broadcast ds_read).  All of them together do not
   // fit the 102 SGPRs of a wave and would be spilled through VGPR lanes (v_readlane = VALU slots).
@@ -721,30 +728,64 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   const int wave = threadIdx.x >> 6;
   const uint64_t waves_total = (uint64_t)gridDim.x * (BLOCK / 64);
   const uint64_t wave_global = (uint64_t)blockIdx.x * (BLOCK / 64) + wave;
+  const bool early_reject = FAST && (H.n_zones > 0);
 
   // wave-uniform counters (ballot + popcount) and per-lane sums
   uint32_t n_reached = 0, n_shell = 0, n_nickel = 0, n_till = 0, n_passed = 0, n_outside = 0;
   double sum_w = 0.0, sum_w2 = 0.0, sum_x = 0.0, sum_y = 0.0, sum_r = 0.0;
-  uint32_t head = 0, tail = 0;   // ring positions (monotone; slot = pos % kQueue)
+  uint32_t h0 = 0, t0 = 0;   // ring 0 (A0 -> A1) positions, monotone; slot = pos % kQueue
+  uint32_t h1 = 0, t1 = 0;   // ring 1 (A1 -> B)
+
+  // LDS accesses of one wave execute in order; the fences only keep the compiler from reordering them
+  auto ring_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto prefix_of = [](uint64_t mask) {   // number of set mask bits below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  };
+
+  // stage A1 for the ray with launch index i (valid lanes only count)
+  auto run_phase_a = [&](uint64_t i, bool valid) {
+    RayState st;
+    bool sampled = false, reached = false;
+    const bool ok = phase_a<FAST>(H, Pb, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
+    const bool alive = valid && ok;
+    n_reached += (uint32_t)__popcll(__ballot(valid && reached));
+    const uint64_t mask = __ballot(alive);
+    const uint32_t cnt = (uint32_t)__popcll(mask);
+    n_shell += cnt;
+    if (alive) {
+      const uint32_t slot = (t1 + prefix_of(mask)) % kQueue;
+      Q.X0[wave][slot] = st.X0; Q.Y0[wave][slot] = st.Y0;
+      Q.tsx[wave][slot] = st.tsx; Q.tsy[wave][slot] = st.tsy;
+      Q.path[wave][slot] = st.path_cb; Q.u5[wave][slot] = st.u5;
+      if (!FAST) Q.zcb[wave][slot] = st.zcb;
+      Q.idx[wave][slot] = st.r_idx | (st.shell << 16);
+    }
+    t1 += cnt;
+  };
 
   auto run_phase_b = [&](uint32_t n_valid) {
     RayState st;
     const bool valid = (uint32_t)lane < n_valid;
-    const uint32_t slot = (head + (uint32_t)lane) % kQueue;
+    const uint32_t slot = (h1 + (uint32_t)lane) % kQueue;
     RayOut out;
     {
       // slots beyond n_valid hold stale (or never written) data: lanes compute on them predicated off,
       // with their indices clamped into range
       st.X0 = Q.X0[wave][slot]; st.Y0 = Q.Y0[wave][slot];
       st.tsx = Q.tsx[wave][slot]; st.tsy = Q.tsy[wave][slot];
-      st.path_cb = Q.path[wave][slot]; st.u5 = Q.u5[wave][slot]; st.zcb = Q.zcb[wave][slot];
+      st.path_cb = Q.path[wave][slot]; st.u5 = Q.u5[wave][slot];
+      st.zcb = FAST ? -(H.dz3 - H.dz1) : Q.zcb[FAST ? 0 : wave][slot];
       const int packed = valid ? Q.idx[wave][slot] : 0;
       st.r_idx = min(packed & 0xFFFF, Pb.n_radii - 1);
       st.shell = min(packed >> 16, H.n_shells - 1);
       st.u5 = valid ? st.u5 : 0.0;
       phase_b<false, FAST>(Pb, L, Tb, Ab, st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
     }
-    head += n_valid;
+    h1 += n_valid;
     n_nickel += (uint32_t)__popcll(__ballot(out.hit_nickel));
     n_till += (uint32_t)__popcll(__ballot(out.till_window));
     const bool passed = out.finished && out.weight != 0.0;
@@ -766,37 +807,55 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     n_outside += (uint32_t)__popcll(__ballot(out.outside));
   };
 
-  for (uint64_t base = wave_global * 64; base < A.n_rays; base += waves_total * 64) {
-    const uint64_t i = base + (uint64_t)lane;
-    RayState st;
-    bool sampled = false, reached = false, alive = false;
-    if (i < A.n_rays) alive = phase_a<FAST>(H, Pb, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
-    n_reached += (uint32_t)__popcll(__ballot(reached));
-    const uint64_t mask = __ballot(alive);
-    const uint32_t cnt = (uint32_t)__popcll(mask);
-    n_shell += cnt;
-    if (alive) {
-      // position among the survivors of this wave: number of set mask bits below this lane
-      const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-      const uint32_t slot = (tail + below) % kQueue;
-      Q.X0[wave][slot] = st.X0; Q.Y0[wave][slot] = st.Y0;
-      Q.tsx[wave][slot] = st.tsx; Q.tsy[wave][slot] = st.tsy;
-      Q.path[wave][slot] = st.path_cb; Q.u5[wave][slot] = st.u5; Q.zcb[wave][slot] = st.zcb;
-      Q.idx[wave][slot] = st.r_idx | (st.shell << 16);
+  uint64_t base = wave_global * 64;
+  for (;;) {
+    const bool have_new = base < A.n_rays;   // wave-uniform
+    if (have_new) {
+      const uint64_t i = base + (uint64_t)lane;
+      const bool valid = i < A.n_rays;
+      if (early_reject) {
+        // ---- stage A0: hi word of u3 (word 2 of Philox block 1) against the zones ----
+        const uint64_t ray_id = A.ray_id_offset + i;
+        const U4 b1 = philox4x32_10((uint32_t)ray_id, (uint32_t)(ray_id >> 32), 1u, 0u, A.seed_lo, A.seed_hi);
+        const uint32_t w = b1.z;
+        bool dead = false, dead_reached = false;
+        for (int z = 0; z < H.n_zones; ++z) {
+          const bool in = (w >= H.zone_lo[z]) && (w <= H.zone_hi[z]);
+          dead = dead || in;
+          dead_reached = dead_reached || (in && ((H.zone_reached >> z) & 1u));
+        }
+        n_reached += (uint32_t)__popcll(__ballot(valid && dead_reached));
+        const bool go = valid && !dead;
+        const uint64_t mask = __ballot(go);
+        if (go) Q.ray[FAST ? wave : 0][(t0 + prefix_of(mask)) % kQueue] = (uint32_t)i;
+        t0 += (uint32_t)__popcll(mask);
+      } else {
+        run_phase_a(i, valid);   // no early-rejection stage for this configuration
+      }
+      base += waves_total * 64;
+      ring_sync();
     }
-    tail += cnt;
-    // LDS accesses of one wave execute in order; the fence only keeps the compiler from reordering them
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (tail - head >= 64u) {
-      run_phase_b(64u);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (early_reject) {
+      // ---- stage A1 on a full wave of A0 survivors (or on the remainder once the input is exhausted) ----
+      const uint32_t n0 = t0 - h0;
+      if (n0 >= 64u || (!have_new && n0 > 0u)) {
+        const uint32_t m = min(n0, 64u);
+        const bool v = (uint32_t)lane < m;
+        const uint32_t idx = v ? Q.ray[FAST ? wave : 0][(h0 + (uint32_t)lane) % kQueue] : 0u;
+        h0 += m;
+        run_phase_a((uint64_t)idx, v);
+        ring_sync();
+      }
     }
+    // ---- stage B on a full wave of A1 survivors (or on the remainder at the very end) ----
+    const uint32_t n1 = t1 - h1;
+    const bool draining = !have_new && (t0 == h0);
+    if (n1 >= 64u || (draining && n1 > 0u)) {
+      run_phase_b(min(n1, 64u));
+      ring_sync();
+    }
+    if (draining && t1 == h1) break;
   }
-  if (tail - head > 0u) run_phase_b(tail - head);
 
   // scalars: wave reduction, then one atomic per wave and quantity
   double* sc = acc + (size_t)A.image_nx * (size_t)A.image_ny;
