@@ -120,6 +120,7 @@ struct sart_context {
   DevBuf<double> d_rcdf, d_ecdf, d_refl;
   DevBuf<uint16_t> d_rguide, d_eguide;
   DevBuf<EnergyDev> d_etab;
+  DevBuf<double> d_replicas;   // kImageReplicas scratch images (kept zeroed between launches)
   DevBuf<double> d_acc;        // scratch accumulator of the blocking convenience call
   DevBuf<sart_axion_t> d_rec;  // scratch records of the blocking convenience call
   bool derived_dirty = true;
@@ -390,11 +391,15 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   if (!p) return fail(SART_ERR_INVALID_ARGUMENT, "params is NULL");
   if (p->image_nx < 1 || p->image_ny < 1 || !(p->image_x_max > p->image_x_min) || !(p->image_y_max > p->image_y_min))
     return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
+  a.replicas = nullptr;
+  a.replica_mask = 0u;
+  a._pad = 0u;
   a.n_rays = p->n_rays;
   a.ray_id_offset = p->ray_id_offset;
   a.seed_lo = static_cast<uint32_t>(p->seed);
   a.seed_hi = static_cast<uint32_t>(p->seed >> 32);
   a.flags = p->flags;
+  if (std::getenv("SART_DEBUG_NO_IMAGE_ATOMICS")) a.flags |= 0x40000000u;   // timing experiment only
   a.image_nx = p->image_nx;
   a.image_ny = p->image_ny;
   a.image_x_min = p->image_x_min;
@@ -756,6 +761,31 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
       done += n;
     }
     return 0;
+  }
+  {
+    // Replication factor from the expected size of the solar image in pixels: plate scale (distance XRT -> detector)
+    // times the angular radius of the emitting core (~0.25 R_sun).  Wide images (BabyIAXO / XMM: f = 7.5 m) see no
+    // contention and add straight into the caller's accumulator.
+    const sart_setup_t& s = c->setup;
+    const double spot_px = s.distance_detector_xrt * (0.25 * s.radius_sun / s.distance_sun_earth) *
+                           a.image_inv_step_x;
+    int R = spot_px > 96.0 ? 1 : (spot_px > 12.0 ? 16 : 64);
+    if (s.test_active) R = 16;
+    if (const char* e = std::getenv("SART_IMAGE_REPLICAS")) R = std::max(1, std::min(kMaxImageReplicas, std::atoi(e)));
+    while (R & (R - 1)) R &= R - 1;   // power of two
+    if (R > 1) {
+      const size_t need = static_cast<size_t>(R) * static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny);
+      if (c->d_replicas.n != need || !c->d_replicas.p) {
+        SART_HIP(hipStreamSynchronize(c->stream));
+        if (int rc = c->d_replicas.resize(need)) return rc;
+        SART_HIP(hipMemset(c->d_replicas.p, 0, need * sizeof(double)));
+      }
+      a.replicas = c->d_replicas.p;
+      a.replica_mask = static_cast<uint32_t>(R - 1);
+    } else {
+      a.replicas = acc_dev;
+      a.replica_mask = 0u;
+    }
   }
   if (c->blocks_per_cu_hist == 0) {
     if (const char* e = std::getenv("SART_HIST_BLOCK")) set_histogram_block(std::atoi(e));   // tuning knob

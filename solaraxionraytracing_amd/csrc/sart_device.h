@@ -159,8 +159,15 @@ struct DevBlob {
 };
 static_assert(sizeof(DevBlob) % 8 == 0, "DevBlob is staged into LDS as 8-byte words");
 
+constexpr int kMaxImageReplicas = 64;   // power of two
+
 struct TraceArgs {
   uint64_t n_rays, ray_id_offset;
+  // Image atomics go to replica (wave id & replica_mask) of a scratch image: contended f64 atomics on a small
+  // focal spot serialise at the memory side.  fold_replicas_kernel adds the replicas into the caller's
+  // accumulator.  replica_mask = 0 (wide images): `replicas` is the accumulator itself, no fold.
+  double* replicas;
+  uint32_t replica_mask, _pad;
   uint32_t seed_lo, seed_hi;
   uint32_t flags;
   int32_t image_nx, image_ny;

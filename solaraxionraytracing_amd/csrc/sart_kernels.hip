@@ -725,10 +725,12 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   const LdsTables L{S.rcdf, S.rguide, S.shells, S.lut};
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: scalar addressing of the rings
   const uint64_t waves_total = (uint64_t)gridDim.x * (BLOCK / 64);
   const uint64_t wave_global = (uint64_t)blockIdx.x * (BLOCK / 64) + wave;
   const bool early_reject = FAST && (H.n_zones > 0);
+  // this wave's replica of the image
+  double* const img = A.replicas + (size_t)((uint32_t)wave_global & A.replica_mask) * ((size_t)A.image_nx * (size_t)A.image_ny);
 
   // wave-uniform counters (ballot + popcount) and per-lane sums
   uint32_t n_reached = 0, n_shell = 0, n_nickel = 0, n_till = 0, n_passed = 0, n_outside = 0;
@@ -801,7 +803,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       const double fy = floor((out.py - Ab.image_y_min) * Ab.image_inv_step_y);
       const int nx = A.image_nx, ny = A.image_ny;
       const bool inside = fx >= 0.0 && fx < (double)nx && fy >= 0.0 && fy < (double)ny;
-      if (inside) unsafeAtomicAdd(&acc[(size_t)((int)fy) * (size_t)nx + (size_t)((int)fx)], out.weight);
+      if (inside && !(A.flags & 0x40000000u))
+        unsafeAtomicAdd(&img[(size_t)((int)fy) * (size_t)nx + (size_t)((int)fx)], out.weight);
       out.outside = !inside;
     }
     n_outside += (uint32_t)__popcll(__ballot(out.outside));
@@ -877,6 +880,19 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   if (blockIdx.x == 0 && threadIdx.x == 0) unsafeAtomicAdd(&sc[SART_ACC_N_RAYS], (double)A.n_rays);
 }
 
+// acc[i] += sum over replicas; replicas are left zeroed for the next launch.
+__global__ __launch_bounds__(256) void fold_replicas_kernel(double* __restrict__ acc, double* __restrict__ replicas, int n_img,
+                                                            int n_replicas) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_img) return;
+  double s = 0.0;
+  for (int r = 0; r < n_replicas; ++r) {
+    s += replicas[(size_t)r * (size_t)n_img + i];
+    replicas[(size_t)r * (size_t)n_img + i] = 0.0;
+  }
+  acc[i] += s;
+}
+
 // Literal drop-in for traceAxionWrapper: one Axion record per ray, in ray order (no compaction).
 constexpr int kRecBlock = 256;
 __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
@@ -949,6 +965,11 @@ void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs&
                             hipStream_t stream, bool fast) {
   if (fast) launch_hist<true>(H, blob, A, acc, n_blocks, stream);
   else launch_hist<false>(H, blob, A, acc, n_blocks, stream);
+  if (A.replica_mask != 0u) {
+    const int n_img = A.image_nx * A.image_ny;
+    hipLaunchKernelGGL(fold_replicas_kernel, dim3((n_img + 255) / 256), dim3(256), 0, stream, acc, A.replicas, n_img,
+                       (int)A.replica_mask + 1);
+  }
 }
 void launch_trace_records(const HotA& H, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream) {
