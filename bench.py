@@ -53,7 +53,10 @@ def main():
     import solaraxionraytracing_amd as sa
     from solaraxionraytracing_amd import _lib as L, distributed as D
 
-    rank, world, local_rank = D.init_process_group_from_env()
+    # SART_BENCH_BACKEND=gloo + SART_BENCH_DEVICE=0: rehearsal of the multi-rank path on a one-GPU box
+    rank, world, local_rank = D.init_process_group_from_env(os.environ.get("SART_BENCH_BACKEND"))
+    if "SART_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SART_BENCH_DEVICE"])
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
@@ -70,7 +73,12 @@ def main():
 
     rays = int(args.rays_per_step)
     rt = sa.RayTracer(full, device=local_rank)
-    rt.set_stream(torch.cuda.current_stream(dev).cuda_stream)   # launches and the RCCL reduce share torch's stream
+    # Launches, torch ops on the accumulator and the RCCL reduce are ordered by ONE explicit stream.  (torch's
+    # default stream has handle 0, which sart_set_stream reads as "the context's own stream".)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    rt.set_stream(stream.cuda_stream)
     acc = torch.zeros(sa.accumulator_len(256), dtype=torch.float64, device=dev)
     seed = 299792458
 
