@@ -204,6 +204,10 @@ typedef struct sart_trace_params_t {
   int32_t accumulate;      /* histogram mode: 0 = zero the accumulator first, 1 = add    */
   double image_x_min, image_x_max;  /* 0 .. ChipXMax in :2622-2625 */
   double image_y_min, image_y_max;
+  /* Optional post-processing histograms (generateResultPlots): 0 = image + scalars only. */
+  int32_t spectra;         /* 1: also accumulate the radial and per-energy histograms described below          */
+  int32_t n_radial_bins;   /* bins of pointdataR over [0, radial_max): the reference bins at 0.001 mm (:2386)   */
+  double radial_max;       /* mm                                                                                */
 } sart_trace_params_t;
 
 /*
@@ -230,6 +234,17 @@ enum {
 
 static inline size_t sart_accumulator_len(int32_t nx, int32_t ny) {
   return (size_t)nx * (size_t)ny + (size_t)SART_ACC_COUNT;
+}
+/*
+ * With params.spectra != 0 the accumulator continues behind the scalars (all f64, passed rays only):
+ *   radial_counts [n_radial_bins]     number of rays per bin of pointdataR (last bin collects r >= radial_max)
+ *   radial_weights[n_radial_bins]     sum of weights per bin  ("Radial distribution", raytracer.nim:2378-2389)
+ *   energy_counts [n_energies + 1]    rays per energy index (index n_energies = the X-ray test source's energy)
+ *   energy_weights[n_energies + 1]    sum of weights per energy index   (flux after the experiment, :2595-2601)
+ *   energy_reflect[n_energies + 1]    sum of `reflect` per energy index (reflectivity vs energy, :2295-2315)
+ */
+static inline size_t sart_accumulator_len_spectra(int32_t nx, int32_t ny, int32_t n_radial_bins, int32_t n_energies) {
+  return sart_accumulator_len(nx, ny) + 2u * (size_t)n_radial_bins + 3u * ((size_t)n_energies + 1u);
 }
 
 /* Host-side view of the scalar tail. */
@@ -294,6 +309,10 @@ int sart_trace_histogram_device(sart_context* ctx, const sart_trace_params_t* pa
 /* Blocking convenience form with HOST outputs (image may be NULL, summary may be NULL). */
 int sart_trace_histogram(sart_context* ctx, const sart_trace_params_t* params,
                          double* image_out_host, sart_summary_t* summary_out);
+/* Same, with params->spectra != 0: spectra_out_host receives the 2*n_radial_bins + 3*(n_energies+1) doubles behind the
+ * scalars (layout above). */
+int sart_trace_histogram_spectra(sart_context* ctx, const sart_trace_params_t* params, double* image_out_host,
+                                 sart_summary_t* summary_out, double* spectra_out_host);
 
 /* ---- measurement -------------------------------------------------------- */
 /*

@@ -72,6 +72,22 @@ int sart_host_perform_angular_scan(sart_context* ctx, const double* angles_deg, 
                                    uint64_t n_rays_per_angle, uint64_t seed, uint64_t ray_id_offset,
                                    uint32_t flags, double* fluxes_out, double* rel_fluxes_out);
 
+/* Containment radii of generateResultPlots (raytracer.nim:2459-2527) from the radial histograms of a spectra trace
+ * (bin k = [k, k+1) * radial_max / n_bins):
+ *   r_sigma1 / r_sigma2     radii holding round(0.68 n) / round(0.955 n) of the passed rays (pointR[sigma1 - 1], :2472-2473)
+ *   r_sigma1_w / r_sigma2_w weighted versions: last radius whose cumulative weight stays below 0.68 / 0.955 of the
+ *                           total (rSigma1W / rSigma2W, :2511-2524)
+ * each reported as the upper edge of the bin in which the threshold is crossed (resolution radial_max / n_bins). */
+int sart_host_containment_radii(const double* radial_counts, const double* radial_weights, int32_t n_bins,
+                                double radial_max, double* r_sigma1, double* r_sigma2, double* r_sigma1_w,
+                                double* r_sigma2_w);
+
+/* plotHeatmap's CSV (raytracer.nim:866-921): `axion_image_{year}{suffix}.csv` with the columns
+ * x, y, photon flux, yr0, yr02, x-position [mm], y-position [mm], xr, xrneg, yr, xr2, xrneg2, yr2
+ * for a width x width image over 0 .. chip_max mm.  Returns the total flux (the `echo` of :886) in *flux_out. */
+int sart_host_write_image_csv(const char* path, const double* image, int32_t width, double chip_max,
+                              double r_sigma1, double r_sigma2, double* flux_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -122,6 +122,20 @@ class Oracle:
         self.lib.sart_oracle_trace_records(C.byref(s), C.byref(self.tables), C.byref(p), buf.ctypes.data_as(C.c_void_p), n_threads)
         return buf
 
+    def trace_spectra(self, n_rays, seed=299792458, ray_id_offset=0, flags=None, image_n=256, n_radial_bins=10_000,
+                      radial_max=10.0, n_threads=0, setup=None):
+        from solaraxionraytracing_amd.raytracer import split_spectra
+        p = self.params(n_rays, seed, ray_id_offset, flags, image_n)
+        p.spectra, p.n_radial_bins, p.radial_max = 1, n_radial_bins, radial_max
+        n_e1 = self.full.energies.size + 1
+        n_img = image_n * image_n
+        acc = np.zeros(n_img + _lib.SART_ACC_COUNT + 2 * n_radial_bins + 3 * n_e1)
+        s = setup if setup is not None else self.full.setup
+        self.lib.sart_oracle_trace_histogram(C.byref(s), C.byref(self.tables), C.byref(p), acc.ctypes.data_as(_dp), n_threads)
+        img = acc[:n_img].reshape(image_n, image_n).copy()
+        summ = {k: acc[n_img + i] for k, i in _lib.ACC.items()}
+        return img, summ, split_spectra(acc[n_img + _lib.SART_ACC_COUNT:], n_radial_bins, n_e1, radial_max)
+
     def trace_histogram(self, n_rays, seed=299792458, ray_id_offset=0, flags=None, image_n=256, n_threads=0, setup=None):
         p = self.params(n_rays, seed, ray_id_offset, flags, image_n)
         acc = np.zeros(image_n * image_n + _lib.SART_ACC_COUNT)

@@ -293,7 +293,7 @@ static v3 get_random_point_from_solar_model(v3 center, real radius, const double
 }
 
 static real get_random_energy_from_solar_model(v3 vectorInSun, v3 center, real radius,
-                                                 const sart_oracle_tables_t* t, real u) { /* :444-471 */
+                                                 const sart_oracle_tables_t* t, real u, int* idx_out) { /* :444-471 */
   real rad = vlength(vsub(vectorInSun, center));
   real r = rad / radius;
   real indexRad = (r - 0.0015) / 0.0005;
@@ -308,6 +308,7 @@ static real get_random_energy_from_solar_model(v3 vectorInSun, v3 center, real r
   int64_t idx = lower_bound_r(cdfEmRate, t->n_energies, u);
   if (idx > t->n_energies - 1) idx = t->n_energies - 1; /* CDF ends at exactly 1.0 (:2675-2677) */
   real energy = t->energies_kev[idx];
+  *idx_out = (int)idx;
   return M_FMAX(0.03, energy); /* QUIRK: discrete energies, clamped to >= 0.03 keV (:470-471) */
 }
 
@@ -703,7 +704,7 @@ static int line_hits_nickel(const sart_setup_t* s, real alpha1_deg, real r1, int
 /* `stage` (oracle-only bookkeeping for the SART_ACC_N_REACHED_TELESCOPE / _SHELL_SELECTED
  * counters): 1 once the ray has passed bore + pipes, 2 once a shell has been selected. */
 static void trace_axion_impl(sart_axion_t* res, const sart_setup_t* s, const sart_oracle_tables_t* t,
-                             uint32_t flags, const double u[6], int* stage) {
+                             uint32_t flags, const double u[6], int* stage, int* e_idx_out) {
   /* centre vectors, initCenterVectors :278-320 */
   const v3 c_sun = V(0.0, -(0.0 * 1.33e10), -s->distance_sun_earth);
   const v3 c_entranceCB = V(0.0, -0.0, 0.0);
@@ -722,7 +723,7 @@ static void trace_axion_impl(sart_axion_t* res, const sart_setup_t* s, const sar
   if (!testXray) { /* :1751-1764; draw order u0..u5 */
     rayOrigin = get_random_point_from_solar_model(c_sun, s->radius_sun, t->flux_radius_cdf, t->n_radii, u[0], u[1], u[2]);
     pointExitCBMagneticField = get_random_point_on_disk(c_exitCBMagneticField, s->magnet_radiusCB, u[3], u[4]);
-    energyAx = get_random_energy_from_solar_model(rayOrigin, c_sun, s->radius_sun, t, u[5]);
+    energyAx = get_random_energy_from_solar_model(rayOrigin, c_sun, s->radius_sun, t, u[5], e_idx_out);
   } else { /* :1765-1806 */
     rayOrigin = get_random_point_on_disk(c_xraySource, s->test_radius, u[0], u[1]);
     energyAx = s->test_energy;
@@ -968,8 +969,8 @@ static void trace_axion_impl(sart_axion_t* res, const sart_setup_t* s, const sar
 
 void sart_oracle_trace_axion(sart_axion_t* res, const sart_setup_t* s, const sart_oracle_tables_t* t,
                              uint32_t flags, const double u[6]) {
-  int stage = 0;
-  trace_axion_impl(res, s, t, flags, u, &stage);
+  int stage = 0, e_idx = 0;
+  trace_axion_impl(res, s, t, flags, u, &stage, &e_idx);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1027,7 +1028,8 @@ int sart_oracle_trace_records(const sart_setup_t* setup, const sart_oracle_table
 }
 
 /* One record into the fused accumulator (layout of include/sart.h SART_ACC_*). */
-static void accumulate_record(const sart_axion_t* r, int stage, const sart_trace_params_t* p, double* acc) {
+static void accumulate_record(const sart_axion_t* r, int stage, const sart_trace_params_t* p, double* acc,
+                              int n_energies, int e_idx) {
   size_t nimg = (size_t)p->image_nx * (size_t)p->image_ny;
   double* sc = acc + nimg;
   sc[SART_ACC_N_RAYS] += 1.0;
@@ -1051,13 +1053,27 @@ static void accumulate_record(const sart_axion_t* r, int stage, const sart_trace
       acc[(size_t)cy * (size_t)p->image_nx + (size_t)cx] += 1 * r->weights / 1.0;
     else
       sc[SART_ACC_N_OUTSIDE_IMAGE] += 1.0; /* IndexDefect in the reference */
+    if (p->spectra) { /* histograms of generateResultPlots, layout of sart_accumulator_len_spectra */
+      double* rad = sc + SART_ACC_COUNT;
+      double* en = rad + 2 * (size_t)p->n_radial_bins;
+      size_t ne1 = (size_t)n_energies + 1;
+      int rb = (int)(r->pointdataR * ((double)p->n_radial_bins / p->radial_max));
+      if (rb > p->n_radial_bins - 1) rb = p->n_radial_bins - 1;
+      rad[rb] += 1.0;
+      rad[(size_t)p->n_radial_bins + rb] += r->weights;
+      en[e_idx] += 1.0;
+      en[ne1 + e_idx] += r->weights;
+      en[2 * ne1 + e_idx] += r->reflect;
+    }
   }
 }
 
 int sart_oracle_trace_histogram(const sart_setup_t* setup, const sart_oracle_tables_t* tables,
                                 const sart_trace_params_t* params, double* accumulator, int n_threads) {
   int nt = resolve_threads(n_threads);
-  size_t len = sart_accumulator_len(params->image_nx, params->image_ny);
+  size_t len = params->spectra ? sart_accumulator_len_spectra(params->image_nx, params->image_ny, params->n_radial_bins,
+                                                              tables->n_energies)
+                               : sart_accumulator_len(params->image_nx, params->image_ny);
   if (!params->accumulate) memset(accumulator, 0, len * sizeof(double));
   int64_t n = (int64_t)params->n_rays;
 #pragma omp parallel num_threads(nt)
@@ -1070,8 +1086,9 @@ int sart_oracle_trace_histogram(const sart_setup_t* setup, const sart_oracle_tab
       memset(&res, 0, sizeof res);
       sart_oracle_uniforms(params->seed, params->ray_id_offset + (uint64_t)i, u);
       int stage = 0;
-      trace_axion_impl(&res, setup, tables, params->flags, u, &stage);
-      accumulate_record(&res, stage, params, local);
+      int e_idx = tables->n_energies; /* energies are discrete (:470); the test source uses the extra slot */
+      trace_axion_impl(&res, setup, tables, params->flags, u, &stage, &e_idx);
+      accumulate_record(&res, stage, params, local, tables->n_energies, e_idx);
     }
 #pragma omp critical
     {

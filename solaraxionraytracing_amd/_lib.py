@@ -106,6 +106,7 @@ class TraceParams(C.Structure):
         ("n_rays", C.c_uint64), ("seed", C.c_uint64), ("ray_id_offset", C.c_uint64), ("flags", C.c_uint32),
         ("image_nx", _i), ("image_ny", _i), ("accumulate", _i),
         ("image_x_min", _d), ("image_x_max", _d), ("image_y_min", _d), ("image_y_max", _d),
+        ("spectra", _i), ("n_radial_bins", _i), ("radial_max", _d),
     ]
 
 
@@ -148,6 +149,7 @@ SART_SYMBOLS = {
     "sart_trace_records_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p]),
     "sart_trace_histogram_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p]),
     "sart_trace_histogram": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _P(Summary)]),
+    "sart_trace_histogram_spectra": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _P(Summary), _dp]),
     "sart_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "sart_get_kernel_timing": (C.c_int, [C.c_void_p, _dp, _P(C.c_int64)]),
     "sart_device_info": (C.c_int, [C.c_void_p, _P(_i), _P(_i), C.c_char_p, C.c_size_t]),
@@ -161,6 +163,8 @@ SART_HOST_SYMBOLS = {
     "sart_host_calc_window_vals": (C.c_int, [_d, _i, _d, _dp, _dp]),
     "sart_host_build_cdfs": (C.c_int, [_dp, _dp, _dp, _i, _i, _dp, _dp]),
     "sart_host_detector_tables": (C.c_int, [_dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _dp, _dp, _dp]),
+    "sart_host_containment_radii": (C.c_int, [_dp, _dp, _i, _d, _dp, _dp, _dp, _dp]),
+    "sart_host_write_image_csv": (C.c_int, [C.c_char_p, _dp, _i, _d, _d, _d, _dp]),
     "sart_host_trace_axion_wrapper": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32]),
     "sart_host_perform_angular_scan": (C.c_int, [C.c_void_p, _dp, _i, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                                  _dp, _dp]),

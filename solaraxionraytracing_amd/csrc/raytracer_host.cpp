@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <cstdio>
 
 namespace {
 
@@ -371,6 +372,67 @@ int sart_host_perform_angular_scan(sart_context* ctx, const double* angles_deg, 
     for (int32_t i = 1; i < n_angles; ++i) maxFlux = std::max(maxFlux, fluxes_out[i]);
     for (int32_t i = 0; i < n_angles; ++i) rel_fluxes_out[i] = fluxes_out[i] / maxFlux;
   }
+  return 0;
+}
+
+int sart_host_containment_radii(const double* counts, const double* weights, int32_t n_bins, double radial_max,
+                                double* r_sigma1, double* r_sigma2, double* r_sigma1_w, double* r_sigma2_w) {
+  if (!counts || !weights || n_bins < 1 || !(radial_max > 0.0))
+    return fail(SART_ERR_INVALID_ARGUMENT, "sart_host_containment_radii: bad argument");
+  const double bin = radial_max / n_bins;
+  double n = 0.0, sumW = 0.0;
+  for (int32_t k = 0; k < n_bins; ++k) { n += counts[k]; sumW += weights[k]; }
+  // unweighted: pointR[round(0.68 n) - 1] of the sorted radii (raytracer.nim:2464-2473)
+  const double k1 = std::round(n * 0.68), k2 = std::round(n * 0.955);
+  double r1 = 0.0, r2 = 0.0, cum = 0.0;
+  bool got1 = false, got2 = false;
+  for (int32_t k = 0; k < n_bins; ++k) {
+    cum += counts[k];
+    if (!got1 && k1 >= 1.0 && cum >= k1) { r1 = (k + 1) * bin; got1 = true; }
+    if (!got2 && k2 >= 1.0 && cum >= k2) { r2 = (k + 1) * bin; got2 = true; }
+  }
+  // weighted: the last radius with cumulative weight < 0.68 / 0.955 of the total (:2511-2524)
+  double r1w = 0.0, r2w = 0.0, cw = 0.0;
+  for (int32_t k = 0; k < n_bins; ++k) {
+    cw += weights[k];
+    if (counts[k] > 0.0) {
+      if (cw < sumW * 0.68) r1w = (k + 1) * bin;
+      else if (cw < sumW * 0.955) r2w = (k + 1) * bin;
+    }
+  }
+  if (r_sigma1) *r_sigma1 = r1;
+  if (r_sigma2) *r_sigma2 = r2;
+  if (r_sigma1_w) *r_sigma1_w = r1w;
+  if (r_sigma2_w) *r_sigma2_w = r2w;
+  return 0;
+}
+
+int sart_host_write_image_csv(const char* path, const double* image, int32_t width, double chip_max, double rSigma1,
+                              double rSigma2, double* flux_out) {
+  if (!path || !image || width < 1) return fail(SART_ERR_INVALID_ARGUMENT, "sart_host_write_image_csv: bad argument");
+  std::FILE* f = std::fopen(path, "w");
+  if (!f) return fail(SART_ERR_INVALID_ARGUMENT, std::string("cannot open ") + path);
+  // raytracer.nim:887-899
+  std::fprintf(f, "x,y,photon flux,yr0,yr02,x-position [mm],y-position [mm],xr,xrneg,yr,xr2,xrneg2,yr2\n");
+  const long n = static_cast<long>(width) * width;
+  const double offset = chip_max / 2.0;  // ChipCenterX :881
+  double flux = 0.0;
+  for (int32_t y = 0; y < width; ++y) {
+    for (int32_t x = 0; x < width; ++x) {
+      const long i = static_cast<long>(y) * width + x;
+      const double z = image[i];  // objectsToDraw[y, x] :874
+      flux += z;
+      // linspace(-r, r, n) :883-884
+      const double t = (n > 1) ? static_cast<double>(i) / static_cast<double>(n - 1) : 0.0;
+      const double yr0 = -rSigma1 + 2.0 * rSigma1 * t, yr02 = -rSigma2 + 2.0 * rSigma2 * t;
+      const double xr = std::sqrt(rSigma1 * rSigma1 - yr0 * yr0), xr2 = std::sqrt(rSigma2 * rSigma2 - yr02 * yr02);
+      std::fprintf(f, "%d,%d,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g,%.17g\n", x, y, z, yr0, yr02,
+                   x * chip_max / width, y * chip_max / width, xr + offset, -xr + offset, yr0 + offset, xr2 + offset,
+                   -xr2 + offset, yr02 + offset);
+    }
+  }
+  std::fclose(f);
+  if (flux_out) *flux_out = flux;
   return 0;
 }
 

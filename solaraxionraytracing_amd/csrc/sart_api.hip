@@ -406,8 +406,21 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   a.image_y_min = p->image_y_min;
   a.image_inv_step_x = 1.0 / ((p->image_x_max - p->image_x_min) / static_cast<double>(p->image_nx));  // :828-830
   a.image_inv_step_y = 1.0 / ((p->image_y_max - p->image_y_min) / static_cast<double>(p->image_ny));
+  a.spectra = p->spectra ? 1 : 0;
+  a.n_radial_bins = 0;
+  a.radial_inv_bin = 0.0;
+  if (p->spectra) {
+    if (p->n_radial_bins < 1 || !(p->radial_max > 0.0)) return fail(SART_ERR_INVALID_ARGUMENT, "invalid radial histogram specification");
+    a.n_radial_bins = p->n_radial_bins;
+    a.radial_inv_bin = static_cast<double>(p->n_radial_bins) / p->radial_max;
+  }
   (void)c;
   return 0;
+}
+
+size_t acc_len_of(const sart_context* c, const sart_trace_params_t* p) {
+  return p->spectra ? sart_accumulator_len_spectra(p->image_nx, p->image_ny, p->n_radial_bins, c->n_energies)
+                    : sart_accumulator_len(p->image_nx, p->image_ny);
 }
 
 HotA hot_of(const DevParams& P) {
@@ -747,8 +760,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   if (int rc = sync_blob(c)) return rc;
   TraceArgs a;
   if (int rc = make_args(c, p, a)) return rc;
-  if (!p->accumulate)
-    SART_HIP(hipMemsetAsync(acc_dev, 0, sart_accumulator_len(p->image_nx, p->image_ny) * sizeof(double), c->stream));
+  if (!p->accumulate) SART_HIP(hipMemsetAsync(acc_dev, 0, acc_len_of(c, p) * sizeof(double), c->stream));
   if (a.n_rays == 0) return 0;
   if (a.n_rays > (1ull << 31)) {   // ray indices inside one launch are 32-bit (stage A0 ring): split
     sart_trace_params_t q = *p;
@@ -807,10 +819,16 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
 }
 
 int sart_trace_histogram(sart_context* c, const sart_trace_params_t* p, double* image_out, sart_summary_t* summary) {
+  return sart_trace_histogram_spectra(c, p, image_out, summary, nullptr);
+}
+
+int sart_trace_histogram_spectra(sart_context* c, const sart_trace_params_t* p, double* image_out, sart_summary_t* summary,
+                                 double* spectra_out) {
   if (!c || !p) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
   SART_HIP(hipSetDevice(c->device));
-  const size_t len = sart_accumulator_len(p->image_nx, p->image_ny);
   if (p->image_nx < 1 || p->image_ny < 1) return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
+  if (p->spectra && (p->n_radial_bins < 1 || !c->have_solar)) return fail(SART_ERR_INVALID_ARGUMENT, "invalid spectra specification");
+  const size_t len = acc_len_of(c, p);
   const bool fresh = (c->d_acc.n != len) || !c->d_acc.p;
   if (int rc = c->d_acc.resize(len)) return rc;
   sart_trace_params_t q = *p;
@@ -820,6 +838,9 @@ int sart_trace_histogram(sart_context* c, const sart_trace_params_t* p, double* 
   if (image_out) SART_HIP(hipMemcpyAsync(image_out, c->d_acc.p, nimg * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (summary)
     SART_HIP(hipMemcpyAsync(summary->v, c->d_acc.p + nimg, SART_ACC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (spectra_out && p->spectra)
+    SART_HIP(hipMemcpyAsync(spectra_out, c->d_acc.p + nimg + SART_ACC_COUNT, (len - nimg - SART_ACC_COUNT) * sizeof(double),
+                            hipMemcpyDeviceToHost, c->stream));
   SART_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }

@@ -172,6 +172,9 @@ struct TraceArgs {
   uint32_t flags;
   int32_t image_nx, image_ny;
   double image_x_min, image_y_min, image_inv_step_x, image_inv_step_y;
+  // optional spectra behind the scalars (include/sart.h: sart_accumulator_len_spectra)
+  int32_t spectra, n_radial_bins;
+  double radial_inv_bin;
 };
 
 }  // namespace sart

@@ -467,7 +467,8 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
 // Results of phase B for one ray (record mode needs all of them; histogram mode a few).
 struct RayOut {
   bool hit_nickel = false, till_window = false, finished = false, outside = false;
-  double px = 0.0, py = 0.0, rdet = 0.0, weight = 0.0;
+  double px = 0.0, py = 0.0, rdet = 0.0, weight = 0.0, reflect = 0.0;
+  int e_idx = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -634,6 +635,8 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   if (!(flags & SART_CF_XRAY_TEST)) weight *= P.exposure;             // :2207-2212
 
   out.finished = live;
+  out.reflect = reflectv;
+  out.e_idx = e_idx;
   out.rdet = fsqrt(rdet2);
   out.px = -pdx + P.chip_cx;                                          // :2203-2204
   out.py = pdy + P.chip_cy;
@@ -806,6 +809,17 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       if (inside && !(A.flags & 0x40000000u))
         unsafeAtomicAdd(&img[(size_t)((int)fy) * (size_t)nx + (size_t)((int)fx)], out.weight);
       out.outside = !inside;
+      if (A.spectra) {   // wave-uniform: radial and per-energy histograms behind the scalars
+        double* rad = acc + (size_t)nx * (size_t)ny + SART_ACC_COUNT;
+        double* en = rad + 2 * (size_t)A.n_radial_bins;
+        const size_t ne1 = (size_t)Pb.n_energies + 1;
+        const int rb = min((int)(out.rdet * Ab.radial_inv_bin), A.n_radial_bins - 1);
+        unsafeAtomicAdd(&rad[rb], 1.0);
+        unsafeAtomicAdd(&rad[(size_t)A.n_radial_bins + rb], out.weight);
+        unsafeAtomicAdd(&en[out.e_idx], 1.0);
+        unsafeAtomicAdd(&en[ne1 + out.e_idx], out.weight);
+        unsafeAtomicAdd(&en[2 * ne1 + out.e_idx], out.reflect);
+      }
     }
     n_outside += (uint32_t)__popcll(__ballot(out.outside));
   };

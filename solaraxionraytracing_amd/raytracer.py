@@ -184,6 +184,20 @@ class RayTracer:
         _lib.check(self.lib.sart_trace_histogram(self.handle, C.byref(p), _lib.as_dp(img), C.byref(summ)))
         return img, {k: summ.v[i] for k, i in _lib.ACC.items()}
 
+    def trace_spectra(self, n_rays: int, seed: int = 299792458, ray_id_offset: int = 0, flags: int | None = None,
+                      image_n: int = 256, n_radial_bins: int = 10_000, radial_max: float = 10.0, accumulate: bool = False):
+        """trace_histogram plus the post-processing histograms of generateResultPlots accumulated on the device:
+        radial distribution (bin 0.001 mm by default, raytracer.nim:2386) and per-energy-index spectra.  Returns
+        (image, summary, spectra dict)."""
+        p = self.trace_params(n_rays, seed, ray_id_offset, flags, image_n, accumulate)
+        p.spectra, p.n_radial_bins, p.radial_max = 1, n_radial_bins, radial_max
+        n_e1 = self.full.energies.size + 1
+        img = np.empty((image_n, image_n))
+        summ = Summary()
+        spec = np.empty(2 * n_radial_bins + 3 * n_e1)
+        _lib.check(self.lib.sart_trace_histogram_spectra(self.handle, C.byref(p), _lib.as_dp(img), C.byref(summ), _lib.as_dp(spec)))
+        return img, {k: summ.v[i] for k, i in _lib.ACC.items()}, split_spectra(spec, n_radial_bins, n_e1, radial_max)
+
     def trace_histogram_device(self, params: TraceParams, accumulator_ptr: int):
         """Asynchronous form: adds into a device accumulator (e.g. ``torch_tensor.data_ptr()``)."""
         _lib.check(self.lib.sart_trace_histogram_device(self.handle, C.byref(params), C.c_void_p(accumulator_ptr)))
@@ -202,6 +216,38 @@ class RayTracer:
         name = C.create_string_buffer(256)
         _lib.check(self.lib.sart_device_info(self.handle, C.byref(ncu), C.byref(ws), name, 256))
         return {"n_cu": ncu.value, "wave_size": ws.value, "name": name.value.decode()}
+
+
+def split_spectra(spec: np.ndarray, n_radial_bins: int, n_e1: int, radial_max: float) -> dict:
+    """Names the pieces of the spectra block of the accumulator (include/sart.h: sart_accumulator_len_spectra)."""
+    o = 0
+    out = {}
+    for name, n in (("radial_counts", n_radial_bins), ("radial_weights", n_radial_bins), ("energy_counts", n_e1),
+                    ("energy_weights", n_e1), ("energy_reflect", n_e1)):
+        out[name] = spec[o:o + n].copy()
+        o += n
+    out["radial_max"] = radial_max
+    return out
+
+
+def containment_radii(spectra: dict):
+    """rSigma1, rSigma2 (unweighted) and rSigma1W, rSigma2W (weighted) of generateResultPlots (raytracer.nim:2459-2527)."""
+    host = _lib.load_host()
+    r = [C.c_double() for _ in range(4)]
+    rc, rw = np.ascontiguousarray(spectra["radial_counts"]), np.ascontiguousarray(spectra["radial_weights"])
+    _lib.check(host.sart_host_containment_radii(_lib.as_dp(rc), _lib.as_dp(rw), rc.size, spectra["radial_max"],
+                                                *[C.byref(x) for x in r]), host=True)
+    return tuple(x.value for x in r)
+
+
+def write_image_csv(path: str, image: np.ndarray, chip_max: float, r_sigma1: float, r_sigma2: float) -> float:
+    """plotHeatmap's `axion_image_{year}{suffix}.csv` (raytracer.nim:887-921).  Returns the total flux."""
+    host = _lib.load_host()
+    img = np.ascontiguousarray(image, dtype=np.float64)
+    flux = C.c_double()
+    _lib.check(host.sart_host_write_image_csv(path.encode(), _lib.as_dp(img), img.shape[0], chip_max, r_sigma1, r_sigma2,
+                                              C.byref(flux)), host=True)
+    return flux.value
 
 
 def accumulator_len(image_n: int = 256) -> int:
