@@ -72,6 +72,13 @@ int sart_host_perform_angular_scan(sart_context* ctx, const double* angles_deg, 
                                    uint64_t n_rays_per_angle, uint64_t seed, uint64_t ray_id_offset,
                                    uint32_t flags, double* fluxes_out, double* rel_fluxes_out);
 
+/* Axion-mass scan in the gas stage (BASELINE config 5; the reference only has the constant mAxion, raytracer.nim:255):
+ * for each m_a set the mass, trace n_rays_per_mass rays, fluxes_out[i] = sum of weights of the passed rays.
+ * Mass i uses ray ids [ray_id_offset + i*n_rays_per_mass, ...). */
+int sart_host_perform_axion_mass_scan(sart_context* ctx, const double* masses_ev, int32_t n_masses,
+                                      uint64_t n_rays_per_mass, uint64_t seed, uint64_t ray_id_offset,
+                                      uint32_t flags, double* fluxes_out);
+
 /* Containment radii of generateResultPlots (raytracer.nim:2459-2527) from the radial histograms of a spectra trace
  * (bin k = [k, k+1) * radial_max / n_bins):
  *   r_sigma1 / r_sigma2     radii holding round(0.68 n) / round(0.955 n) of the passed rays (pointR[sigma1 - 1], :2472-2473)

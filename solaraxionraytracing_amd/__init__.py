@@ -6,7 +6,7 @@ libsart_host.so (C++ host mirror of the reference's setup/driver layer).
 """
 from . import _lib, tables  # noqa: F401
 from .raytracer import (FullRaytraceSetup, RayTracer, accumulator_len, calculateFluxFractions, initFullSetup,  # noqa: F401
-                        newFullSetup, performAngularScan)
+                        newFullSetup, performAngularScan, performAxionMassScan)
 
 __all__ = ["FullRaytraceSetup", "RayTracer", "accumulator_len", "calculateFluxFractions", "initFullSetup",
-           "newFullSetup", "performAngularScan", "tables"]
+           "newFullSetup", "performAngularScan", "performAxionMassScan", "tables"]

@@ -375,6 +375,31 @@ int sart_host_perform_angular_scan(sart_context* ctx, const double* angles_deg, 
   return 0;
 }
 
+int sart_host_perform_axion_mass_scan(sart_context* ctx, const double* masses_ev, int32_t n_masses, uint64_t n_rays_per_mass,
+                                      uint64_t seed, uint64_t ray_id_offset, uint32_t flags, double* fluxes_out) {
+  if (!ctx || !masses_ev || n_masses < 1 || !fluxes_out)
+    return fail(SART_ERR_INVALID_ARGUMENT, "sart_host_perform_axion_mass_scan: bad argument");
+  sart_setup_t setup;
+  if (int rc = sart_get_setup(ctx, &setup)) { g_err = sart_last_error(); return rc; }
+  sart_trace_params_t p;
+  std::memset(&p, 0, sizeof p);
+  p.n_rays = n_rays_per_mass;
+  p.seed = seed;
+  p.flags = flags;
+  p.image_nx = 256; p.image_ny = 256;
+  p.image_x_min = 0.0; p.image_x_max = setup.chip_x_max; p.image_y_min = 0.0; p.image_y_max = setup.chip_y_max;
+  for (int32_t i = 0; i < n_masses; ++i) {
+    int rc = sart_set_axion_mass(ctx, masses_ev[i]);
+    if (rc) { g_err = sart_last_error(); return rc; }
+    p.ray_id_offset = ray_id_offset + static_cast<uint64_t>(i) * n_rays_per_mass;
+    sart_summary_t sum;
+    rc = sart_trace_histogram(ctx, &p, nullptr, &sum);
+    if (rc) { g_err = sart_last_error(); return rc; }
+    fluxes_out[i] = sum.v[SART_ACC_SUM_WEIGHTS];
+  }
+  return 0;
+}
+
 int sart_host_containment_radii(const double* counts, const double* weights, int32_t n_bins, double radial_max,
                                 double* r_sigma1, double* r_sigma2, double* r_sigma1_w, double* r_sigma2_w) {
   if (!counts || !weights || n_bins < 1 || !(radial_max > 0.0))

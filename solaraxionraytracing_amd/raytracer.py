@@ -261,15 +261,29 @@ def calculateFluxFractions(tracer: RayTracer, n_rays: int = 1_000_000, seed: int
     return tracer.trace_histogram(n_rays, seed, ray_id_offset)
 
 
-def performAngularScan(tracer: RayTracer, angularScanMin: float, angularScanMax: float, numAngularScanPoints: int = 50,
-                       n_rays_per_angle: int = 1_000_000, seed: int = 299792458, flags: int | None = None):
-    """performAngularScan (raytracer.nim:2778-2802) through the C++ host driver: returns (angles, fluxes,
-    relative fluxes)."""
+def performAxionMassScan(tracer: RayTracer, masses_ev, n_rays_per_mass: int = 1_000_000, seed: int = 299792458,
+                         flags: int | None = None, ray_id_offset: int = 0):
+    """Gas-stage m_a scan (BASELINE config 5) through the C++ host driver: flux (sum of weights) per axion mass."""
     host = _lib.load_host()
-    angles = np.linspace(angularScanMin, angularScanMax, numAngularScanPoints)
+    masses = np.ascontiguousarray(masses_ev, dtype=np.float64)
+    fluxes = np.empty_like(masses)
+    fl = tracer.full.flags if flags is None else flags
+    _lib.check(host.sart_host_perform_axion_mass_scan(tracer.handle, _lib.as_dp(masses), masses.size, n_rays_per_mass, seed,
+                                                      ray_id_offset, fl, _lib.as_dp(fluxes)), host=True)
+    return fluxes
+
+
+def performAngularScan(tracer: RayTracer, angularScanMin: float, angularScanMax: float, numAngularScanPoints: int = 50,
+                       n_rays_per_angle: int = 1_000_000, seed: int = 299792458, flags: int | None = None,
+                       angles=None, ray_id_offset: int = 0):
+    """performAngularScan (raytracer.nim:2778-2802) through the C++ host driver: returns (angles, fluxes,
+    relative fluxes).  ``angles`` overrides the linspace (used when angle bins are sharded over GPUs)."""
+    host = _lib.load_host()
+    angles = np.linspace(angularScanMin, angularScanMax, numAngularScanPoints) if angles is None else \
+        np.ascontiguousarray(angles, dtype=np.float64)
     fluxes = np.empty_like(angles)
     rel = np.empty_like(angles)
     fl = tracer.full.flags if flags is None else flags
     _lib.check(host.sart_host_perform_angular_scan(tracer.handle, _lib.as_dp(angles), angles.size, n_rays_per_angle,
-                                                   seed, 0, fl, _lib.as_dp(fluxes), _lib.as_dp(rel)), host=True)
+                                                   seed, ray_id_offset, fl, _lib.as_dp(fluxes), _lib.as_dp(rel)), host=True)
     return angles, fluxes, rel

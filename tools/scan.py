@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Scan drivers of the hot path, one process per GPU:
+
+  angular   performAngularScan (raytracer.nim:2778-2815; CLI --angularScanMin/Max --numAngularScanPoints, :2817-2862):
+            effective-area style scan of telescope_turned_y, angle bins sharded over the ranks (BASELINE config 4).
+            Writes a CSV (the reference only makes a PDF) and compares with the two curves the reference overlays
+            (xmm_newton_angular_effective_area.csv, McXtrace_angular_xmm.csv; :2805-2813).
+  mass      gas-stage axion-mass scan (BASELINE config 5): masses sharded over the ranks.
+
+Examples
+  python tools/scan.py angular --angularScanMin 0 --angularScanMax 0.3 --numAngularScanPoints 16 --rays 1e7
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/scan.py mass --points 32 --rays 3e8
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("mode", choices=["angular", "mass"])
+    ap.add_argument("--angularScanMin", type=float, default=0.0)
+    ap.add_argument("--angularScanMax", type=float, default=0.3)
+    ap.add_argument("--numAngularScanPoints", type=int, default=16)
+    ap.add_argument("--points", type=int, default=32, help="mass scan points")
+    ap.add_argument("--massMin", type=float, default=0.0)
+    ap.add_argument("--massMax", type=float, default=0.02, help="eV; the literal-units gas stage has m_gamma = 0.008235 eV")
+    ap.add_argument("--rays", type=float, default=1e7, help="rays per scan point")
+    ap.add_argument("--chip", type=float, default=100.0, help="chip size in mm for the angular scan (SURVEY App. C)")
+    ap.add_argument("--out", default="gpurun_out/scan.csv")
+    args = ap.parse_args()
+
+    import torch
+    import solaraxionraytracing_amd as sa
+    from solaraxionraytracing_amd import _lib as L, distributed as D, tables
+
+    rank, world, local_rank = D.init_process_group_from_env(os.environ.get("SART_BENCH_BACKEND"))
+    if "SART_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SART_BENCH_DEVICE"])
+    n_rays = int(args.rays)
+    if args.mode == "angular":
+        full = sa.initFullSetup()
+        full.setup.chip_x_max = full.setup.chip_y_max = args.chip       # ChipXMax = 100 mm alternative (raytracer.nim:262-264)
+        flags = L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS | L.CF_IGNORE_CONV_PROB   # cf. comment :2315
+        xs = np.linspace(args.angularScanMin, args.angularScanMax, args.numAngularScanPoints)
+    else:
+        full = sa.initFullSetup(stage=L.SK_GAS)
+        flags = 0
+        xs = np.linspace(args.massMin, args.massMax, args.points)
+    mine = D.shard_angles(len(xs), rank, world)
+    with sa.RayTracer(full, device=local_rank) as rt:
+        if args.mode == "angular":
+            # every bin keeps its own ray-id block so that the result does not depend on the number of ranks
+            vals = [sa.performAngularScan(rt, 0, 0, 1, n_rays, flags=flags, angles=[xs[i]], ray_id_offset=i * n_rays)[1][0] for i in mine]
+        else:
+            vals = [sa.performAxionMassScan(rt, [xs[i]], n_rays, flags=flags, ray_id_offset=i * n_rays)[0] for i in mine]
+    dev = torch.device("cuda", local_rank) if (world > 1 and torch.distributed.get_backend() == "nccl") else "cpu"
+    curve = D.gather_scan(torch.tensor(vals, dtype=torch.float64, device=dev), mine, len(xs)).cpu().numpy()
+    if rank == 0:
+        rel = curve / curve.max()
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w") as f:
+            if args.mode == "angular":
+                ref = tables.reference_curves()
+                xmm_x = ref["xmm_angle_arcmin"] / 60.0
+                ok = ref["xmm_effective_area"] > 0
+                xmm = np.interp(xs, xmm_x[ok], ref["xmm_effective_area"][ok] / ref["xmm_effective_area"].max())
+                mcx = np.interp(xs, ref["mcxtrace_angle_deg"], ref["mcxtrace_rel_flux"])
+                f.write("Angle [deg],flux,relative flux,XMM theory,McXtrace\n")
+                for a, c, r, t, m in zip(xs, curve, rel, xmm, mcx):
+                    f.write("%.6g,%.10g,%.8f,%.6f,%.6f\n" % (a, c, r, t, m))
+                print("angular scan: relative flux", np.round(rel, 4).tolist())
+                print("XMM theory          :", np.round(xmm, 4).tolist())
+                print("McXtrace            :", np.round(mcx, 4).tolist())
+            else:
+                f.write("m_a [eV],flux,relative flux\n")
+                for a, c, r in zip(xs, curve, rel):
+                    f.write("%.8g,%.10g,%.8f\n" % (a, c, r))
+                print("mass scan: m_a", np.round(xs, 5).tolist())
+                print("relative flux", np.round(rel, 4).tolist())
+        print("wrote", args.out)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
