@@ -4,7 +4,7 @@
 A "step" is one pass of the hot path (sample -> bore/pipes -> Wolter shells -> reflectivity -> detector ->
 focal-plane histogram) over one batch of --rays-per-step rays per GPU, with all tables resident in HBM.
 Workload = BASELINE.json configs[2]: BabyIAXO magnet + XMM-Newton shells (58), vacuum, InGridIAXO window,
-256x256 focal-plane image; default 10 x 1e8 = 1e9 rays per GPU.  Inputs are the documented synthetic tables
+256x256 focal-plane image; one step = one 1e9-ray image per GPU.  Inputs are the documented synthetic tables
 (E1 Primakoff emission on AGSS09, G1 Henke gold reflectivity; the reference's own input files are not shipped).
 
 Multi-GPU (weak scaling): one process per GPU (torchrun contract), rays shard by global ray id, every rank
@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rays-per-step", type=float, default=1e8)
+    ap.add_argument("--rays-per-step", type=float, default=1e9, help="rays per step and GPU (one BabyIAXO image of BASELINE configs[2])")
     ap.add_argument("--workload", default="babyiaxo_xmm", choices=["babyiaxo_xmm", "cast_llnl_gold"])
     ap.add_argument("--cpu-sample", type=float, default=3e8, help="rays of the CPU-baseline sample")
     ap.add_argument("--profile-run", action="store_true", help="no CPU baseline (run under rocprofv3)")

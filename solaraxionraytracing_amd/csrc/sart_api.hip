@@ -121,6 +121,7 @@ struct sart_context {
   DevBuf<uint16_t> d_rguide, d_eguide;
   DevBuf<EnergyDev> d_etab;
   DevBuf<double> d_replicas;   // kImageReplicas scratch images (kept zeroed between launches)
+  DevBuf<double> d_partials;   // per-workgroup partial sums of the scalars
   DevBuf<double> d_acc;        // scratch accumulator of the blocking convenience call
   DevBuf<sart_axion_t> d_rec;  // scratch records of the blocking convenience call
   bool derived_dirty = true;
@@ -392,6 +393,7 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   if (p->image_nx < 1 || p->image_ny < 1 || !(p->image_x_max > p->image_x_min) || !(p->image_y_max > p->image_y_min))
     return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
   a.replicas = nullptr;
+  a.partials = nullptr;
   a.replica_mask = 0u;
   a._pad = 0u;
   a.n_rays = p->n_rays;
@@ -804,6 +806,12 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
     c->blocks_per_cu_hist = std::max(1, histogram_blocks_per_cu(histogram_block(), true));
     if (const char* e = std::getenv("SART_HIST_BLOCKS_PER_CU")) c->blocks_per_cu_hist = std::max(1, std::atoi(e));
   }
+  const int n_blocks = grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_hist, histogram_block());
+  if (c->d_partials.n < static_cast<size_t>(n_blocks) * SART_ACC_COUNT) {
+    SART_HIP(hipStreamSynchronize(c->stream));
+    if (int rc = c->d_partials.resize(static_cast<size_t>(c->n_cu) * 16 * SART_ACC_COUNT)) return rc;
+  }
+  a.partials = c->d_partials.p;
   {
     TimedLaunch tl(c);
     // specialised instantiation for the common configuration (solar source, telescope not rotated, vacuum,
@@ -811,8 +819,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
     const DevParams& P = c->params;
     const bool fast = !P.test_active && !P.rotated && !P.stage_gas && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) &&
                       !std::getenv("SART_FORCE_GENERIC");
-    launch_trace_histogram(c->hot, c->d_blob.p, a, acc_dev,
-                           grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_hist, histogram_block()), c->stream, fast);
+    launch_trace_histogram(c->hot, c->d_blob.p, a, acc_dev, n_blocks, c->stream, fast);
   }
   SART_HIP(hipGetLastError());
   return 0;

@@ -168,6 +168,9 @@ struct TraceArgs {
   // accumulator.  replica_mask = 0 (wide images): `replicas` is the accumulator itself, no fold.
   double* replicas;
   uint32_t replica_mask, _pad;
+  // Per-workgroup partial sums of the SART_ACC_COUNT scalars (plain stores; fold_scalars_kernel adds them to the
+  // accumulator): thousands of f64 atomics on the same 11 addresses serialise for hundreds of microseconds.
+  double* partials;
   uint32_t seed_lo, seed_hi;
   uint32_t flags;
   int32_t image_nx, image_ny;

@@ -874,24 +874,41 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     if (draining && t1 == h1) break;
   }
 
-  // scalars: wave reduction, then one atomic per wave and quantity
-  double* sc = acc + (size_t)A.image_nx * (size_t)A.image_ny;
+  // scalars: wave reduction -> LDS -> one plain store per workgroup and quantity (folded by fold_scalars_kernel)
+  __shared__ double red[BLOCK / 64][SART_ACC_COUNT];
   const double sw = wave_sum(sum_w), sw2 = wave_sum(sum_w2), sxx = wave_sum(sum_x), syy = wave_sum(sum_y),
                srr = wave_sum(sum_r);
   if (lane == 0) {
-    unsafeAtomicAdd(&sc[SART_ACC_SUM_WEIGHTS], sw);
-    unsafeAtomicAdd(&sc[SART_ACC_SUM_WEIGHTS_SQ], sw2);
-    unsafeAtomicAdd(&sc[SART_ACC_SUM_X], sxx);
-    unsafeAtomicAdd(&sc[SART_ACC_SUM_Y], syy);
-    unsafeAtomicAdd(&sc[SART_ACC_SUM_R], srr);
-    unsafeAtomicAdd(&sc[SART_ACC_N_PASSED], (double)n_passed);
-    unsafeAtomicAdd(&sc[SART_ACC_N_PASSED_TILL_WINDOW], (double)n_till);
-    unsafeAtomicAdd(&sc[SART_ACC_N_HIT_NICKEL], (double)n_nickel);
-    unsafeAtomicAdd(&sc[SART_ACC_N_REACHED_TELESCOPE], (double)n_reached);
-    unsafeAtomicAdd(&sc[SART_ACC_N_SHELL_SELECTED], (double)n_shell);
-    unsafeAtomicAdd(&sc[SART_ACC_N_OUTSIDE_IMAGE], (double)n_outside);
+    double* r = red[wave];
+    for (int k = 0; k < SART_ACC_COUNT; ++k) r[k] = 0.0;
+    r[SART_ACC_SUM_WEIGHTS] = sw;
+    r[SART_ACC_SUM_WEIGHTS_SQ] = sw2;
+    r[SART_ACC_SUM_X] = sxx;
+    r[SART_ACC_SUM_Y] = syy;
+    r[SART_ACC_SUM_R] = srr;
+    r[SART_ACC_N_PASSED] = (double)n_passed;
+    r[SART_ACC_N_PASSED_TILL_WINDOW] = (double)n_till;
+    r[SART_ACC_N_HIT_NICKEL] = (double)n_nickel;
+    r[SART_ACC_N_REACHED_TELESCOPE] = (double)n_reached;
+    r[SART_ACC_N_SHELL_SELECTED] = (double)n_shell;
+    r[SART_ACC_N_OUTSIDE_IMAGE] = (double)n_outside;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) unsafeAtomicAdd(&sc[SART_ACC_N_RAYS], (double)A.n_rays);
+  __syncthreads();
+  if (threadIdx.x < SART_ACC_COUNT) {
+    double t = 0.0;
+    for (int w = 0; w < BLOCK / 64; ++w) t += red[w][threadIdx.x];
+    A.partials[(size_t)blockIdx.x * SART_ACC_COUNT + threadIdx.x] = t;
+  }
+}
+
+// acc scalars += sum over workgroups of the partials; N_RAYS += n_rays.
+__global__ __launch_bounds__(64) void fold_scalars_kernel(double* __restrict__ scalars, const double* __restrict__ partials,
+                                                          int n_blocks, double n_rays) {
+  const int k = threadIdx.x;
+  if (k >= SART_ACC_COUNT) return;
+  double t = (k == SART_ACC_N_RAYS) ? n_rays : 0.0;
+  for (int b = 0; b < n_blocks; ++b) t += partials[(size_t)b * SART_ACC_COUNT + k];
+  scalars[k] += t;
 }
 
 // acc[i] += sum over replicas; replicas are left zeroed for the next launch.
@@ -979,11 +996,11 @@ void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs&
                             hipStream_t stream, bool fast) {
   if (fast) launch_hist<true>(H, blob, A, acc, n_blocks, stream);
   else launch_hist<false>(H, blob, A, acc, n_blocks, stream);
-  if (A.replica_mask != 0u) {
-    const int n_img = A.image_nx * A.image_ny;
+  const int n_img = A.image_nx * A.image_ny;
+  hipLaunchKernelGGL(fold_scalars_kernel, dim3(1), dim3(64), 0, stream, acc + n_img, A.partials, n_blocks, (double)A.n_rays);
+  if (A.replica_mask != 0u)
     hipLaunchKernelGGL(fold_replicas_kernel, dim3((n_img + 255) / 256), dim3(256), 0, stream, acc, A.replicas, n_img,
                        (int)A.replica_mask + 1);
-  }
 }
 void launch_trace_records(const HotA& H, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream) {
