@@ -85,6 +85,39 @@ __device__ __forceinline__ double fsqrt(double x) {
   return (x > 0.0) ? g : ((x == 0.0) ? 0.0 : __builtin_nan(""));   // rsq(0) = inf would give NaN; negative -> NaN
 }
 
+// sin(pi a), cos(pi a) for a in [0, 2] (a = 2u or u with u uniform in [0, 1)): n = rint(2a), r = a - n/2 in
+// [-1/4, 1/4], Taylor series in (pi r) (truncation < 6e-17 relative), quadrant from n.  The library sincospi carries
+// range reduction and inf/NaN handling for arbitrary arguments that this path never needs.
+__device__ __forceinline__ void sincospi_02(double a, double* sn, double* cs) {
+  const double n = __builtin_rint(a + a);
+  const double r = fma(-0.5, n, a);
+  const int q = (int)n;                          // 0 .. 4
+  const double x = r * r;
+  double ps = -2.1915353447830204e-05;           // coefficients (-1)^k pi^(2k+1) / (2k+1)!, k = 7 .. 0
+  ps = fma(ps, x, 4.6630280576761234e-04);
+  ps = fma(ps, x, -7.370430945714348e-03);
+  ps = fma(ps, x, 8.214588661112819e-02);
+  ps = fma(ps, x, -5.992645293207919e-01);
+  ps = fma(ps, x, 2.550164039877345e+00);
+  ps = fma(ps, x, -5.167712780049969e+00);
+  ps = fma(ps, x, 3.141592653589793e+00);
+  const double sr = ps * r;                      // sin(pi r)
+  double pc = 4.303069587032944e-06;             // coefficients (-1)^k pi^(2k) / (2k)!, k = 8 .. 1
+  pc = fma(pc, x, -1.0463810492484565e-04);
+  pc = fma(pc, x, 1.929574309403922e-03);
+  pc = fma(pc, x, -2.580689139001405e-02);
+  pc = fma(pc, x, 2.3533063035889312e-01);
+  pc = fma(pc, x, -1.3352627688545893e+00);
+  pc = fma(pc, x, 4.058712126416768e+00);
+  pc = fma(pc, x, -4.934802200544679e+00);
+  const double cr = fma(pc, x, 1.0);             // cos(pi r)
+  // a = n/2 + r:  sin(pi a) = sin(n pi/2) cos(pi r) + cos(n pi/2) sin(pi r), etc.
+  const bool odd = (q & 1) != 0;
+  const double s0 = odd ? cr : sr, c0 = odd ? sr : cr;
+  *sn = (q & 2) ? -s0 : s0;                      // n = 0: s, 1: c, 2: -s, 3: -c, 4: s
+  *cs = ((q + 1) & 2) ? -c0 : c0;                // n = 0: c, 1: -s, 2: -c, 3: s, 4: c
+}
+
 // asin for the grazing angles of the path (|x| < ~0.03): odd Taylor series
 // asin x = x + x^3/6 + 3x^5/40 + 5x^7/112 + 35x^9/1152 + 63x^11/2816 + 231x^13/13312 + 143x^15/10240,
 // truncation error < 1e-19 below 0.06; the library function outside.
@@ -156,7 +189,8 @@ __device__ __forceinline__ bool pick_root(double a, double hb, double c, double 
   const double disc = fma(hb, hb, -a * c);
   const double sq = fsqrt(disc);  // NaN for disc < 0 -> every comparison below is false -> miss
   const double q = (hb >= 0.0) ? (-hb - sq) : (-hb + sq);
-  const double qa = q * frcp(a), cq = c * frcp(q);
+  const double raq = frcp(a * q);            // one reciprocal: 1/a = q raq, 1/q = a raq
+  const double qa = q * q * raq, cq = c * a * raq;
   const double root1 = (hb >= 0.0) ? qa : cq;
   const double root2 = (hb >= 0.0) ? cq : qa;
   if (root1 > zlo && root1 < zhi) { z = root1; return true; }
@@ -171,8 +205,9 @@ __device__ __forceinline__ bool pick_root(double a, double hb, double c, double 
 __device__ __forceinline__ double reflect(double& wx, double& wy, double& wz, double L, double nx, double ny,
                                           double nz, double N2) {
   const double dnw = fma(nx, wx, fma(ny, wy, nz * wz));
-  const double f = dnw * frcp(N2);
-  const double c2 = dnw * f * frcp(L);
+  const double rnl = frcp(N2 * L);           // one reciprocal for both 1/N2 and 1/(N2 L)
+  const double c2 = dnw * dnw * rnl;
+  const double f = dnw * (L * rnl);
   if (dnw >= 0.0) {
     wx = fma(-2.0 * f, nx, wx);
     wy = fma(-2.0 * f, ny, wy);
@@ -281,8 +316,8 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   if (!cfg_test) {
     // getRandomPointFromSolarModel (:425-442): theta1 = 360 u0 deg, theta2 = 180 u1 deg (uniform in theta)
     double s1, c1, s2, c2;
-    sincospi(2.0 * u0, &s1, &c1);
-    sincospi(u1, &s2, &c2);
+    sincospi_02(2.0 * u0, &s1, &c1);
+    sincospi_02(u1, &s2, &c2);
     {
       // lowerBound(fluxRadiusCDF, u2) (:437) inside the guide bracket; bounded, branch-free walk
       const int k = (int)(u2 * (double)kRadiusGuide);
@@ -299,7 +334,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
     const double ox = c1 * s2 * r, oy = s1 * s2 * r, oz = c2 * r - H.sun_distance;
     // getRandomPointOnDisk (:412-422)
     double sp, cp;
-    sincospi(2.0 * u4, &sp, &cp);
+    sincospi_02(2.0 * u4, &sp, &cp);
     const double rr = H.radius_cb * fsqrt(u3);
     ex = cp * rr;
     ey = sp * rr;
@@ -309,7 +344,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   } else {
     // X-ray test source (:1765-1806)
     double sp, cp;
-    sincospi(2.0 * u1, &sp, &cp);
+    sincospi_02(2.0 * u1, &sp, &cp);
     const double rr = P.test_radius * fsqrt(u0);
     const double ox = cp * rr + P.test_x, oy = sp * rr + P.test_y, oz = P.test_z;
     if (P.test_parallel) {
@@ -317,7 +352,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
       ey = oy + (u3 * 0.5) - 0.25;
     } else {
       double sq, cq;
-      sincospi(2.0 * u3, &sq, &cq);
+      sincospi_02(2.0 * u3, &sq, &cq);
       const double r2 = H.radius_cb * fsqrt(u2);
       ex = cq * r2;
       ey = sq * r2;
