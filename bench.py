@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=float, default=3e8, help="rays of the CPU-baseline sample")
     ap.add_argument("--profile-run", action="store_true", help="no CPU baseline (run under rocprofv3)")
     ap.add_argument("--traffic-bytes-per-launch", type=float, default=None,
-                    help="HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)")
+                    help="fabric bytes per launch from a separate rocprofv3 --pmc pass; default: profiles/pmc_traffic.json "
+                         "if it was measured for the same workload and launch size")
     return ap.parse_args()
 
 
@@ -72,6 +73,17 @@ def main():
         wl_name = "CAST magnet + LLNL 14 shells, gold_0.25microns reflectivities (BASELINE configs[1])"
 
     rays = int(args.rays_per_step)
+    traffic = args.traffic_bytes_per_launch
+    traffic_note = None
+    if traffic is None:
+        try:   # PMC counters cannot be collected from inside this process; use the committed separate-pass measurement
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                t = json.load(f)
+            if t["workload"] == args.workload:
+                traffic = t["bytes_per_ray"] * rays
+                traffic_note = t["note"]
+        except Exception:
+            pass
     rt = sa.RayTracer(full, device=local_rank)
     # Launches, torch ops on the accumulator and the RCCL reduce are ordered by ONE explicit stream.  (torch's
     # default stream has handle 0, which sart_set_stream reads as "the context's own stream".)
@@ -146,7 +158,7 @@ def main():
                        "tables": full.meta, "sharding": "global ray id, 1 RCCL reduce of image+scalars",
                        "device": rt.device_info()},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": args.traffic_bytes_per_launch,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "trace_histogram_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": n_launch,
                          "algorithmic_bytes_per_ray": bytes_per_ray, "headline_bytes_per_ray_upper_bound": BYTES_DETECTOR,
                          "secondary_f64_valu": {"achieved_tflops": flops_per_ray * rays / avg_kernel_s / 1e12,

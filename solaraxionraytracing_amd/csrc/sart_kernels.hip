@@ -936,14 +936,21 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   }
 }
 
-// acc scalars += sum over workgroups of the partials; N_RAYS += n_rays.
-__global__ __launch_bounds__(64) void fold_scalars_kernel(double* __restrict__ scalars, const double* __restrict__ partials,
-                                                          int n_blocks, double n_rays) {
-  const int k = threadIdx.x;
-  if (k >= SART_ACC_COUNT) return;
-  double t = (k == SART_ACC_N_RAYS) ? n_rays : 0.0;
-  for (int b = 0; b < n_blocks; ++b) t += partials[(size_t)b * SART_ACC_COUNT + k];
-  scalars[k] += t;
+// acc scalars += sum over workgroups of the partials; N_RAYS += n_rays.  256 threads: 16 groups x 16 quantities.
+__global__ __launch_bounds__(256) void fold_scalars_kernel(double* __restrict__ scalars, const double* __restrict__ partials,
+                                                           int n_blocks, double n_rays) {
+  static_assert(SART_ACC_COUNT == 16, "layout of the reduction below");
+  __shared__ double red[16][16];
+  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
+  double t = 0.0;
+  for (int b = g; b < n_blocks; b += 16) t += partials[(size_t)b * SART_ACC_COUNT + k];
+  red[g][k] = t;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    double s = (k == SART_ACC_N_RAYS) ? n_rays : 0.0;
+    for (int i = 0; i < 16; ++i) s += red[i][k];
+    scalars[k] += s;
+  }
 }
 
 // acc[i] += sum over replicas; replicas are left zeroed for the next launch.
@@ -1032,7 +1039,7 @@ void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs&
   if (fast) launch_hist<true>(H, blob, A, acc, n_blocks, stream);
   else launch_hist<false>(H, blob, A, acc, n_blocks, stream);
   const int n_img = A.image_nx * A.image_ny;
-  hipLaunchKernelGGL(fold_scalars_kernel, dim3(1), dim3(64), 0, stream, acc + n_img, A.partials, n_blocks, (double)A.n_rays);
+  hipLaunchKernelGGL(fold_scalars_kernel, dim3(1), dim3(256), 0, stream, acc + n_img, A.partials, n_blocks, (double)A.n_rays);
   if (A.replica_mask != 0u)
     hipLaunchKernelGGL(fold_replicas_kernel, dim3((n_img + 255) / 256), dim3(256), 0, stream, acc, A.replicas, n_img,
                        (int)A.replica_mask + 1);

@@ -11,12 +11,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # Build the native pieces once if they are missing (hipcc cross-compiles without a GPU).
-    pkg = os.path.join(ROOT, "solaraxionraytracing_amd")
-    need = [os.path.join(pkg, "libsart.so"), os.path.join(pkg, "libsart_host.so"),
-            os.path.join(ROOT, "oracle", "libsart_oracle.so"), os.path.join(ROOT, "oracle", "libsart_oracle_ld.so")]
-    if not all(os.path.exists(p) for p in need):
-        subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, check=True)
+    # Keep the native pieces in step with their sources: `make` is a no-op when they are up to date
+    # (hipcc cross-compiles without a GPU; the same toolchain exists on the GPU box).
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "solaraxionraytracing_amd", "csrc")], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
 
 
 def _has_gpu():
