@@ -79,6 +79,17 @@ int sart_host_perform_axion_mass_scan(sart_context* ctx, const double* masses_ev
                                       uint64_t n_rays_per_mass, uint64_t seed, uint64_t ray_id_offset,
                                       uint32_t flags, double* fluxes_out);
 
+/* HDF5 reflectivity files read by initReflectivity (raytracer.nim:1174-1186, :1196-1209; written by
+ * tools/llnl_layer_reflectivity.nim:62-80 and tools/convert_reflectivities_to_h5.nim:29-48): datasets `/Energy` (nE,1) keV,
+ * `/Angles` (nA,1) deg, and `/Reflectivity` (single coating) or `/Reflectivity0..N-1` (LLNL), f64, declared shape (nE, nA)
+ * but laid out [angle][energy] row-major.  Only min/max of the axes are used (uniform grid).  libhdf5 is loaded at run
+ * time (dlopen); without it these calls return SART_ERR_UNSUPPORTED. */
+int sart_host_h5_reflectivity_info(const char* path, int32_t* n_coatings, int32_t* n_angles, int32_t* n_energies,
+                                   double* angle_min, double* angle_max, double* energy_min, double* energy_max);
+int sart_host_h5_read_reflectivity(const char* path, double* data_out /* [n_coatings][n_angles][n_energies] */);
+int sart_host_h5_write_reflectivity(const char* path, int32_t n_coatings, int32_t n_angles, int32_t n_energies,
+                                    const double* angles_deg, const double* energies_kev, const double* data);
+
 /* Containment radii of generateResultPlots (raytracer.nim:2459-2527) from the radial histograms of a spectra trace
  * (bin k = [k, k+1) * radial_max / n_bins):
  *   r_sigma1 / r_sigma2     radii holding round(0.68 n) / round(0.955 n) of the passed rays (pointR[sigma1 - 1], :2472-2473)

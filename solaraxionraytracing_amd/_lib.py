@@ -164,6 +164,9 @@ SART_HOST_SYMBOLS = {
     "sart_host_build_cdfs": (C.c_int, [_dp, _dp, _dp, _i, _i, _dp, _dp]),
     "sart_host_detector_tables": (C.c_int, [_dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _dp, _dp, _dp]),
     "sart_host_perform_axion_mass_scan": (C.c_int, [C.c_void_p, _dp, _i, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _dp]),
+    "sart_host_h5_reflectivity_info": (C.c_int, [C.c_char_p, _P(_i), _P(_i), _P(_i), _dp, _dp, _dp, _dp]),
+    "sart_host_h5_read_reflectivity": (C.c_int, [C.c_char_p, _dp]),
+    "sart_host_h5_write_reflectivity": (C.c_int, [C.c_char_p, _i, _i, _i, _dp, _dp, _dp]),
     "sart_host_containment_radii": (C.c_int, [_dp, _dp, _i, _d, _dp, _dp, _dp, _dp]),
     "sart_host_write_image_csv": (C.c_int, [C.c_char_p, _dp, _i, _d, _d, _d, _dp]),
     "sart_host_trace_axion_wrapper": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32]),

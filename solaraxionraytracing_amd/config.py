@@ -1,0 +1,96 @@
+"""The reference's configuration surface for the hot path: `config/config.toml` (keys of
+config/config_default.toml:1-50; parsers raytracer.nim:984-1096) and the cligen flags of `main`
+(raytracer.nim:2817-2850) -> the inputs of `initFullSetup`.  Host-side plumbing only.
+
+Resolution of the three input files follows the reference: `[Resources].resourcePath` / `solarModelFile`,
+`goldReflFile`, `llnlReflFile` (:2645-2647, :1170-1171, :1193-1194).  When a file is not there (the reference does not
+ship them) the documented synthetic stand-in of tables.py is used and noted in ``FullRaytraceSetup.meta``.
+"""
+from __future__ import annotations
+
+import os
+
+from . import _lib, tables
+from .raytracer import FullRaytraceSetup, initFullSetup
+
+_ENUMS = {
+    "experimentSetup": {"CAST": _lib.ES_CAST, "BabyIAXO": _lib.ES_BABYIAXO},                       # raytracer.nim:16-18
+    "detectorSetup": {"InGrid2017": _lib.DK_INGRID2017, "InGrid2018": _lib.DK_INGRID2018,
+                      "InGridIAXO": _lib.DK_INGRIDIAXO},                                              # :164-167
+    "stageSetup": {"vacuum": _lib.SK_VACUUM, "gas": _lib.SK_GAS},                                    # :39-41
+    "telescopeSetup": {"LLNL": _lib.TK_LLNL, "XMM": _lib.TK_XMM, "CustomBabyIAXO": _lib.TK_CUSTOM_BABYIAXO,
+                       "Abrixas": _lib.TK_ABRIXAS, "Other": _lib.TK_OTHER},                          # :31-37
+}
+
+
+def flags_from_cli(ignoreDetWindow=False, ignoreGasAbs=False, ignoreConvProb=False, ignoreReflection=False, xrayTest=False,
+                   detectorInstall=False, magnet=False) -> int:
+    """set[ConfigFlags] from the switches of `main` (raytracer.nim:2842-2849)."""
+    f = 0
+    if ignoreDetWindow: f |= _lib.CF_IGNORE_DET_WINDOW
+    if ignoreGasAbs: f |= _lib.CF_IGNORE_GAS_ABS
+    if ignoreConvProb: f |= _lib.CF_IGNORE_CONV_PROB
+    if ignoreReflection: f |= _lib.CF_IGNORE_REFLECTION
+    if xrayTest: f |= _lib.CF_XRAY_TEST
+    if magnet: f |= _lib.CF_READ_MAGNET_CONFIG
+    if detectorInstall: f |= _lib.CF_READ_DET_INSTALL_CONFIG
+    return f
+
+
+def parse_setup(cfg: dict):
+    """parseSetup (raytracer.nim:1024-1030); an unknown name raises ValueError like parseEnum."""
+    out = []
+    for key in ("experimentSetup", "detectorSetup", "stageSetup", "telescopeSetup"):
+        name = cfg["Setup"][key]
+        if name not in _ENUMS[key]:
+            raise ValueError("invalid enum value: %s = %r" % (key, name))
+        out.append(_ENUMS[key][name])
+    return tuple(out)
+
+
+def load_config(path: str) -> dict:
+    import tomli
+    with open(path, "rb") as f:
+        return tomli.load(f)
+
+
+def init_full_setup_from_config(config_path: str, flags: int = 0, **overrides) -> FullRaytraceSetup:
+    """initFullSetup(parseSetup()..., flags) driven by a config.toml (raytracer.nim:2852-2859)."""
+    cfg = load_config(config_path)
+    es, dk, sk, tk = parse_setup(cfg)
+    base = os.path.dirname(os.path.abspath(config_path))
+    res = cfg.get("Resources", {})
+    rdir = os.path.normpath(os.path.join(base, res.get("resourcePath", "../resources")))
+
+    magnet_cfg = source_cfg = install_cfg = None
+    m = cfg.get("Magnet", {})
+    if (flags & _lib.CF_READ_MAGNET_CONFIG) or m.get("useConfig", False):          # maybeParseMagnetConfig :1032-1051
+        magnet_cfg = _lib.MagnetConfig(m["B"], m["radiusCB"], m["lengthColdbore"], m["lengthB"], m["pGasRoom"], m["tGas"])
+    t = cfg.get("TestXraySource", {})
+    if (flags & _lib.CF_XRAY_TEST) or t.get("useConfig", False):                   # maybeParseTestXraySource :1053-1076
+        source_cfg = _lib.TestSourceConfig(int(t["active"]), int(t["parallel"]), t["energy"], t["distance"], t["radius"],
+                                           t["offAxisUp"], t["offAxisLeft"], t["activity"], t["lengthCol"])
+    d = cfg.get("DetectorInstallation", {})
+    if (flags & _lib.CF_READ_DET_INSTALL_CONFIG) or d.get("useConfig", False):     # maybeParseDetectorInstallation :1078-1096
+        install_cfg = _lib.DetectorInstallConfig(d["distanceDetectorXRT"], d["distanceWindowFocalPlane"], d["lateralShift"],
+                                                 d["transversalShift"])
+
+    kw = dict(magnet_cfg=magnet_cfg, source_cfg=source_cfg, install_cfg=install_cfg)
+    notes = []
+    solar = os.path.join(rdir, res.get("solarModelFile", "solar_model_dataframe.csv"))
+    if os.path.exists(solar):
+        kw["solar_model_csv"] = solar
+    else:
+        notes.append("solarModelFile %s not found: synthetic E1 emission table" % solar)
+    refl_key = "llnlReflFile" if tk == _lib.TK_LLNL else "goldReflFile"
+    refl = os.path.join(rdir, res.get(refl_key, ""))
+    if res.get(refl_key) and os.path.exists(refl):
+        kw["reflectivity"] = tables.read_reflectivity_h5(refl)
+    else:
+        notes.append("%s %s not found: synthetic Henke-derived reflectivity" % (refl_key, refl))
+    kw.update(overrides)
+    full = initFullSetup(es, dk, sk, tk, flags, **kw)
+    full.outpath = os.path.normpath(os.path.join(base, res.get("outputPath", "../out")))
+    full.meta["config"] = config_path
+    full.meta["notes"] = notes
+    return full

@@ -13,6 +13,7 @@
 #include <vector>
 #include <algorithm>
 #include <cstdio>
+#include <dlfcn.h>
 
 namespace {
 
@@ -239,6 +240,75 @@ int newDetectorSetup(int32_t kind, sart_setup_t& s) {
   return 0;
 }
 
+// ---- libhdf5 through dlopen (HDF5 1.10 C API; hid_t = int64_t) ------------------------------------------------
+struct H5 {
+  using hid = int64_t;
+  void* lib = nullptr;
+  int (*H5open)() = nullptr;
+  hid (*H5Fopen)(const char*, unsigned, hid) = nullptr;
+  hid (*H5Fcreate)(const char*, unsigned, hid, hid) = nullptr;
+  int (*H5Fclose)(hid) = nullptr;
+  hid (*H5Dopen2)(hid, const char*, hid) = nullptr;
+  hid (*H5Dcreate2)(hid, const char*, hid, hid, hid, hid, hid) = nullptr;
+  int (*H5Dclose)(hid) = nullptr;
+  hid (*H5Dget_space)(hid) = nullptr;
+  long long (*H5Sget_simple_extent_npoints)(hid) = nullptr;
+  hid (*H5Screate_simple)(int, const unsigned long long*, const unsigned long long*) = nullptr;
+  int (*H5Sclose)(hid) = nullptr;
+  int (*H5Dread)(hid, hid, hid, hid, hid, void*) = nullptr;
+  int (*H5Dwrite)(hid, hid, hid, hid, hid, const void*) = nullptr;
+  int (*H5Lexists)(hid, const char*, hid) = nullptr;
+  int (*H5Eset_auto2)(hid, void*, void*) = nullptr;
+  hid native_double = -1;
+  bool ok = false;
+
+  static H5& get() {
+    static H5 h;
+    static bool tried = false;
+    if (tried) return h;
+    tried = true;
+    const char* names[] = {"libhdf5.so", "libhdf5.so.103", "libhdf5_serial.so", "/opt/conda/lib/libhdf5.so", nullptr};
+    for (int i = 0; names[i] && !h.lib; ++i) h.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!h.lib) return h;
+#define SART_H5SYM(n) h.n = reinterpret_cast<decltype(h.n)>(dlsym(h.lib, #n)); if (!h.n) return h;
+    SART_H5SYM(H5open) SART_H5SYM(H5Fopen) SART_H5SYM(H5Fcreate) SART_H5SYM(H5Fclose) SART_H5SYM(H5Dopen2)
+    SART_H5SYM(H5Dcreate2) SART_H5SYM(H5Dclose) SART_H5SYM(H5Dget_space) SART_H5SYM(H5Sget_simple_extent_npoints)
+    SART_H5SYM(H5Screate_simple) SART_H5SYM(H5Sclose) SART_H5SYM(H5Dread) SART_H5SYM(H5Dwrite) SART_H5SYM(H5Lexists)
+    SART_H5SYM(H5Eset_auto2)
+#undef SART_H5SYM
+    if (h.H5open() < 0) return h;
+    hid* nd = reinterpret_cast<hid*>(dlsym(h.lib, "H5T_NATIVE_DOUBLE_g"));
+    if (!nd) return h;
+    h.native_double = *nd;
+    h.H5Eset_auto2(0, nullptr, nullptr);   // errors are reported through return codes
+    h.ok = true;
+    return h;
+  }
+
+  // reads a whole f64 dataset; returns its number of elements or -1
+  long long read_all(hid file, const char* name, std::vector<double>& out) {
+    if (H5Lexists(file, name, 0) <= 0) return -1;
+    const hid d = H5Dopen2(file, name, 0);
+    if (d < 0) return -1;
+    const hid sp = H5Dget_space(d);
+    const long long n = H5Sget_simple_extent_npoints(sp);
+    H5Sclose(sp);
+    if (n <= 0) { H5Dclose(d); return -1; }
+    out.resize(static_cast<size_t>(n));
+    const int rc = H5Dread(d, native_double, 0, 0, 0, out.data());
+    H5Dclose(d);
+    return rc < 0 ? -1 : n;
+  }
+};
+
+int h5_count_coatings(H5& h, H5::hid f, bool& single) {
+  single = h.H5Lexists(f, "Reflectivity", 0) > 0;
+  if (single) return 1;
+  int n = 0;
+  while (n < SART_MAX_COATINGS && h.H5Lexists(f, ("Reflectivity" + std::to_string(n)).c_str(), 0) > 0) ++n;
+  return n;
+}
+
 }  // namespace
 
 extern "C" {
@@ -398,6 +468,73 @@ int sart_host_perform_axion_mass_scan(sart_context* ctx, const double* masses_ev
     fluxes_out[i] = sum.v[SART_ACC_SUM_WEIGHTS];
   }
   return 0;
+}
+
+int sart_host_h5_reflectivity_info(const char* path, int32_t* n_coatings, int32_t* n_angles, int32_t* n_energies,
+                                   double* amin, double* amax, double* emin, double* emax) {
+  H5& h = H5::get();
+  if (!h.ok) return fail(SART_ERR_UNSUPPORTED, "libhdf5 could not be loaded");
+  if (!path) return fail(SART_ERR_INVALID_ARGUMENT, "path is NULL");
+  const H5::hid f = h.H5Fopen(path, 0u /* H5F_ACC_RDONLY */, 0);
+  if (f < 0) return fail(SART_ERR_INVALID_ARGUMENT, std::string("cannot open ") + path);  // IOError in the reference (:1174)
+  std::vector<double> energy, angles;
+  const long long nE = h.read_all(f, "Energy", energy), nA = h.read_all(f, "Angles", angles);
+  bool single = false;
+  const int nC = h5_count_coatings(h, f, single);
+  h.H5Fclose(f);
+  if (nE < 2 || nA < 2 || nC < 1) return fail(SART_ERR_INVALID_ARGUMENT, "not a reflectivity file (datasets Energy / Angles / Reflectivity*)");
+  if (n_coatings) *n_coatings = nC;
+  if (n_angles) *n_angles = static_cast<int32_t>(nA);
+  if (n_energies) *n_energies = static_cast<int32_t>(nE);
+  if (amin) *amin = *std::min_element(angles.begin(), angles.end());   // (angles.min, angles.max) :1183
+  if (amax) *amax = *std::max_element(angles.begin(), angles.end());
+  if (emin) *emin = *std::min_element(energy.begin(), energy.end());
+  if (emax) *emax = *std::max_element(energy.begin(), energy.end());
+  return 0;
+}
+
+int sart_host_h5_read_reflectivity(const char* path, double* data_out) {
+  H5& h = H5::get();
+  if (!h.ok) return fail(SART_ERR_UNSUPPORTED, "libhdf5 could not be loaded");
+  if (!path || !data_out) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  const H5::hid f = h.H5Fopen(path, 0u, 0);
+  if (f < 0) return fail(SART_ERR_INVALID_ARGUMENT, std::string("cannot open ") + path);
+  std::vector<double> energy, angles, buf;
+  const long long nE = h.read_all(f, "Energy", energy), nA = h.read_all(f, "Angles", angles);
+  bool single = false;
+  const int nC = h5_count_coatings(h, f, single);
+  int rc = 0;
+  for (int c = 0; c < nC && !rc; ++c) {
+    const std::string name = single ? "Reflectivity" : "Reflectivity" + std::to_string(c);
+    if (h.read_all(f, name.c_str(), buf) != nE * nA) { rc = fail(SART_ERR_INVALID_ARGUMENT, name + ": unexpected size"); break; }
+    // memory is [angle][energy] whatever the declared shape says (reshape(reflDset.shape), :1180)
+    std::memcpy(data_out + static_cast<size_t>(c) * nA * nE, buf.data(), static_cast<size_t>(nA * nE) * sizeof(double));
+  }
+  h.H5Fclose(f);
+  return rc;
+}
+
+int sart_host_h5_write_reflectivity(const char* path, int32_t nC, int32_t nA, int32_t nE, const double* angles,
+                                    const double* energies, const double* data) {
+  H5& h = H5::get();
+  if (!h.ok) return fail(SART_ERR_UNSUPPORTED, "libhdf5 could not be loaded");
+  if (!path || !angles || !energies || !data || nC < 1 || nA < 2 || nE < 2) return fail(SART_ERR_INVALID_ARGUMENT, "bad argument");
+  const H5::hid f = h.H5Fcreate(path, 2u /* H5F_ACC_TRUNC */, 0, 0);
+  if (f < 0) return fail(SART_ERR_INVALID_ARGUMENT, std::string("cannot create ") + path);
+  auto put = [&](const std::string& name, unsigned long long d0, unsigned long long d1, const double* src) {
+    const unsigned long long dims[2] = {d0, d1};
+    const H5::hid sp = h.H5Screate_simple(2, dims, nullptr);
+    const H5::hid d = h.H5Dcreate2(f, name.c_str(), h.native_double, sp, 0, 0, 0);
+    const int rc = (d < 0) ? -1 : h.H5Dwrite(d, h.native_double, 0, 0, 0, src);
+    if (d >= 0) h.H5Dclose(d);
+    h.H5Sclose(sp);
+    return rc;
+  };
+  int rc = put("Energy", nE, 1, energies) | put("Angles", nA, 1, angles);
+  for (int c = 0; c < nC; ++c)   // declared (nE, nA), written from [angle][energy] memory - as the reference's tools do
+    rc |= put(nC == 1 ? "Reflectivity" : "Reflectivity" + std::to_string(c), nE, nA, data + static_cast<size_t>(c) * nA * nE);
+  h.H5Fclose(f);
+  return rc < 0 ? fail(SART_ERR_INTERNAL, "HDF5 write failed") : 0;
 }
 
 int sart_host_containment_radii(const double* counts, const double* weights, int32_t n_bins, double radial_max,

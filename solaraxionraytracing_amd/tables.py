@@ -137,6 +137,31 @@ def llnl_reflectivity_grids(n_angles: int = 1000, n_energies: int = 1000) -> Ref
                             g.energy_min, g.energy_max)
 
 
+def read_reflectivity_h5(path: str) -> ReflectivityGrid:
+    """Reads `gold_0.25microns_reflectivities.h5` / `llnl_layer_reflectivities.h5` (schema of raytracer.nim:1174-1209)
+    through libhdf5 (C++ host library)."""
+    import ctypes as C
+    host = _lib.load_host()
+    nc, na, ne = C.c_int32(), C.c_int32(), C.c_int32()
+    lim = [C.c_double() for _ in range(4)]
+    _lib.check(host.sart_host_h5_reflectivity_info(path.encode(), C.byref(nc), C.byref(na), C.byref(ne),
+                                                   *[C.byref(x) for x in lim]), host=True)
+    data = np.empty((nc.value, na.value, ne.value))
+    _lib.check(host.sart_host_h5_read_reflectivity(path.encode(), _lib.as_dp(data)), host=True)
+    return ReflectivityGrid(data, *[x.value for x in lim])
+
+
+def write_reflectivity_h5(path: str, grid: ReflectivityGrid):
+    """Writes a reflectivity grid in the reference's H5 schema (what tools/convert_reflectivities_to_h5.nim and
+    tools/llnl_layer_reflectivity.nim produce)."""
+    host = _lib.load_host()
+    nc, na, ne = grid.data.shape
+    angles = np.linspace(grid.angle_min, grid.angle_max, na)
+    energies = np.linspace(grid.energy_min, grid.energy_max, ne)
+    _lib.check(host.sart_host_h5_write_reflectivity(path.encode(), nc, na, ne, _lib.as_dp(angles), _lib.as_dp(energies),
+                                                    _lib.as_dp(np.ascontiguousarray(grid.data))), host=True)
+
+
 def analytic_reflectivity_grid(n_coatings: int = 1, n_angles: int = 1000, n_energies: int = 1000) -> ReflectivityGrid:
     """G2 (stress): R = exp(-alpha / 0.5 deg) * exp(-E / 10 keV)."""
     angles = np.linspace(0.0, 1.5, n_angles)[:, None]

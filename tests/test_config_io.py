@@ -1,0 +1,131 @@
+"""the reference's config / file surface on the host side (TOML keys of config_default.toml,
+HDF5 reflectivity schema, solar-model CSV)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from solaraxionraytracing_amd import _lib as L, config, tables
+
+# same sections and keys as config/config_default.toml:1-50 (values differ: CAST/LLNL with the magnet block enabled)
+SAMPLE = """
+[Resources]
+resourcePath   = "res"
+outputPath     = "out"
+llnlEfficiency = "llnl_xray_telescope_cast_effective_area_parallel_light_DTU_thesis.csv"
+goldFilePrefix = "henke_download/"
+rawSolarModel  = "AGSS09_solar_model_stripped.dat"
+solarModelFile = "solar_model_dataframe.csv"
+llnlReflFile   = "llnl_layer_reflectivities.h5"
+goldReflFile   = "gold_0.25microns_reflectivities.h5"
+
+[ReadOpacityFile]
+solarModelFile = "solar_model_dataframe.csv"
+opcdPath       = "OPCD"
+
+[Setup]
+experimentSetup = "CAST"
+detectorSetup   = "InGrid2018"
+stageSetup      = "vacuum"
+telescopeSetup  = "LLNL"
+
+[Magnet]
+useConfig = true
+B = 8.5
+radiusCB = 21.0
+lengthColdbore = 9756.0
+lengthB = 9260.0
+pGasRoom = 1.0
+tGas = 1.7
+
+[TestXraySource]
+useConfig = false
+active = true
+parallel = false
+energy = 1.0
+distance = 2000.0
+radius = 350.0
+offAxisUp = 0.0
+offAxisLeft = 0.0
+activity = 0.125
+lengthCol = 0.021
+
+[DetectorInstallation]
+useConfig = false
+distanceDetectorXRT = 1485.0
+distanceWindowFocalPlane = 0.0
+lateralShift = 0.0
+transversalShift = 0.0
+"""
+
+
+def _h5_available():
+    try:
+        tables.write_reflectivity_h5("/tmp/_sart_probe.h5", tables.analytic_reflectivity_grid(1, 4, 4))
+        return True
+    except L.SartError:
+        return False
+
+
+def test_config_toml_drives_init_full_setup(tmp_path):
+    cfgdir = tmp_path / "config"
+    cfgdir.mkdir()
+    (tmp_path / "config" / "res").mkdir()
+    p = cfgdir / "config.toml"
+    p.write_text(SAMPLE)
+    full = config.init_full_setup_from_config(str(p), n_radii=60, n_energies=50, refl_n_angles=30, refl_n_energies=30)
+    s = full.setup
+    assert (s.experiment, s.telescope_kind, s.detector_kind, s.stage) == (L.ES_CAST, L.TK_LLNL, L.DK_INGRID2018, L.SK_VACUUM)
+    assert (s.magnet_B, s.magnet_radiusCB) == (8.5, 21.0)            # [Magnet] useConfig = true (raytracer.nim:1040)
+    assert s.test_active == 0 and s.distance_detector_xrt == 1485.0
+    assert len(full.meta["notes"]) == 2 and full.reflectivity.data.shape[0] == 4   # files absent -> synthetic stand-ins
+    # --magnet / --detectorInstall / --xrayTest flags force the blocks (raytracer.nim:1040, 1061, 1086)
+    fl = config.flags_from_cli(xrayTest=True, detectorInstall=True)
+    assert fl == L.CF_XRAY_TEST | L.CF_READ_DET_INSTALL_CONFIG
+    full2 = config.init_full_setup_from_config(str(p), fl, n_radii=60, n_energies=50, refl_n_angles=30, refl_n_energies=30)
+    assert full2.setup.test_active == 1 and full2.setup.test_parallel == 0 and full2.setup.test_length_col == 0.021
+    # bad enum -> ValueError like parseEnum (:1027)
+    p.write_text(SAMPLE.replace('"LLNL"', '"Chandra"'))
+    with pytest.raises(ValueError):
+        config.init_full_setup_from_config(str(p))
+
+
+@pytest.mark.skipif(not _h5_available(), reason="libhdf5 not loadable")
+def test_h5_reflectivity_roundtrip_and_schema(tmp_path):
+    g = tables.llnl_reflectivity_grids(37, 29)
+    path = str(tmp_path / "llnl_layer_reflectivities.h5")
+    tables.write_reflectivity_h5(path, g)
+    r = tables.read_reflectivity_h5(path)
+    np.testing.assert_array_equal(r.data, g.data)
+    assert (r.angle_min, r.angle_max, r.energy_min, r.energy_max) == (0.0, 1.5, 0.03, 15.0)
+    if os.path.exists("/opt/conda/bin/h5dump"):
+        hdr = subprocess.run(["/opt/conda/bin/h5dump", "-H", path], capture_output=True, text=True).stdout
+        # datasets of tools/llnl_layer_reflectivity.nim:62-80: (nE,1), (nA,1), Reflectivity0..3 declared (nE, nA)
+        for name in ("Energy", "Angles", "Reflectivity0", "Reflectivity3"):
+            assert 'DATASET "%s"' % name in hdr
+        assert "( 29, 37 )" in hdr and "( 37, 1 )" in hdr and "( 29, 1 )" in hdr
+    single = tables.gold_reflectivity_grid(11, 13)
+    path2 = str(tmp_path / "gold_0.25microns_reflectivities.h5")
+    tables.write_reflectivity_h5(path2, single)
+    assert tables.read_reflectivity_h5(path2).data.shape == (1, 11, 13)
+    with pytest.raises(L.SartError):
+        tables.read_reflectivity_h5(str(tmp_path / "missing.h5"))
+
+
+@pytest.mark.skipif(not _h5_available(), reason="libhdf5 not loadable")
+def test_config_picks_up_real_files_when_present(tmp_path):
+    cfgdir = tmp_path / "config"
+    res = cfgdir / "res"
+    res.mkdir(parents=True)
+    (cfgdir / "config.toml").write_text(SAMPLE.replace("useConfig = true", "useConfig = false"))
+    tables.write_reflectivity_h5(str(res / "llnl_layer_reflectivities.h5"), tables.analytic_reflectivity_grid(4, 20, 16))
+    radii, energies = tables.solar_grid(12, 9)
+    with open(res / "solar_model_dataframe.csv", "w") as f:
+        f.write("Radius,Energy [keV],emRates\n")
+        for r_ in radii:
+            for e in energies:
+                f.write("%s,%s,%s\n" % (repr(float(r_)), repr(float(e)), repr(float(1.0 + e))))
+    full = config.init_full_setup_from_config(str(cfgdir / "config.toml"))
+    assert full.meta["notes"] == [] and full.diffFluxCDFs.shape == (12, 9) and full.reflectivity.data.shape == (4, 20, 16)
+    assert full.setup.magnet_B == 9.0
