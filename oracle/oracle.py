@@ -27,9 +27,12 @@ class OracleTables(C.Structure):
     ]
 
 
+_TARGETS = {"f64": "libsart_oracle.so", "ld": "libsart_oracle_ld.so", "q": "libsart_oracle_q.so"}
+
+
 def build(variant: str = "f64") -> str:
     """Compiles the oracle with gcc if needed; returns the library path."""
-    target = {"f64": "libsart_oracle.so", "ld": "libsart_oracle_ld.so"}[variant]
+    target = _TARGETS[variant]
     subprocess.run(["make", "-s", "-C", _DIR, target], check=True)
     return os.path.join(_DIR, target)
 
@@ -39,7 +42,7 @@ _libs = {}
 
 def load(variant: str = "f64") -> C.CDLL:
     if variant not in _libs:
-        path = os.path.join(_DIR, {"f64": "libsart_oracle.so", "ld": "libsart_oracle_ld.so"}[variant])
+        path = os.path.join(_DIR, _TARGETS[variant])
         if not os.path.exists(path):
             build(variant)
         lib = C.CDLL(path)

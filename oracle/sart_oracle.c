@@ -38,7 +38,11 @@
  * 80-bit long double: a DIAGNOSTIC variant used by tests to measure how much of a difference between
  * two f64 implementations is rounding noise of the reference's formulation (it subtracts points of
  * magnitude 1e11..1.5e14 mm) rather than a different algorithm. */
-#ifdef SART_ORACLE_LONG_DOUBLE
+#if defined(SART_ORACLE_QUAD)
+#include <quadmath.h>
+typedef __float128 real;   /* second diagnostic variant: IEEE binary128 (libquadmath), 113-bit mantissa */
+#define M_(f) f##q
+#elif defined(SART_ORACLE_LONG_DOUBLE)
 typedef long double real;
 #define M_(f) f##l
 #else

@@ -7,6 +7,8 @@ Two oracles are used (oracle/sart_oracle.c built twice from one source):
           focal plane.  HIP-vs-f64 differences are bounded by that envelope (tolerances below).
  * ld   — the same source in 80-bit long double, 2048x less of that noise.  HIP-vs-ld shows that what remains is
           not an algorithmic difference: positions agree to 5e-6 mm, weights to 1e-6 relative.
+ * q    — the same source in IEEE binary128: HIP agrees to 1e-10 mm / 2e-8 relative with identical decisions for every
+          ray, i.e. the HIP path evaluates the reference's algorithm more accurately than its own f64 formulation does.
 """
 import ctypes as C
 
@@ -70,6 +72,26 @@ def test_records_match_long_double_oracle_tightly(name):
     np.testing.assert_array_equal(rec["kinds"], ref["kinds"])
     np.testing.assert_allclose(rec["transProbArgon"], ref["transProbArgon"], rtol=1e-13)
     np.testing.assert_array_equal(rec["pixvalsX"], ref["pixvalsX"])
+
+
+@pytest.mark.parametrize("name", SETUP_NAMES)
+def test_records_match_binary128_oracle(name):
+    """Third build of the same oracle source in IEEE binary128 (libquadmath): no rounding noise left in the
+    reference's formulation.  Every decision of every ray is identical and positions agree to 1e-10 mm — what differs
+    between the HIP path and the f64 reference is the reference's own rounding."""
+    from oracle.oracle import Oracle
+    full = make_setup(name)
+    n = 40_000
+    with sa.RayTracer(full) as rt:
+        rec = rt.traceAxionWrapper(n, seed=44)
+    ref = Oracle(full, "q").trace_records(n, seed=44)
+    for f in ("passed", "passedTillWindow", "hitNickel", "shellNumber", "kinds", "kindsWindow"):
+        np.testing.assert_array_equal(rec[f], ref[f])
+    m = rec["passedTillWindow"] == 1
+    for f in ("pointdataX", "pointdataY", "pointdataR", "pointdataXBefore", "pointdataYBefore", "deviationDet", "yawAngles"):
+        assert np.abs(rec[f] - ref[f]).max(initial=0.0) < 1e-10, f
+    for f in ("weights", "reflect", "transmissionMagnet", "transProbWindow", "energiesAx"):
+        np.testing.assert_allclose(rec[f][m], ref[f][m], rtol=2e-8, atol=0)
 
 
 @pytest.mark.parametrize("name", ["babyiaxo_xmm", "cast_llnl", "cast_abrixas", "babyiaxo_xmm_gas"])
