@@ -171,6 +171,16 @@ __device__ __forceinline__ double cos_small(double x) {
   return cos(x);
 }
 
+// The table pointers of a launch are read from the LDS copy of the parameter blob, where the compiler cannot see
+// their address space and would emit flat_load (which counts on both vmcnt and lgkmcnt and so serialises against the
+// LDS traffic of the same wave).  They always point to global memory: say so.
+template <typename T>
+using global_ptr = const __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ __forceinline__ global_ptr<T> as_global(const T* p) {
+  return (global_ptr<T>)p;
+}
+
 // lowerBound(a, key) with the answer known to lie in [lo, hi] (guide-table bracket):
 // first index i with a[i] >= key  (std/algorithm.lowerBound semantics).
 template <typename Ptr>
@@ -262,11 +272,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Energy index drawn with u5 from the CDF row of the sampled radius (getRandomEnergyFromSolarModel, :444-471).
 __device__ __forceinline__ int sample_energy_index(const DevParams& P, const DevTables& T, int r_idx, double u5) {
-  const double* row = T.diff_flux_cdfs + (size_t)r_idx * (size_t)P.n_energies;
-  const uint16_t* g = T.energy_guide + (size_t)r_idx * (size_t)(kEnergyGuide + 1);
+  const auto row = as_global(T.diff_flux_cdfs) + (size_t)r_idx * (size_t)P.n_energies;
+  const auto g = as_global(T.energy_guide) + (size_t)r_idx * (size_t)(kEnergyGuide + 1);
   const int k = (int)(u5 * (double)kEnergyGuide);
   const int idx = lower_bound_bracket(row, (int)g[k], (int)g[k + 1], u5);
   return min(idx, P.n_energies - 1);
+}
+
+static_assert(sizeof(EnergyDev) == 8 * sizeof(double), "EnergyDev is loaded as eight f64");
+__device__ __forceinline__ EnergyDev load_energy_row(const DevTables& T, int e_idx) {
+  const auto p = as_global(reinterpret_cast<const double*>(T.energy_tab)) + (size_t)e_idx * 8;
+  return EnergyDev{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
 }
 
 // cos(n phi) from c = cos(phi): Chebyshev T16 (four doublings) or T6 = T2(T3).
@@ -595,7 +611,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
 
   // ---- weights (:2116-2128) ----
   const int e_idx = (e_idx_in >= 0) ? e_idx_in : sample_energy_index(P, T, st.r_idx, st.u5);
-  const EnergyDev en = T.energy_tab[e_idx];
+  const EnergyDev en = load_energy_row(T, e_idx);
   const double path_cb = st.path_cb;
   double trans_magnet;
   {
@@ -622,7 +638,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   if (!(flags & SART_CF_IGNORE_REFLECTION)) {
     // computeReflectivity (:1533-1580): bilinear in (angle, energy); the energy interpolation is folded
     // into the per-energy-index table, leaving a linear interpolation in the angle.
-    const double* tab = T.refl + ((size_t)sh.coating * (size_t)(P.n_energies + 1) + (size_t)e_idx) * (size_t)P.refl_n_angles;
+    const auto tab = as_global(T.refl) + ((size_t)sh.coating * (size_t)(P.n_energies + 1) + (size_t)e_idx) * (size_t)P.refl_n_angles;
     const int na2 = P.refl_n_angles - 2;
     const double amin = P.refl_angle_min, inv_da = P.refl_inv_dangle, da = P.refl_dangle;
     auto refl_at = [&](double sin2a) {
@@ -721,15 +737,15 @@ struct __align__(16) QueueLds {
 
 template <int BLOCK>
 __device__ __forceinline__ void stage_tables(TablesLds& S, const DevParams& P, const DevTables& T) {
-  for (int i = threadIdx.x; i < P.n_radii; i += BLOCK) S.rcdf[i] = T.flux_radius_cdf[i];
-  for (int i = threadIdx.x; i <= kRadiusGuide; i += BLOCK) S.rguide[i] = T.radius_guide[i];
+  for (int i = threadIdx.x; i < P.n_radii; i += BLOCK) S.rcdf[i] = as_global(T.flux_radius_cdf)[i];
+  for (int i = threadIdx.x; i <= kRadiusGuide; i += BLOCK) S.rguide[i] = as_global(T.radius_guide)[i];
   {
-    const uint64_t* src = reinterpret_cast<const uint64_t*>(T.shells);
+    const auto src = as_global(reinterpret_cast<const uint64_t*>(T.shells));
     uint64_t* dst = reinterpret_cast<uint64_t*>(S.shells);
     const int n = P.n_shells * (int)(sizeof(ShellDev) / 8);
     for (int i = threadIdx.x; i < n; i += BLOCK) dst[i] = src[i];
   }
-  for (int i = threadIdx.x; i < P.lut_n; i += BLOCK) S.lut[i] = T.shell_lut[i];
+  for (int i = threadIdx.x; i < P.lut_n; i += BLOCK) S.lut[i] = as_global(T.shell_lut)[i];
   __syncthreads();
 }
 
@@ -993,7 +1009,7 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
     if (sampled) {
       e_idx = H.test_active ? P.n_energies : sample_energy_index(P, T, st.r_idx, st.u5);
       rec.emratesPre = 1.0;                          // :1818
-      rec.energiesPre = T.energy_tab[e_idx].energy;  // :1819
+      rec.energiesPre = load_energy_row(T, e_idx).energy;  // :1819
     }
     if (__ballot(alive)) {
       RayOut ro;
