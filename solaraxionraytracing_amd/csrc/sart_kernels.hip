@@ -218,15 +218,18 @@ __device__ __forceinline__ double reflect(double& wx, double& wy, double& wz, do
   const double rnl = frcp(N2 * L);           // one reciprocal for both 1/N2 and 1/(N2 L)
   const double c2 = dnw * dnw * rnl;
   const double f = dnw * (L * rnl);
-  if (dnw >= 0.0) {
-    wx = fma(-2.0 * f, nx, wx);
-    wy = fma(-2.0 * f, ny, wy);
-    wz = fma(-2.0 * f, nz, wz);
-  } else {  // normal facing the ray: the reference's formula is then not a mirror reflection; keep it
+  const double ox = wx, oy = wy, oz = wz;
+  wx = fma(-2.0 * f, nx, ox);                // mirror reflection (normal on the far side of the ray: n.w >= 0)
+  wy = fma(-2.0 * f, ny, oy);
+  wz = fma(-2.0 * f, nz, oz);
+  if (__ballot(dnw < 0.0)) {                 // wave-uniform; practically never taken
+    // normal facing the ray: the reference's formula is then not a mirror reflection; keep it
     const double k = 1.0 - 4.0 * c2;
-    wx = fma(2.0 * f, nx, k * wx);
-    wy = fma(2.0 * f, ny, k * wy);
-    wz = fma(2.0 * f, nz, k * wz);
+    if (dnw < 0.0) {
+      wx = fma(2.0 * f, nx, k * ox);
+      wy = fma(2.0 * f, ny, k * oy);
+      wz = fma(2.0 * f, nz, k * oz);
+    }
   }
   return c2;
 }
@@ -563,8 +566,10 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   // tan(a1) > num / (l - z1)  <=>  sin^2(a1) ((l - z1)^2 + num^2) > num^2   (num >= 0, l - z1 > 0)
   {
     const double lz = P.l_mirror - z1, num = sh.nickel_num;
-    const bool nick = (lz > 0.0) ? (sin2_a1 * fma(lz, lz, num * num) > num * num)
-                                 : (fsqrt(sin2_a1 / (1.0 - sin2_a1)) > num / lz);
+    bool nick = sin2_a1 * fma(lz, lz, num * num) > num * num;
+    if (__ballot(!(lz > 0.0))) {               // wave-uniform; only for a missed mirror with z1 >= l (never in practice)
+      if (!(lz > 0.0)) nick = fsqrt(sin2_a1 / (1.0 - sin2_a1)) > num / lz;
+    }
     out.hit_nickel = live && (st.shell > 0) && nick;
   }
   if (RECORDS && out.hit_nickel) rec->hitNickel = 1;
@@ -644,9 +649,9 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     auto refl_at = [&](double sin2a) {
       const double alpha = asin_small(fsqrt(sin2a)) * 57.29577951308232;   // getMirrorAngle (:782-795), degrees
       const double t = (alpha - amin) * inv_da;
-      int i = (int)floor(t);          // NaN -> 0
+      int i = (int)t;                 // = floor(t) for t >= 0; negative or NaN t ends in cell 0 through the clamp
       i = max(min(i, na2), 0);
-      const double xu = (alpha - (amin + (double)i * da)) * inv_da;
+      const double xu = (alpha - fma((double)i, da, amin)) * inv_da;
       const double g0 = tab[i], g1 = tab[i + 1];
       return fma(xu, g1 - g0, g0);
     };
