@@ -293,3 +293,37 @@ def test_bench_two_rank_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["total_rays"] == 2 * 3 * 2e7 and d["scaling"] == "weak"
     assert d["results"]["passed_fraction"] == pytest.approx(0.2144, abs=2e-3)
     assert d["value"] > 1e9
+
+
+def test_early_rejection_stage_is_exact():
+    """Stage A0 (rays classified from the bore-exit radius alone) must not change any counter or the image: same
+    launch with the stage switched off (SART_NO_EARLY_REJECT, read when a context uploads its parameter block)."""
+    import os
+    full = sa.initFullSetup()            # full-size BabyIAXO / XMM tables: the configuration the stage exists for
+    n = 20_000_000
+    with sa.RayTracer(full) as rt:
+        img_a, s_a = rt.trace_histogram(n, seed=17)
+    os.environ["SART_NO_EARLY_REJECT"] = "1"
+    try:
+        with sa.RayTracer(full) as rt:
+            img_b, s_b = rt.trace_histogram(n, seed=17)
+    finally:
+        del os.environ["SART_NO_EARLY_REJECT"]
+    for k in ("N_RAYS", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW", "N_PASSED", "N_OUTSIDE_IMAGE"):
+        assert s_a[k] == s_b[k], k
+    assert s_a["N_REACHED_TELESCOPE"] / n == pytest.approx(0.5475, abs=1e-3)
+    np.testing.assert_allclose(img_a, img_b, rtol=1e-10, atol=img_b.max() * 1e-14)
+    assert s_a["SUM_WEIGHTS"] == pytest.approx(s_b["SUM_WEIGHTS"], rel=1e-12)
+
+
+def test_launch_splitting_beyond_32bit_ray_indices():
+    """One call with more than 2^31 rays is split into launches internally; ray ids continue across the split."""
+    full = make_setup("babyiaxo_xmm")
+    n = (1 << 31) + 12_345
+    with sa.RayTracer(full) as rt:
+        _, s = rt.trace_histogram(n, seed=2)
+        _, s1 = rt.trace_histogram(1 << 31, seed=2)
+        _, s2 = rt.trace_histogram(12_345, seed=2, ray_id_offset=1 << 31, accumulate=True)
+    assert s["N_RAYS"] == n == s2["N_RAYS"]
+    for k in ("N_PASSED", "N_HIT_NICKEL", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED"):
+        assert s[k] == s2[k], k
