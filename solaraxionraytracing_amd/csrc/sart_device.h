@@ -18,7 +18,7 @@ namespace sart {
 constexpr int kMaxShells = 64;
 constexpr int kMaxStrips = 16;       // half the number of window strips that are looped over
 constexpr int kRadiusGuide = 2048;   // buckets of the guide table in front of fluxRadiusCDF
-constexpr int kEnergyGuide = 256;    // buckets per radius row in front of diffFluxCDFs
+constexpr int kEnergyGuide = 2048;    // buckets per radius row in front of diffFluxCDFs
 constexpr int kShellLutMax = 1024;   // cells of the radial look-up table of the shell selection
 constexpr int kMaxRadii = 2048;      // fluxRadiusCDF entries that fit the LDS stage
 
