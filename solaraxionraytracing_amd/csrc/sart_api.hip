@@ -453,6 +453,7 @@ HotA hot_of(const DevParams& P) {
 void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h) {
   h.n_zones = 0;
   h.zone_reached = 0;
+  for (int z = 0; z < kMaxZones; ++z) { h.zone_lo[z] = 1u; h.zone_hi[z] = 0u; }   // empty
   if (P.test_active || P.rotated || n_radii < 1) return;
   const double R = P.radius_cb;
   const double r_sun_max = (0.0015 + (n_radii - 1) * 0.0005) * P.sun_radius;

@@ -892,7 +892,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const U4 b1 = philox4x32_10((uint32_t)ray_id, (uint32_t)(ray_id >> 32), 1u, 0u, A.seed_lo, A.seed_hi);
         const uint32_t w = b1.z;
         bool dead = false, dead_reached = false;
-        for (int z = 0; z < H.n_zones; ++z) {
+#pragma unroll
+        for (int z = 0; z < kMaxZones; ++z) {   // fully unrolled: the zone bounds stay in SGPRs (unused zones are empty: lo > hi)
           const bool in = (w >= H.zone_lo[z]) && (w <= H.zone_hi[z]);
           dead = dead || in;
           dead_reached = dead_reached || (in && ((H.zone_reached >> z) & 1u));

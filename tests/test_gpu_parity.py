@@ -327,3 +327,27 @@ def test_launch_splitting_beyond_32bit_ray_indices():
     assert s["N_RAYS"] == n == s2["N_RAYS"]
     for k in ("N_PASSED", "N_HIT_NICKEL", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED"):
         assert s[k] == s2[k], k
+
+
+@pytest.mark.parametrize("kw", [dict(emission="flat", reflectivity="analytic"),
+                                dict(emission="flat", reflectivity="henke", n_radii=2048, n_energies=700),
+                                dict(emission="primakoff", reflectivity="analytic", n_radii=9, n_energies=2, refl_n_angles=2, refl_n_energies=2)])
+def test_other_table_shapes_against_binary128_oracle(kw):
+    """Stress inputs of SURVEY 8(d): flat emission (E3: wide guide brackets, every energy equally likely), analytic
+    reflectivity (G2), the largest radius table the LDS stage takes (2048) and degenerate tiny tables."""
+    from oracle.oracle import Oracle
+    args = dict(n_radii=300, n_energies=200, refl_n_angles=64, refl_n_energies=48)
+    args.update(kw)
+    for full in (sa.initFullSetup(**args), sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, **args)):
+        n = 30_000
+        with sa.RayTracer(full) as rt:
+            rec = rt.traceAxionWrapper(n, seed=3)
+            img, s = rt.trace_histogram(n, seed=3)
+        ref = Oracle(full, "q").trace_records(n, seed=3)
+        for f in ("passed", "passedTillWindow", "hitNickel", "shellNumber", "kindsWindow"):
+            np.testing.assert_array_equal(rec[f], ref[f])
+        np.testing.assert_array_equal(rec["energiesPre"], ref["energiesPre"])
+        m = rec["passed"] == 1
+        assert np.abs(rec["pointdataX"] - ref["pointdataX"]).max(initial=0.0) < 1e-10
+        np.testing.assert_allclose(rec["weights"][m], ref["weights"][m], rtol=2e-8)
+        assert s["N_PASSED"] == m.sum() and s["SUM_WEIGHTS"] == pytest.approx(rec["weights"][m].sum(), rel=1e-12)
