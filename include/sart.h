@@ -314,6 +314,17 @@ int sart_trace_histogram(sart_context* ctx, const sart_trace_params_t* params,
 int sart_trace_histogram_spectra(sart_context* ctx, const sart_trace_params_t* params, double* image_out_host,
                                  sart_summary_t* summary_out, double* spectra_out_host);
 
+/* ---- multi-GPU ---------------------------------------------------------- */
+/*
+ * Sum the fused accumulators of n contexts (one per GPU of this process) into the one of contexts[root]:
+ * a single RCCL ncclReduce(ncclSum, f64) of n_doubles elements over xGMI (grouped over the devices).
+ * accumulators_device[i] must live on the device of contexts[i].  Blocking.  n == 1 is a no-op.
+ * A host that runs one process per GPU (e.g. under MPI / torchrun) reduces with its own communicator instead
+ * (bench.py: torch.distributed, backend "nccl" = RCCL).  Returns SART_ERR_UNSUPPORTED if librccl cannot be loaded.
+ */
+int sart_reduce_across_devices(sart_context* const* contexts, double* const* accumulators_device, int32_t n,
+                               size_t n_doubles, int32_t root);
+
 /* ---- measurement -------------------------------------------------------- */
 /*
  * HIP-event timing of the hot-path kernels on the stream they are launched on.

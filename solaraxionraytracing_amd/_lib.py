@@ -150,6 +150,7 @@ SART_SYMBOLS = {
     "sart_trace_histogram_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p]),
     "sart_trace_histogram": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _P(Summary)]),
     "sart_trace_histogram_spectra": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _P(Summary), _dp]),
+    "sart_reduce_across_devices": (C.c_int, [_P(C.c_void_p), _P(C.c_void_p), _i, C.c_size_t, _i]),
     "sart_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "sart_get_kernel_timing": (C.c_int, [C.c_void_p, _dp, _P(C.c_int64)]),
     "sart_device_info": (C.c_int, [C.c_void_p, _P(_i), _P(_i), C.c_char_p, C.c_size_t]),

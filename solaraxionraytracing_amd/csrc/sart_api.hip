@@ -4,6 +4,7 @@
 // There is NO CPU fallback in this library: without a HIP device sart_create() fails with
 // SART_ERR_NO_DEVICE, and nothing here links or loads oracle/.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -850,6 +851,72 @@ int sart_trace_histogram_spectra(sart_context* c, const sart_trace_params_t* p, 
     SART_HIP(hipMemcpyAsync(spectra_out, c->d_acc.p + nimg + SART_ACC_COUNT, (len - nimg - SART_ACC_COUNT) * sizeof(double),
                             hipMemcpyDeviceToHost, c->stream));
   SART_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// RCCL through dlopen (the library is only needed by hosts that drive several GPUs from one process)
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  int (*CommInitAll)(void**, int, const int*) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  static Rccl& get() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", nullptr};
+    for (int i = 0; names[i] && !r.lib; ++i) r.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+    if (!r.lib) return r;
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.lib, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.Reduce = reinterpret_cast<decltype(r.Reduce)>(dlsym(r.lib, "ncclReduce"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.lib, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.lib, "ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    r.ok = r.CommInitAll && r.CommDestroy && r.Reduce && r.GroupStart && r.GroupEnd && r.GetErrorString;
+    return r;
+  }
+};
+}  // namespace
+
+int sart_reduce_across_devices(sart_context* const* ctxs, double* const* accs, int32_t n, size_t n_doubles, int32_t root) {
+  if (!ctxs || !accs || n < 1 || root < 0 || root >= n) return fail(SART_ERR_INVALID_ARGUMENT, "sart_reduce_across_devices: bad argument");
+  for (int i = 0; i < n; ++i) {
+    if (!ctxs[i] || !accs[i]) return fail(SART_ERR_INVALID_ARGUMENT, "NULL context / accumulator");
+    for (int j = 0; j < i; ++j)
+      if (ctxs[j]->device == ctxs[i]->device) return fail(SART_ERR_INVALID_ARGUMENT, "contexts must be on distinct devices");
+  }
+  for (int i = 0; i < n; ++i) {   // everything queued so far must be visible to the collective
+    SART_HIP(hipSetDevice(ctxs[i]->device));
+    SART_HIP(hipStreamSynchronize(ctxs[i]->stream));
+  }
+  if (n == 1) return 0;
+  Rccl& r = Rccl::get();
+  if (!r.ok) return fail(SART_ERR_UNSUPPORTED, "librccl could not be loaded");
+  std::vector<void*> comms(n, nullptr);
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+  int rc = r.CommInitAll(comms.data(), n, devs.data());
+  if (rc != 0) return fail(SART_ERR_INTERNAL, std::string("ncclCommInitAll: ") + r.GetErrorString(rc));
+  rc = r.GroupStart();
+  for (int i = 0; i < n && rc == 0; ++i) {
+    if (hipSetDevice(ctxs[i]->device) != hipSuccess) { rc = -1; break; }
+    rc = r.Reduce(accs[i], accs[i], n_doubles, 8 /* ncclDouble (ncclFloat64) */, 0 /* ncclSum */, root, comms[i], ctxs[i]->stream);
+  }
+  const int rc_end = r.GroupEnd();
+  if (rc == 0) rc = rc_end;
+  for (int i = 0; i < n; ++i) {
+    (void)hipSetDevice(ctxs[i]->device);
+    (void)hipStreamSynchronize(ctxs[i]->stream);
+    r.CommDestroy(comms[i]);
+  }
+  if (rc != 0) return fail(SART_ERR_INTERNAL, std::string("ncclReduce: ") + (rc > 0 ? r.GetErrorString(rc) : "hipSetDevice failed"));
   return 0;
 }
 

@@ -351,3 +351,24 @@ def test_other_table_shapes_against_binary128_oracle(kw):
         assert np.abs(rec["pointdataX"] - ref["pointdataX"]).max(initial=0.0) < 1e-10
         np.testing.assert_allclose(rec["weights"][m], ref["weights"][m], rtol=2e-8)
         assert s["N_PASSED"] == m.sum() and s["SUM_WEIGHTS"] == pytest.approx(rec["weights"][m].sum(), rel=1e-12)
+
+
+def test_reduce_across_devices_single_process_entry_point():
+    """sart_reduce_across_devices: argument checking and the n == 1 path run here; the n > 1 RCCL
+    path needs several GPUs in one process (one-GPU box: not exercised) — bench.py's per-process reduce is."""
+    full = make_setup("babyiaxo_xmm")
+    lib = L.load_sart()
+    import torch
+    with sa.RayTracer(full) as rt:
+        acc = torch.zeros(sa.accumulator_len(256), dtype=torch.float64, device="cuda")
+        p = rt.trace_params(50_000, seed=1)
+        rt.trace_histogram_device(p, acc.data_ptr())
+        ctxs = (C.c_void_p * 1)(rt.handle)
+        accs = (C.c_void_p * 1)(acc.data_ptr())
+        assert lib.sart_reduce_across_devices(ctxs, accs, 1, acc.numel(), 0) == 0     # also synchronises the stream
+        assert acc[256 * 256 + L.ACC["N_RAYS"]].item() == 50_000
+        assert lib.sart_reduce_across_devices(ctxs, accs, 1, acc.numel(), 3) == -1    # root out of range
+        two = (C.c_void_p * 2)(rt.handle, rt.handle)
+        accs2 = (C.c_void_p * 2)(acc.data_ptr(), acc.data_ptr())
+        assert lib.sart_reduce_across_devices(two, accs2, 2, acc.numel(), 0) == -1    # same device twice
+        assert b"distinct devices" in lib.sart_last_error()
