@@ -176,14 +176,36 @@ def main():
         dist.destroy_process_group()
 
 
+def available_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes give a
+    container a share of the host's hardware threads)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:     # cgroup v1
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(full, n_sample: int, seed: int):
     """The CPU oracle (restatement of the Nim path; the Nim binary cannot be built) timed on this host's cores on a
     bounded sample of the same workload."""
     from oracle.oracle import Oracle
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores = available_cpus()
     o = Oracle(full)
     o.trace_histogram(200_000, seed=seed, n_threads=cores)   # warm up threads / page in tables
     t0 = time.perf_counter()
