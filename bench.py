@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rays-per-step", type=float, default=1e9, help="rays per step and GPU (one BabyIAXO image of BASELINE configs[2])")
     ap.add_argument("--workload", default="babyiaxo_xmm", choices=["babyiaxo_xmm", "cast_llnl_gold"])
-    ap.add_argument("--cpu-sample", type=float, default=3e8, help="rays of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=float, default=6e8, help="rays of the CPU-baseline sample")
     ap.add_argument("--profile-run", action="store_true", help="no CPU baseline (run under rocprofv3)")
     ap.add_argument("--traffic-bytes-per-launch", type=float, default=None,
                     help="fabric bytes per launch from a separate rocprofv3 --pmc pass; default: profiles/pmc_traffic.json "
