@@ -19,13 +19,14 @@
 
 namespace sart {
 void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
-                            hipStream_t stream, bool fast);
+                            hipStream_t stream, int variant);
+int histogram_block_of(int variant);
 void launch_trace_records(const HotA& H, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream);
 void set_histogram_block(int block);
 int histogram_block();
 int records_block();
-int histogram_blocks_per_cu(int block, bool fast);
+int histogram_blocks_per_cu(int variant);
 }  // namespace sart
 
 using namespace sart;
@@ -93,7 +94,8 @@ size_t lower_bound_idx(const double* a, size_t n, double key) {
 struct sart_context {
   int device = 0;
   int n_cu = 0;
-  int blocks_per_cu_hist = 0, blocks_per_cu_rec = 0;
+  int blocks_per_cu_hist[3] = {0, 0, 0}, blocks_per_cu_rec = 0;
+  bool env_read = false;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string device_name;
@@ -455,7 +457,7 @@ void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h
   h.n_zones = 0;
   h.zone_reached = 0;
   for (int z = 0; z < kMaxZones; ++z) { h.zone_lo[z] = 1u; h.zone_hi[z] = 0u; }   // empty
-  if (P.test_active || P.rotated || n_radii < 1) return;
+  if (P.test_active || n_radii < 1) return;   // the bound on |slope| holds for rays from the Sun only
   const double R = P.radius_cb;
   const double r_sun_max = (0.0015 + (n_radii - 1) * 0.0005) * P.sun_radius;
   const double s_max = (r_sun_max + R) / (P.sun_distance + P.length_b - r_sun_max) * (1.0 + 1e-6);
@@ -472,7 +474,8 @@ void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h
   struct Z { double lo, hi; bool reached; };
   std::vector<Z> zones;
   if (K_dead < R) zones.push_back({K_dead, 1e300, false});
-  const bool on_axis = (P.entrance_x == 0.0 && P.entrance_y == 0.0);
+  // zones in terms of the radial distance at the telescope entrance need the telescope on the magnet axis
+  const bool on_axis = (P.entrance_x == 0.0 && P.entrance_y == 0.0) && !P.rotated;
   if (on_axis && K_in > 0) {
     auto add_reached = [&](double lo, double hi) {   // radial in [lo, hi] certainly => blocked; clip to r <= K_in
       hi = std::min(hi, K_in);
@@ -803,12 +806,21 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
       a.replica_mask = 0u;
     }
   }
-  if (c->blocks_per_cu_hist == 0) {
+  // kernel variant: 0 = specialised for the common configuration (solar source, telescope not rotated, vacuum, no
+  // hole loop); 1 = generic, not rotated; 2 = generic, rotated
+  const DevParams& P = c->params;
+  const bool fast = !P.test_active && !P.rotated && !P.stage_gas && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) &&
+                    !std::getenv("SART_FORCE_GENERIC");
+  const int variant = fast ? 0 : (P.rotated ? 2 : 1);
+  if (!c->env_read) {
     if (const char* e = std::getenv("SART_HIST_BLOCK")) set_histogram_block(std::atoi(e));   // tuning knob
-    c->blocks_per_cu_hist = std::max(1, histogram_blocks_per_cu(histogram_block(), true));
-    if (const char* e = std::getenv("SART_HIST_BLOCKS_PER_CU")) c->blocks_per_cu_hist = std::max(1, std::atoi(e));
+    c->env_read = true;
   }
-  const int n_blocks = grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_hist, histogram_block());
+  if (c->blocks_per_cu_hist[variant] == 0) {
+    c->blocks_per_cu_hist[variant] = std::max(1, histogram_blocks_per_cu(variant));
+    if (const char* e = std::getenv("SART_HIST_BLOCKS_PER_CU")) c->blocks_per_cu_hist[variant] = std::max(1, std::atoi(e));
+  }
+  const int n_blocks = grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_hist[variant], histogram_block_of(variant));
   if (c->d_partials.n < static_cast<size_t>(n_blocks) * SART_ACC_COUNT) {
     SART_HIP(hipStreamSynchronize(c->stream));
     if (int rc = c->d_partials.resize(static_cast<size_t>(c->n_cu) * 16 * SART_ACC_COUNT)) return rc;
@@ -816,12 +828,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   a.partials = c->d_partials.p;
   {
     TimedLaunch tl(c);
-    // specialised instantiation for the common configuration (solar source, telescope not rotated, vacuum,
-    // no hole loop); anything else runs the generic one
-    const DevParams& P = c->params;
-    const bool fast = !P.test_active && !P.rotated && !P.stage_gas && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) &&
-                      !std::getenv("SART_FORCE_GENERIC");
-    launch_trace_histogram(c->hot, c->d_blob.p, a, acc_dev, n_blocks, c->stream, fast);
+    launch_trace_histogram(c->hot, c->d_blob.p, a, acc_dev, n_blocks, c->stream, variant);
   }
   SART_HIP(hipGetLastError());
   return 0;

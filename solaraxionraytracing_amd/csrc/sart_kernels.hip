@@ -313,11 +313,13 @@ __device__ __forceinline__ double cos_n_phi(int n, double c) {
 //
 // FAST = the configuration known at compile time to be: solar source (no X-ray test source), telescope
 // not rotated, no hole loop in the optics.  The generic instantiation reads those switches at run time.
-template <bool FAST>
+// ROT: telescope rotation known at compile time (0 / 1) or read at run time (-1).
+template <bool FAST, int ROT>
 __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const LdsTables& L, uint32_t seed_lo,
                                         uint32_t seed_hi, uint64_t ray_id, RayState& st, bool& sampled, bool& reached) {
+  static_assert(!(FAST && ROT != 0), "FAST implies an unrotated telescope");
   const bool cfg_test = FAST ? false : (H.test_active != 0);
-  const bool cfg_rotated = FAST ? false : (H.rotated != 0);
+  const bool cfg_rotated = (ROT < 0) ? (H.rotated != 0) : (ROT != 0);
   const bool cfg_holes = FAST ? false : (H.telescope_kind == SART_TK_XMM && H.inner_blocks < 0);
   const uint32_t id_lo = (uint32_t)ray_id, id_hi = (uint32_t)(ray_id >> 32);
   const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, seed_lo, seed_hi);
@@ -731,13 +733,13 @@ struct __align__(16) TablesLds {
 };
 
 // per-wave survivor rings (structure of arrays: lane i reads slot (head + i) % 128 -> conflict-free)
-template <int WAVES, bool FAST>
+template <int WAVES, bool ROT>
 struct __align__(16) QueueLds {
   double X0[WAVES][kQueue], Y0[WAVES][kQueue], tsx[WAVES][kQueue], tsy[WAVES][kQueue];
   double path[WAVES][kQueue], u5[WAVES][kQueue];
-  double zcb[FAST ? 1 : WAVES][kQueue];   // z of pointExitCB: constant unless the telescope is rotated
+  double zcb[ROT ? WAVES : 1][kQueue];    // z of pointExitCB: constant unless the telescope is rotated
   int idx[WAVES][kQueue];                 // r_idx | shell << 16
-  uint32_t ray[FAST ? WAVES : 1][kQueue]; // ring 0 (FAST only): launch indices of rays that passed stage A0
+  uint32_t ray[WAVES][kQueue];            // ring 0: launch indices of rays that passed stage A0
 };
 
 template <int BLOCK>
@@ -761,11 +763,13 @@ __device__ __forceinline__ void stage_tables(TablesLds& S, const DevParams& P, c
 //   A1  phase A (full sampling + cuts + shell selection) on full waves of A0 survivors
 //   B   phase B (mirrors + weights + accumulation) on full waves of A1 survivors
 // Ray i of this launch has the global id ray_id_offset + i; n_rays < 2^32 per launch.
-template <int BLOCK, bool FAST>
+// FAST: solar source, vacuum, no hole loop, telescope not rotated (all known at compile time).  ROT: rotated telescope
+// (ring 1 then also carries z of pointExitCB; 768 threads so that the rings still fit the LDS).
+template <int BLOCK, bool FAST, bool ROT>
 __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
                                                                 double* __restrict__ acc) {
   __shared__ TablesLds S;
-  __shared__ QueueLds<BLOCK / 64, FAST> Q;
+  __shared__ QueueLds<BLOCK / 64, ROT> Q;
   // Only the ~20 scalars phase A needs for every ray travel in the kernel arguments (SGPRs); everything
   // else is read from an LDS copy of the parameter blob (broadcast ds_read).  All of them together do not
   // fit the 102 SGPRs of a wave and would be spilled through VGPR lanes (v_readlane = VALU slots).
@@ -787,7 +791,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: scalar addressing of the rings
   const uint64_t waves_total = (uint64_t)gridDim.x * (BLOCK / 64);
   const uint64_t wave_global = (uint64_t)blockIdx.x * (BLOCK / 64) + wave;
-  const bool early_reject = FAST && (H.n_zones > 0);
+  const bool early_reject = H.n_zones > 0;   // wave-uniform; the host builds no zones for the X-ray test source
   // this wave's replica of the image
   double* const img = A.replicas + (size_t)((uint32_t)wave_global & A.replica_mask) * ((size_t)A.image_nx * (size_t)A.image_ny);
 
@@ -811,7 +815,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   auto run_phase_a = [&](uint64_t i, bool valid) {
     RayState st;
     bool sampled = false, reached = false;
-    const bool ok = phase_a<FAST>(H, Pb, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
+    const bool ok = phase_a<FAST, ROT ? 1 : 0>(H, Pb, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
     const bool alive = valid && ok;
     n_reached += (uint32_t)__popcll(__ballot(valid && reached));
     const uint64_t mask = __ballot(alive);
@@ -822,7 +826,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       Q.X0[wave][slot] = st.X0; Q.Y0[wave][slot] = st.Y0;
       Q.tsx[wave][slot] = st.tsx; Q.tsy[wave][slot] = st.tsy;
       Q.path[wave][slot] = st.path_cb; Q.u5[wave][slot] = st.u5;
-      if (!FAST) Q.zcb[wave][slot] = st.zcb;
+      if (ROT) Q.zcb[wave][slot] = st.zcb;
       Q.idx[wave][slot] = st.r_idx | (st.shell << 16);
     }
     t1 += cnt;
@@ -839,7 +843,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       st.X0 = Q.X0[wave][slot]; st.Y0 = Q.Y0[wave][slot];
       st.tsx = Q.tsx[wave][slot]; st.tsy = Q.tsy[wave][slot];
       st.path_cb = Q.path[wave][slot]; st.u5 = Q.u5[wave][slot];
-      st.zcb = FAST ? -(H.dz3 - H.dz1) : Q.zcb[FAST ? 0 : wave][slot];
+      st.zcb = ROT ? Q.zcb[ROT ? wave : 0][slot] : -(H.dz3 - H.dz1);
       const int packed = valid ? Q.idx[wave][slot] : 0;
       st.r_idx = min(packed & 0xFFFF, Pb.n_radii - 1);
       st.shell = min(packed >> 16, H.n_shells - 1);
@@ -901,7 +905,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         n_reached += (uint32_t)__popcll(__ballot(valid && dead_reached));
         const bool go = valid && !dead;
         const uint64_t mask = __ballot(go);
-        if (go) Q.ray[FAST ? wave : 0][(t0 + prefix_of(mask)) % kQueue] = (uint32_t)i;
+        if (go) Q.ray[wave][(t0 + prefix_of(mask)) % kQueue] = (uint32_t)i;
         t0 += (uint32_t)__popcll(mask);
       } else {
         run_phase_a(i, valid);   // no early-rejection stage for this configuration
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       if (n0 >= 64u || (!have_new && n0 > 0u)) {
         const uint32_t m = min(n0, 64u);
         const bool v = (uint32_t)lane < m;
-        const uint32_t idx = v ? Q.ray[FAST ? wave : 0][(h0 + (uint32_t)lane) % kQueue] : 0u;
+        const uint32_t idx = v ? Q.ray[wave][(h0 + (uint32_t)lane) % kQueue] : 0u;
         h0 += m;
         run_phase_a((uint64_t)idx, v);
         ring_sync();
@@ -1010,7 +1014,7 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
     sart_axion_t rec = {};   // newSeq[Axion] zero-initialises (:2760)
     RayState st;
     bool sampled, reached;
-    const bool alive = phase_a<false>(H, P, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
+    const bool alive = phase_a<false, -1>(H, P, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
     int e_idx = -1;
     if (sampled) {
       e_idx = H.test_active ? P.n_energies : sample_energy_index(P, T, st.r_idx, st.u5);
@@ -1031,35 +1035,54 @@ static int g_hist_block = 1024;
 void set_histogram_block(int block) { g_hist_block = block; }
 int histogram_block() { return g_hist_block; }
 int records_block() { return kRecBlock; }
-template <bool FAST>
-static hipError_t occupancy_of(int block, int* n) {
-  switch (block) {
-    case 512: return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, trace_histogram_kernel<512, FAST>, 512, 0);
-    case 768: return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, trace_histogram_kernel<768, FAST>, 768, 0);
-    case 1024: return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, trace_histogram_kernel<1024, FAST>, 1024, 0);
-    default: return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, trace_histogram_kernel<256, FAST>, 256, 0);
-  }
+// Variants: 0 = FAST (1024 threads), 1 = generic, telescope not rotated (1024 threads), 2 = generic, rotated (768 threads:
+// ring 1 carries one more field).  SART_HIST_BLOCK overrides the block size of variants 0 / 1 for tuning.
+template <int BLOCK, bool FAST, bool ROT>
+static void launch_variant(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks, hipStream_t stream) {
+  hipLaunchKernelGGL((trace_histogram_kernel<BLOCK, FAST, ROT>), dim3(n_blocks), dim3(BLOCK), 0, stream, H, blob, A, acc);
 }
-// resident workgroups per CU for the persistent grid (occupancy API: LDS- and register-limited)
-int histogram_blocks_per_cu(int block, bool fast) {
+int histogram_block_of(int variant) { return variant == 2 ? 768 : g_hist_block; }
+
+int histogram_blocks_per_cu(int variant) {
   int n = 0;
-  const hipError_t e = fast ? occupancy_of<true>(block, &n) : occupancy_of<false>(block, &n);
+  hipError_t e;
+  if (variant == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<768, false, true>, 768, 0);
+  else if (variant == 1) {
+    switch (g_hist_block) {
+      case 256: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<256, false, false>, 256, 0); break;
+      case 512: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<512, false, false>, 512, 0); break;
+      case 768: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<768, false, false>, 768, 0); break;
+      default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, false, false>, 1024, 0); break;
+    }
+  } else {
+    switch (g_hist_block) {
+      case 256: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<256, true, false>, 256, 0); break;
+      case 512: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<512, true, false>, 512, 0); break;
+      case 768: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<768, true, false>, 768, 0); break;
+      default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, true, false>, 1024, 0); break;
+    }
+  }
   return (e == hipSuccess && n > 0) ? n : 1;
 }
 
-template <bool FAST>
-static void launch_hist(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks, hipStream_t stream) {
-  switch (g_hist_block) {
-    case 512: hipLaunchKernelGGL((trace_histogram_kernel<512, FAST>), dim3(n_blocks), dim3(512), 0, stream, H, blob, A, acc); break;
-    case 768: hipLaunchKernelGGL((trace_histogram_kernel<768, FAST>), dim3(n_blocks), dim3(768), 0, stream, H, blob, A, acc); break;
-    case 1024: hipLaunchKernelGGL((trace_histogram_kernel<1024, FAST>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc); break;
-    default: hipLaunchKernelGGL((trace_histogram_kernel<256, FAST>), dim3(n_blocks), dim3(256), 0, stream, H, blob, A, acc); break;
-  }
-}
 void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
-                            hipStream_t stream, bool fast) {
-  if (fast) launch_hist<true>(H, blob, A, acc, n_blocks, stream);
-  else launch_hist<false>(H, blob, A, acc, n_blocks, stream);
+                            hipStream_t stream, int variant) {
+  if (variant == 2) launch_variant<768, false, true>(H, blob, A, acc, n_blocks, stream);
+  else if (variant == 1) {
+    switch (g_hist_block) {
+      case 256: launch_variant<256, false, false>(H, blob, A, acc, n_blocks, stream); break;
+      case 512: launch_variant<512, false, false>(H, blob, A, acc, n_blocks, stream); break;
+      case 768: launch_variant<768, false, false>(H, blob, A, acc, n_blocks, stream); break;
+      default: launch_variant<1024, false, false>(H, blob, A, acc, n_blocks, stream); break;
+    }
+  } else {
+    switch (g_hist_block) {
+      case 256: launch_variant<256, true, false>(H, blob, A, acc, n_blocks, stream); break;
+      case 512: launch_variant<512, true, false>(H, blob, A, acc, n_blocks, stream); break;
+      case 768: launch_variant<768, true, false>(H, blob, A, acc, n_blocks, stream); break;
+      default: launch_variant<1024, true, false>(H, blob, A, acc, n_blocks, stream); break;
+    }
+  }
   const int n_img = A.image_nx * A.image_ny;
   hipLaunchKernelGGL(fold_scalars_kernel, dim3(1), dim3(256), 0, stream, acc + n_img, A.partials, n_blocks, (double)A.n_rays);
   if (A.replica_mask != 0u)

@@ -295,11 +295,19 @@ def test_bench_two_rank_rehearsal():
     assert d["value"] > 1e9
 
 
-def test_early_rejection_stage_is_exact():
+@pytest.mark.parametrize("variant", ["vacuum", "gas", "rotated"])
+def test_early_rejection_stage_is_exact(variant):
     """Stage A0 (rays classified from the bore-exit radius alone) must not change any counter or the image: same
-    launch with the stage switched off (SART_NO_EARLY_REJECT, read when a context uploads its parameter block)."""
+    launch with the stage switched off (SART_NO_EARLY_REJECT, read when a context uploads its parameter block).
+    The three variants are the three instantiations of the histogram kernel (specialised / generic / generic rotated:
+    only the zone of rays that die in the pipes applies when the telescope is turned)."""
     import os
-    full = sa.initFullSetup()            # full-size BabyIAXO / XMM tables: the configuration the stage exists for
+    from solaraxionraytracing_amd import _lib as L
+    # full-size BabyIAXO / XMM tables: the configuration the stage exists for
+    full = sa.initFullSetup(stage=L.SK_GAS) if variant == "gas" else sa.initFullSetup()
+    if variant == "rotated":
+        full.setup.telescope_turned_y_deg = 0.1
+        full.setup.telescope_turned_x_deg = -0.05
     n = 20_000_000
     with sa.RayTracer(full) as rt:
         img_a, s_a = rt.trace_histogram(n, seed=17)
