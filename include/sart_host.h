@@ -11,6 +11,7 @@
 #define SART_HOST_H
 
 #include "sart.h"
+#include "sart_emission.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -105,6 +106,18 @@ int sart_host_containment_radii(const double* radial_counts, const double* radia
  * for a width x width image over 0 .. chip_max mm.  Returns the total flux (the `echo` of :886) in *flux_out. */
 int sart_host_write_image_csv(const char* path, const double* image, int32_t width, double chip_max,
                               double r_sigma1, double r_sigma2, double* flux_out);
+
+/* First loop of calculateOpacities (readOpacityFile.nim:655-705): the per-radius plasma quantities the emission-table
+ * producer (sart_emission.h) needs, from the columns of the solar-model file (AGSS09_solar_model_stripped.dat):
+ * temp_K[n] = Temp, rho[n] = Rho, mass_fractions[n][29] = H1 He4 He3 C12 C13 N14 N15 O16 O17 O18 Ne Na Mg Al Si P S Cl Ar K
+ * Ca Sc Ti V Cr Mn Fe Co Ni (the order of `elements`, :125-128). */
+int sart_host_solar_zones(const double* temp_K, const double* rho, const double* mass_fractions, int32_t n_radii,
+                          sart_solar_zone_t* zones_out);
+
+/* getFluxFractionR (readOpacityFile.nim:535-584): differential flux at Earth in 1/(keV y m^2) per energy, summed over the
+ * radial zones of an emission table [n_radii][n_energies] (zone r at 0.0015 + 0.0005 r solar radii). */
+int sart_host_flux_spectrum(const double* em_rates, int32_t n_radii, const double* energies_kev, int32_t n_energies,
+                            double* diff_flux_out);
 
 #ifdef __cplusplus
 }

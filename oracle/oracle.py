@@ -147,3 +147,71 @@ class Oracle:
         img = acc[:image_n * image_n].reshape(image_n, image_n).copy()
         summ = {k: acc[image_n * image_n + i] for k, i in _lib.ACC.items()}
         return img, summ, used
+
+
+# ---- emission-table producer (oracle/sart_emission_oracle.c) --------------------------------------------------------
+_em_lib = None
+
+
+def load_emission() -> C.CDLL:
+    global _em_lib
+    if _em_lib is None:
+        path = os.path.join(_DIR, "libsart_emission_oracle.so")
+        if not os.path.exists(path):
+            subprocess.run(["make", "-s", "-C", _DIR, "libsart_emission_oracle.so"], check=True)
+        from solaraxionraytracing_amd._lib import EmissionParams, SolarZone
+        lib = C.CDLL(path)
+        lib.sart_emission_oracle_zones.argtypes = [_dp, _dp, _dp, _i, C.POINTER(SolarZone)]
+        lib.sart_emission_oracle_zones.restype = None
+        lib.sart_emission_oracle_fnew.argtypes = [_d, _d]
+        lib.sart_emission_oracle_fnew.restype = _d
+        lib.sart_emission_oracle_bfield.argtypes = [_d]
+        lib.sart_emission_oracle_bfield.restype = _d
+        lib.sart_emission_oracle_table.argtypes = [C.POINTER(SolarZone), _i, _dp, _i, _dp, C.POINTER(EmissionParams), _dp, _dp,
+                                                   _i, _i, _i]
+        lib.sart_emission_oracle_table.restype = C.c_int
+        lib.sart_emission_oracle_flux_spectrum.argtypes = [_dp, _i, _dp, _i, _dp]
+        lib.sart_emission_oracle_flux_spectrum.restype = None
+        _em_lib = lib
+    return _em_lib
+
+
+def emission_zones(temp_K, rho, mass_fractions):
+    from solaraxionraytracing_amd._lib import SolarZone
+    lib = load_emission()
+    temp_K = np.ascontiguousarray(temp_K, dtype=np.float64)
+    rho = np.ascontiguousarray(rho, dtype=np.float64)
+    frac = np.ascontiguousarray(mass_fractions, dtype=np.float64)
+    zones = (SolarZone * temp_K.size)()
+    lib.sart_emission_oracle_zones(temp_K.ctypes.data_as(_dp), rho.ctypes.data_as(_dp), frac.ctypes.data_as(_dp), temp_K.size, zones)
+    return zones
+
+
+def emission_table(zones, energies, params, abs_coefs=None, components=False, r_stride=1, e_stride=1, n_threads=0):
+    """Oracle emission table; only every r_stride-th radius / e_stride-th energy is evaluated (others are NaN)."""
+    lib = load_emission()
+    energies = np.ascontiguousarray(energies, dtype=np.float64)
+    n_r, n_e = len(zones), energies.size
+    out = np.full((n_r, n_e), np.nan)
+    comp = np.full((8, n_r, n_e), np.nan) if components else None
+    if abs_coefs is not None:
+        abs_coefs = np.ascontiguousarray(abs_coefs, dtype=np.float64)
+    if n_threads <= 0:
+        n_threads = len(os.sched_getaffinity(0))
+    rc = lib.sart_emission_oracle_table(zones, n_r, energies.ctypes.data_as(_dp), n_e,
+                                        abs_coefs.ctypes.data_as(_dp) if abs_coefs is not None else None, C.byref(params),
+                                        out.ctypes.data_as(_dp), comp.ctypes.data_as(_dp) if components else None,
+                                        r_stride, e_stride, n_threads)
+    if rc != 0:
+        raise RuntimeError("sart_emission_oracle_table failed")
+    return (out, comp) if components else out
+
+
+def emission_flux_spectrum(em_rates, energies):
+    lib = load_emission()
+    em = np.ascontiguousarray(em_rates, dtype=np.float64)
+    energies = np.ascontiguousarray(energies, dtype=np.float64)
+    out = np.empty(energies.size)
+    lib.sart_emission_oracle_flux_spectrum(em.ctypes.data_as(_dp), em.shape[0], energies.ctypes.data_as(_dp), energies.size,
+                                           out.ctypes.data_as(_dp))
+    return out

@@ -35,7 +35,7 @@ CF_READ_DET_INSTALL_CONFIG = 1 << 6
 ACC = dict(SUM_WEIGHTS=0, N_PASSED=1, N_PASSED_TILL_WINDOW=2, N_HIT_NICKEL=3, SUM_X=4, SUM_Y=5, SUM_R=6,
            SUM_WEIGHTS_SQ=7, N_RAYS=8, N_REACHED_TELESCOPE=9, N_SHELL_SELECTED=10, N_OUTSIDE_IMAGE=11)
 
-SART_ERR_NO_DEVICE = -2
+SART_ERR_INVALID_ARGUMENT, SART_ERR_NO_DEVICE = -1, -2
 
 _d = C.c_double
 _i = C.c_int32
@@ -127,6 +127,20 @@ class DetectorInstallConfig(C.Structure):
     _fields_ = [(n, _d) for n in ("distanceDetectorXRT", "distanceWindowFocalPlane", "lateralShift", "transversalShift")]
 
 
+class SolarZone(C.Structure):
+    """sart_solar_zone_t (include/sart_emission.h)"""
+    _fields_ = [(n, _d) for n in ("radius_frac", "temp_K", "rho", "n_e", "n_H", "n_He")] + [("temp_index", _i), ("ne_index", _i)]
+
+
+class EmissionParams(C.Structure):
+    """sart_emission_params_t"""
+    _fields_ = [("g_ae", _d), ("g_agamma", _d), ("g_anuclei", _d), ("terms", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+# SART_EM_* term bits, in the order of the component planes
+EM_TERMS = ("compton", "term1", "ee_brems", "free_free", "primakoff", "long_plasmon", "trans_plasmon", "iron57")
+EM_ALL = 0xFF
+
 _P = C.POINTER
 _dp = _P(_d)
 
@@ -154,6 +168,12 @@ SART_SYMBOLS = {
     "sart_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "sart_get_kernel_timing": (C.c_int, [C.c_void_p, _dp, _P(C.c_int64)]),
     "sart_device_info": (C.c_int, [C.c_void_p, _P(_i), _P(_i), C.c_char_p, C.c_size_t]),
+    # include/sart_emission.h
+    "sart_emission_default_params": (None, [_P(EmissionParams)]),
+    "sart_emission_table": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _i, _dp, _P(EmissionParams), _dp, _dp]),
+    "sart_emission_table_device": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _i, C.c_void_p, _P(EmissionParams),
+                                             C.c_void_p, C.c_void_p]),
+    "sart_emission_last_kernel_ms": (_d, []),
 }
 
 # every symbol include/sart_host.h declares
@@ -173,6 +193,8 @@ SART_HOST_SYMBOLS = {
     "sart_host_trace_axion_wrapper": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32]),
     "sart_host_perform_angular_scan": (C.c_int, [C.c_void_p, _dp, _i, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                                  _dp, _dp]),
+    "sart_host_solar_zones": (C.c_int, [_dp, _dp, _dp, _i, _P(SolarZone)]),
+    "sart_host_flux_spectrum": (C.c_int, [_dp, _i, _dp, _i, _dp]),
 }
 
 

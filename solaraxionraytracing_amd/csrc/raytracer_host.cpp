@@ -598,4 +598,70 @@ int sart_host_write_image_csv(const char* path, const double* image, int32_t wid
   return 0;
 }
 
+// ---- solar emission-table producer: host side (readOpacityFile.nim) -------------------------------------------------
+
+// First loop of calculateOpacities (readOpacityFile.nim:655-705): per-radius number densities, electron density and the
+// nearest OPCD grid points from the columns of the solar-model file.
+int sart_host_solar_zones(const double* temp_K, const double* rho, const double* mass_fractions, int32_t n_radii,
+                          sart_solar_zone_t* zones_out) {
+  if (!temp_K || !rho || !mass_fractions || !zones_out || n_radii < 1)
+    return fail(SART_ERR_INVALID_ARGUMENT, "sart_host_solar_zones: bad argument");
+  // const atomicMass / charges :120-132, in the order of the model-file columns (H1 He4 He3 C12 C13 N14 N15 O16 O17 O18 Ne ... Ni)
+  static const double atomic_mass[29] = {1.0078,  4.0026,  3.0160,  12.0000, 13.0033, 14.0030, 15.0001, 15.9949, 16.9991, 17.9991,
+                                         20.1797, 22.9897, 24.3055, 26.9815, 28.085,  30.9737, 32.0675, 35.4515, 39.8775, 39.0983,
+                                         40.078,  44.9559, 47.867,  50.9415, 51.9961, 54.9380, 55.845,  58.9331, 58.6934};
+  const double amu = 1.6605e-24;  // :651
+  int temperature = 0, n_e_int = 0;  // declared outside the loop in the reference (:622-629): a radius without a grid point
+                                     // within one step keeps the previous radius' value
+  for (int32_t i = 0; i < n_radii; ++i) {
+    if (!(temp_K[i] > 0.0) || !(rho[i] > 0.0)) return fail(SART_ERR_INVALID_ARGUMENT, "sart_host_solar_zones: Temp and Rho must be positive");
+    const double* x = mass_fractions + static_cast<size_t>(i) * 29;
+    const double per_amu = rho[i] / amu;
+    sart_solar_zone_t& z = zones_out[i];
+    z.radius_frac = static_cast<double>(i) * 0.0005 + 0.0015;                                             // :698
+    z.temp_K = temp_K[i];
+    z.rho = rho[i];
+    z.n_H = (x[0] / atomic_mass[0]) * per_amu;                                                           // :661
+    z.n_He = (x[1] + x[2]) / ((atomic_mass[1] * x[1] + atomic_mass[2] * x[2]) / (x[1] + x[2])) * rho[i] / amu;  // :662-667
+    double n_e = 0.0;
+    for (int k = 0; k < 29; ++k) {
+      const double charge = (k == 0) ? 1.0 : (k <= 2) ? 2.0 : (k <= 4) ? 6.0 : (k <= 6) ? 7.0 : (k <= 9) ? 8.0 : static_cast<double>(k);  // :129-132
+      n_e += per_amu * charge * x[k] / atomic_mass[k];                                                   // :681-683
+    }
+    z.n_e = n_e;
+    const double lt = std::log10(temp_K[i]) / 0.025;
+    for (int it = 0; it <= 90; ++it)
+      if (std::fabs(lt - static_cast<double>(140 + 2 * it)) <= 1.0) temperature = 140 + 2 * it;          // :686-689
+    const double ln = std::log10(n_e) / 0.25;
+    for (int in = 0; in <= 17; ++in)
+      if (std::fabs(ln - static_cast<double>(74 + in * 2)) <= 1.0) n_e_int = 74 + in * 2;                // :692-695
+    z.temp_index = temperature;
+    z.ne_index = n_e_int;
+  }
+  return 0;
+}
+
+// getFluxFractionR (readOpacityFile.nim:535-584): flux spectrum at Earth in 1/(keV y m^2), summed over the radial zones.
+int sart_host_flux_spectrum(const double* em_rates, int32_t n_radii, const double* energies_kev, int32_t n_energies,
+                            double* diff_flux_out) {
+  if (!em_rates || !energies_kev || !diff_flux_out || n_radii < 1 || n_energies < 1)
+    return fail(SART_ERR_INVALID_ARGUMENT, "sart_host_flux_spectrum: bad argument");
+  const double pi = 3.14159265358979323846;
+  const double r_sun = 6.957e11, r_sunearth = 1.5e14, hbar = 6.582119514e-25, keV2cm = 1.97327e-8;   // :540-545
+  const double factor = std::pow(r_sun * 0.1 / keV2cm, 3.0) / (std::pow(0.1 * r_sunearth, 2.0) * (1.0e6 * hbar)) /
+                        (3.1709791983765E-8 * 1.0e-4);                                                // :546-548
+  for (int32_t e = 0; e < n_energies; ++e) {
+    const double e_keV = energies_kev[e];
+    double sum = 0.0, r_last = 0.0;
+    for (int32_t r = 0; r < n_radii; ++r) {
+      const double r_perc = static_cast<double>(r) * 0.0005 + 0.0015;
+      // both branches of the `if e_keV > 0.4` are the same expression (:569-575)
+      sum += em_rates[static_cast<size_t>(r) * n_energies + e] * (r_perc - r_last) * r_perc * r_perc * e_keV * e_keV * 0.5 / (pi * pi);
+      r_last = r_perc;
+    }
+    diff_flux_out[e] = sum * factor;
+  }
+  return 0;
+}
+
 }  // extern "C"

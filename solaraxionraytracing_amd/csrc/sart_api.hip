@@ -556,6 +556,13 @@ struct TimedLaunch {
 
 }  // namespace
 
+// Used by the other translation units of libsart.so (sart_emission.hip); not part of the C-ABI.
+namespace sart {
+__attribute__((visibility("hidden"))) int context_device(sart_context* c) { return c->device; }
+__attribute__((visibility("hidden"))) hipStream_t context_stream(sart_context* c) { return c->stream; }
+__attribute__((visibility("hidden"))) int set_error(int code, const std::string& msg) { return fail(code, msg); }
+}  // namespace sart
+
 extern "C" {
 
 int sart_abi_version(void) { return SART_ABI_VERSION; }

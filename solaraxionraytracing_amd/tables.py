@@ -91,6 +91,20 @@ def read_solar_model_csv(path: str):
     return radii, energies, np.ascontiguousarray(em)
 
 
+def write_solar_model_csv(path: str, radii: np.ndarray, energies: np.ndarray, em_rates: np.ndarray):
+    """Writes an emission table in the layout `calculateOpacities` returns and `main` saves
+    (readOpacityFile.nim:853-854, :986: per radius one block with the columns Radius, Energy [keV], emRates) — the file
+    `initFullSetup` reads back (raytracer.nim:2647-2668)."""
+    em = np.asarray(em_rates, dtype=np.float64)
+    if em.shape != (len(radii), len(energies)):
+        raise ValueError("em_rates must be [n_radii][n_energies]")
+    with open(path, "w") as f:
+        f.write("Radius,Energy [keV],emRates\n")
+        for i, r in enumerate(radii):
+            rs = repr(float(r))
+            f.write("".join("%s,%s,%s\n" % (rs, repr(float(e)), repr(float(v))) for e, v in zip(energies, em[i])))
+
+
 def build_cdfs(em_rates: np.ndarray, radii: np.ndarray, energies: np.ndarray):
     """fluxRadiusCDF / diffFluxCDFs of initFullSetup (raytracer.nim:2670-2705), via libsart_host."""
     host = _lib.load_host()

@@ -129,3 +129,14 @@ def test_config_picks_up_real_files_when_present(tmp_path):
     full = config.init_full_setup_from_config(str(cfgdir / "config.toml"))
     assert full.meta["notes"] == [] and full.diffFluxCDFs.shape == (12, 9) and full.reflectivity.data.shape == (4, 20, 16)
     assert full.setup.magnet_B == 9.0
+
+
+def test_solar_model_csv_round_trip(tmp_path):
+    from solaraxionraytracing_amd import tables
+    radii, energies = tables.solar_grid(12, 9)
+    em = np.random.default_rng(2).random((12, 9)) * 1e-36
+    path = str(tmp_path / "solar_model_dataframe.csv")
+    tables.write_solar_model_csv(path, radii, energies, em)
+    assert open(path).readline().strip() == "Radius,Energy [keV],emRates"
+    r2, e2, em2 = tables.read_solar_model_csv(path)
+    assert np.array_equal(r2, radii) and np.array_equal(e2, energies) and np.array_equal(em2, em)

@@ -20,8 +20,8 @@ def _declared(header):
 
 def test_libsart_exports_every_declared_symbol():
     lib = L.load_sart()
-    names = _declared("sart.h")
-    assert len(names) >= 20
+    names = sorted(_declared("sart.h") + _declared("sart_emission.h"))
+    assert len(names) >= 24
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(L.SART_SYMBOLS) == names          # the ctypes table binds exactly the header
@@ -38,13 +38,15 @@ def test_libsart_host_exports_every_declared_symbol():
 
 def test_struct_sizes_match_c_header(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include "sart.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(sart_setup_t),'
-                   ' sizeof(sart_axion_t), sizeof(sart_trace_params_t), sizeof(sart_summary_t));return 0;}')
+    src.write_text('#include "sart_emission.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sart_setup_t),'
+                   ' sizeof(sart_axion_t), sizeof(sart_trace_params_t), sizeof(sart_summary_t), sizeof(sart_solar_zone_t),'
+                   ' sizeof(sart_emission_params_t));return 0;}')
     import subprocess
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
-    assert [int(x) for x in out] == [C.sizeof(L.Setup), C.sizeof(L.Axion), C.sizeof(L.TraceParams), C.sizeof(L.Summary)]
+    assert [int(x) for x in out] == [C.sizeof(L.Setup), C.sizeof(L.Axion), C.sizeof(L.TraceParams), C.sizeof(L.Summary),
+                                     C.sizeof(L.SolarZone), C.sizeof(L.EmissionParams)]
     assert C.sizeof(L.Axion) == 208
 
 

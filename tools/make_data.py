@@ -85,8 +85,11 @@ def solar_profile():
     temp_kev = temp * 8.617e-8
     n_e_kev = n_e * 7.683e-24                             # keV^3
     ks2 = (4.0 * np.pi * alpha / temp_kev) * (n_e_kev + n_h * 7.645e-24 + 4.0 * n_he * 7.645e-24)
+    # raw columns for the emission-table producer (include/sart_emission.h): Temp [K], Rho [g/cm^3] and the 29 mass fractions
+    fractions = np.stack([col[name] for name in ELEMENTS], axis=1)
     np.savez_compressed(os.path.join(OUT, "solar_profile.npz"), radius=col["Radius"], temp_kev=temp_kev,
-                        n_e_kev3=n_e_kev, n_h_kev3=n_h * 7.645e-24, n_he_kev3=n_he * 7.645e-24, debye_ks2=ks2)
+                        n_e_kev3=n_e_kev, n_h_kev3=n_h * 7.645e-24, n_he_kev3=n_he * 7.645e-24, debye_ks2=ks2,
+                        temp_K=temp, rho=rho, mass_fractions=fractions)
 
 
 def reference_curves():
