@@ -765,6 +765,18 @@ __device__ __forceinline__ void stage_tables(TablesLds& S, const DevParams& P, c
 // Ray i of this launch has the global id ray_id_offset + i; n_rays < 2^32 per launch.
 // FAST: solar source, vacuum, no hole loop, telescope not rotated (all known at compile time).  ROT: rotated telescope
 // (ring 1 then also carries z of pointExitCB; 768 threads so that the rings still fit the LDS).
+// Re-reads the HotA block (the first kernel argument) from the kernel-argument segment with scalar loads.  The pointer
+// is laundered so that the loads stay where they are written (the start of a phase-A pass) instead of being hoisted
+// out of the persistent loop: ~50 SGPRs held across stage B get spilled through VGPR lanes (v_readlane = VALU slots).
+__device__ __forceinline__ void reload_hot(HotA& dst) {
+  typedef const __attribute__((address_space(4))) uint32_t* kernarg_ptr;
+  kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(HotA) / 4); ++k) d[k] = p[k];
+}
+
 template <int BLOCK, bool FAST, bool ROT>
 __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
                                                                 double* __restrict__ acc) {
@@ -815,7 +827,9 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   auto run_phase_a = [&](uint64_t i, bool valid) {
     RayState st;
     bool sampled = false, reached = false;
-    const bool ok = phase_a<FAST, ROT ? 1 : 0>(H, Pb, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
+    HotA Hl;
+    reload_hot(Hl);
+    const bool ok = phase_a<FAST, ROT ? 1 : 0>(Hl, Pb, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
     const bool alive = valid && ok;
     n_reached += (uint32_t)__popcll(__ballot(valid && reached));
     const uint64_t mask = __ballot(alive);

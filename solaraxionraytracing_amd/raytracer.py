@@ -62,6 +62,9 @@ def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_IN
             em, meta_em = emission, "user"
         elif emission == "primakoff":
             em, meta_em = tables.primakoff_emission_table(n_radii, n_energies), "E1-primakoff-agss09"
+        elif emission == "agss09":   # all analytic terms of readOpacityFile.nim on the AGSS09 model, made on the GPU (BASELINE configs[4])
+            from . import emission as _emission
+            em, meta_em = _emission.agss09_emission_table(n_radii, n_energies)[2], "E0-agss09-all-terms-gpu"
         elif emission == "flat":
             em, meta_em = tables.flat_emission_table(n_radii, n_energies), "E3-flat"
         else:

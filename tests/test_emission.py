@@ -201,6 +201,8 @@ def test_emission_table_feeds_the_ray_tracer():
     radii, energies, em_rates = em.agss09_emission_table()
     assert em.last_kernel_ms() > 0.0
     full = sa.initFullSetup(emission=em_rates)
+    full2 = sa.initFullSetup(emission="agss09")
+    assert np.array_equal(full.diffFluxCDFs, full2.diffFluxCDFs) and full2.meta["emission"].startswith("E0")
     with sa.RayTracer(full) as rt:
         img, s = rt.trace_histogram(2_000_000, seed=3)
     assert s["N_PASSED"] / s["N_RAYS"] == pytest.approx(0.2144, abs=1e-2)     # geometry-dominated
