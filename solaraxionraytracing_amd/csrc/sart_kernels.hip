@@ -37,6 +37,9 @@ struct U4 { uint32_t x, y, z, w; };
 
 __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                             uint32_t k1) {
+  // The round keys are wave-uniform; keep their schedule (20 s_add) next to its use instead of letting it be hoisted
+  // out of the persistent loop into 20 SGPRs that then get spilled through VGPR lanes.
+  asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;   // one v_mad_u64_u32 yields both halves
