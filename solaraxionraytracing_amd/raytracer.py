@@ -187,6 +187,30 @@ class RayTracer:
         _lib.check(self.lib.sart_trace_histogram(self.handle, C.byref(p), _lib.as_dp(img), C.byref(summ)))
         return img, {k: summ.v[i] for k, i in _lib.ACC.items()}
 
+    def trace_image(self, n_rays: int, nx: int, ny: int, x_range=None, y_range=None, seed: int = 299792458,
+                    ray_id_offset: int = 0, flags: int | None = None):
+        """prepareHeatmap with any binning / window (raytracer.nim:818-842): e.g. the 3000 x 3000 maps of
+        generateResultPlots (:2626, :2630).  Returns (image[ny][nx], summary)."""
+        p = self.trace_params(n_rays, seed, ray_id_offset, flags, 1, False)
+        p.image_nx, p.image_ny = int(nx), int(ny)
+        if x_range is not None:
+            p.image_x_min, p.image_x_max = float(x_range[0]), float(x_range[1])
+        if y_range is not None:
+            p.image_y_min, p.image_y_max = float(y_range[0]), float(y_range[1])
+        img = np.empty((ny, nx))
+        summ = Summary()
+        _lib.check(self.lib.sart_trace_histogram(self.handle, C.byref(p), _lib.as_dp(img), C.byref(summ)))
+        return img, {k: summ.v[i] for k, i in _lib.ACC.items()}
+
+    def y_slice_histogram(self, n_rays: int, half_width: float = 0.05, bin_width: float = 0.001, **kw):
+        """`y_{year}.pdf` of generateResultPlots (raytracer.nim:2551-2559): weighted histogram (bin 0.001 mm) of the
+        y-positions of the rays with |x - ChipCenterX| < 0.05 mm — one image column.  Returns (bin edges, flux per bin)."""
+        s = self.full.setup
+        cx = 0.5 * s.chip_x_max
+        ny = int(round(s.chip_y_max / bin_width))
+        img, _ = self.trace_image(n_rays, 1, ny, x_range=(cx - half_width, cx + half_width), y_range=(0.0, s.chip_y_max), **kw)
+        return np.linspace(0.0, s.chip_y_max, ny + 1), img[:, 0].copy()
+
     def trace_spectra(self, n_rays: int, seed: int = 299792458, ray_id_offset: int = 0, flags: int | None = None,
                       image_n: int = 256, n_radial_bins: int = 10_000, radial_max: float = 10.0, accumulate: bool = False):
         """trace_histogram plus the post-processing histograms of generateResultPlots accumulated on the device:

@@ -380,3 +380,33 @@ def test_reduce_across_devices_single_process_entry_point():
         accs2 = (C.c_void_p * 2)(acc.data_ptr(), acc.data_ptr())
         assert lib.sart_reduce_across_devices(two, accs2, 2, acc.numel(), 0) == -1    # same device twice
         assert b"distinct devices" in lib.sart_last_error()
+
+
+def test_high_resolution_heatmap_and_y_slice():
+    """The other binnings of generateResultPlots through the same entry point: the 3000 x 3000 heat map (:2626) and the
+    y-slice histogram of the rays within 0.05 mm of the chip centre in x (:2551-2559), against oracle records."""
+    from oracle.oracle import Oracle
+    full = make_setup("babyiaxo_xmm")
+    n = 400_000
+    o = Oracle(full)
+    rec = o.trace_records(n, seed=21)
+    ok = rec["passed"].astype(bool)
+    with sa.RayTracer(full) as rt:
+        img, s = rt.trace_image(n, 3000, 3000, seed=21)
+        edges, flux = rt.y_slice_histogram(n, seed=21)
+        coarse, _ = rt.trace_histogram(n, seed=21)
+    assert img.shape == (3000, 3000)
+    assert img.sum() == pytest.approx(s["SUM_WEIGHTS"], rel=1e-11) and s["N_OUTSIDE_IMAGE"] == 0
+    assert s["SUM_WEIGHTS"] == pytest.approx(rec["weights"][ok].sum(), rel=2e-4)    # edge rays within the f64 oracle's noise
+    # 3000 = 12 x 250, 256-pixel map over the same 14 mm: compare on a common 2 x 2 grid of quadrants
+    q = lambda a: np.array([[a[:a.shape[0] // 2, :a.shape[1] // 2].sum(), a[:a.shape[0] // 2, a.shape[1] // 2:].sum()],
+                            [a[a.shape[0] // 2:, :a.shape[1] // 2].sum(), a[a.shape[0] // 2:, a.shape[1] // 2:].sum()]])
+    np.testing.assert_allclose(q(img), q(coarse), rtol=1e-9)
+    # y slice: oracle rays with |x - 7| < 0.05 (positions are stored as -x + 7 / y + 7, :2203-2204)
+    x, y, w = rec["pointdataX"][ok], rec["pointdataY"][ok], rec["weights"][ok]
+    sel = np.abs(x - 7.0) < 0.05
+    want, _ = np.histogram(y[sel], bins=edges, weights=w[sel])
+    assert flux.size == 14000 and sel.sum() > 50
+    assert flux.sum() == pytest.approx(want.sum(), rel=2e-2)          # rays within the oracle's f64 noise of the slice edge may flip
+    # same rays land in the same 0.001 mm bins up to that noise: compare on 0.05 mm bins
+    np.testing.assert_allclose(flux.reshape(280, 50).sum(axis=1), want.reshape(280, 50).sum(axis=1), atol=0.06 * want.max() + 1e-300, rtol=0.1)
