@@ -13,12 +13,14 @@
 //     hit the surface normals reduce to closed forms without a square root;
 //   * a Philox4x32-10 counter block per ray (key = seed, counter = global ray id) replaces the
 //     reference's shared xoroshiro stream, draw order as in the reference;
-//   * the path is split at the point where most rays have died (bore, pipes, spider, glass fronts:
-//     ~2/3 of all rays for BabyIAXO): phase A (sample + cuts + shell selection) runs one ray per
-//     lane; survivors are compacted with a wavefront ballot + prefix count into a per-wave LDS
-//     ring, and phase B (mirrors + weights + accumulation) runs on full waves of survivors;
-//   * per-setup scalars travel in the kernel arguments (SGPRs); the radius CDF, its guide table,
-//     the shell table and the shell look-up table are staged into LDS once per workgroup;
+//   * the path is split where most rays die (bore, pipes, spider, glass fronts: ~2/3 of all rays for
+//     BabyIAXO) into three stages that each run on full waves: A0 (one Philox block: rays that the
+//     radius of their bore-exit point alone proves dead), A1 = phase A (sample + cuts + shell
+//     selection), B = phase B (mirrors + weights + accumulation); survivors are compacted with a
+//     wavefront ballot + prefix count into per-wave LDS rings between the stages;
+//   * phase A's scalars travel in the kernel arguments (re-read with scalar loads at the start of
+//     each pass); the radius CDF, its guide table, the shell table and the shell look-up table
+//     are staged into LDS once per workgroup;
 //   * results are accumulated on the device: f64 atomics into the focal-plane image, wave
 //     reductions for the scalars.
 // Lines cited as ":NNNN" refer to src/raytracer.nim of the reference.
