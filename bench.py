@@ -169,11 +169,30 @@ def main():
         }
         if world == 1 and not args.profile_run:
             out["cpu_baseline"] = cpu_baseline(full, int(args.cpu_sample), seed)
+            if args.workload == "babyiaxo_xmm":
+                out["other_workloads"] = [other_workload_rate()]
         print(json.dumps(out))
     rt.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_workload_rate():
+    """BASELINE configs[1] (CAST magnet + LLNL telescope, gold reflectivities, 1e8 rays) beside the headline workload:
+    three 1e8-ray launches, HIP-event kernel time.  Informational; `value` is the BabyIAXO workload."""
+    import solaraxionraytracing_amd as sa
+    from solaraxionraytracing_amd import _lib as L
+    full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
+    n = 100_000_000
+    with sa.RayTracer(full) as rt:
+        rt.trace_histogram(n // 10, seed=1)
+        rt.enable_kernel_timing(True)
+        for k in range(3):
+            _, s = rt.trace_histogram(n, seed=1, ray_id_offset=k * n, accumulate=(k > 0))
+        ms, n_launch = rt.kernel_timing()
+    return {"workload": "CAST magnet + LLNL 14 shells, gold_0.25microns reflectivities, 1e8 rays (BASELINE configs[1])",
+            "rays_per_s": n / (ms / n_launch) * 1e3, "ms_per_launch": ms / n_launch, "passed_fraction": s["N_PASSED"] / s["N_RAYS"]}
 
 
 def available_cpus() -> int:
