@@ -398,7 +398,7 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   a.replicas = nullptr;
   a.partials = nullptr;
   a.replica_mask = 0u;
-  a._pad = 0u;
+  a.replica_stride = 0u;
   a.n_rays = p->n_rays;
   a.ray_id_offset = p->ray_id_offset;
   a.seed_lo = static_cast<uint32_t>(p->seed);
@@ -795,12 +795,18 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
     const sart_setup_t& s = c->setup;
     const double spot_px = s.distance_detector_xrt * (0.25 * s.radius_sun / s.distance_sun_earth) *
                            a.image_inv_step_x;
-    int R = spot_px > 96.0 ? 1 : (spot_px > 12.0 ? 16 : 64);
-    if (s.test_active) R = 16;
+    // Measured on CAST / LLNL (88 % of all rays land within ~30 pixels): 1 replica 12.4 ms per 1e8 rays, 16: 5.5, 64: 4.4,
+    // 128: 4.4, 512: 4.6 (3.99 ms with the atomics switched off).
+    int R = spot_px > 96.0 ? 1 : 64;
+    if (s.test_active) R = 64;
     if (const char* e = std::getenv("SART_IMAGE_REPLICAS")) R = std::max(1, std::min(kMaxImageReplicas, std::atoi(e)));
     while (R & (R - 1)) R &= R - 1;   // power of two
     if (R > 1) {
-      const size_t need = static_cast<size_t>(R) * static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny);
+      const size_t n_img = static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny);
+      const size_t pad = 32;   // replicas do not start on the same power-of-two boundary (measured: within noise)
+      if (n_img + pad > 0xFFFFFFFFull) return fail(SART_ERR_INVALID_ARGUMENT, "image too large for replicated accumulation");
+      a.replica_stride = static_cast<uint32_t>(n_img + pad);
+      const size_t need = static_cast<size_t>(R) * (n_img + pad);
       if (c->d_replicas.n != need || !c->d_replicas.p) {
         SART_HIP(hipStreamSynchronize(c->stream));
         if (int rc = c->d_replicas.resize(need)) return rc;

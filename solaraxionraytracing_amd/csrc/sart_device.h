@@ -159,7 +159,7 @@ struct DevBlob {
 };
 static_assert(sizeof(DevBlob) % 8 == 0, "DevBlob is staged into LDS as 8-byte words");
 
-constexpr int kMaxImageReplicas = 64;   // power of two
+constexpr int kMaxImageReplicas = 128;   // power of two
 
 struct TraceArgs {
   uint64_t n_rays, ray_id_offset;
@@ -167,7 +167,8 @@ struct TraceArgs {
   // focal spot serialise at the memory side.  fold_replicas_kernel adds the replicas into the caller's
   // accumulator.  replica_mask = 0 (wide images): `replicas` is the accumulator itself, no fold.
   double* replicas;
-  uint32_t replica_mask, _pad;
+  uint32_t replica_mask;
+  uint32_t replica_stride;   // doubles between two replicas (image size + padding, see sart_api.hip)
   // Per-workgroup partial sums of the SART_ACC_COUNT scalars (plain stores; fold_scalars_kernel adds them to the
   // accumulator): thousands of f64 atomics on the same 11 addresses serialise for hundreds of microseconds.
   double* partials;

@@ -39,9 +39,6 @@ struct U4 { uint32_t x, y, z, w; };
 
 __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                             uint32_t k1) {
-  // The round keys are wave-uniform; keep their schedule (20 s_add) next to its use instead of letting it be hoisted
-  // out of the persistent loop into 20 SGPRs that then get spilled through VGPR lanes.
-  asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;   // one v_mad_u64_u32 yields both halves
@@ -810,7 +807,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   const uint64_t wave_global = (uint64_t)blockIdx.x * (BLOCK / 64) + wave;
   const bool early_reject = H.n_zones > 0;   // wave-uniform; the host builds no zones for the X-ray test source
   // this wave's replica of the image
-  double* const img = A.replicas + (size_t)((uint32_t)wave_global & A.replica_mask) * ((size_t)A.image_nx * (size_t)A.image_ny);
+  double* const img = A.replicas + (size_t)((uint32_t)wave_global & A.replica_mask) * (size_t)A.replica_stride;
 
   // wave-uniform counters (ballot + popcount) and per-lane sums
   uint32_t n_reached = 0, n_shell = 0, n_nickel = 0, n_till = 0, n_passed = 0, n_outside = 0;
@@ -1000,13 +997,13 @@ __global__ __launch_bounds__(256) void fold_scalars_kernel(double* __restrict__ 
 
 // acc[i] += sum over replicas; replicas are left zeroed for the next launch.
 __global__ __launch_bounds__(256) void fold_replicas_kernel(double* __restrict__ acc, double* __restrict__ replicas, int n_img,
-                                                            int n_replicas) {
+                                                            int n_replicas, uint32_t stride) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_img) return;
   double s = 0.0;
   for (int r = 0; r < n_replicas; ++r) {
-    s += replicas[(size_t)r * (size_t)n_img + i];
-    replicas[(size_t)r * (size_t)n_img + i] = 0.0;
+    s += replicas[(size_t)r * (size_t)stride + i];
+    replicas[(size_t)r * (size_t)stride + i] = 0.0;
   }
   acc[i] += s;
 }
@@ -1106,7 +1103,7 @@ void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs&
   hipLaunchKernelGGL(fold_scalars_kernel, dim3(1), dim3(256), 0, stream, acc + n_img, A.partials, n_blocks, (double)A.n_rays);
   if (A.replica_mask != 0u)
     hipLaunchKernelGGL(fold_replicas_kernel, dim3((n_img + 255) / 256), dim3(256), 0, stream, acc, A.replicas, n_img,
-                       (int)A.replica_mask + 1);
+                       (int)A.replica_mask + 1, A.replica_stride);
 }
 void launch_trace_records(const HotA& H, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream) {
