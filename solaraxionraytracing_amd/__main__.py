@@ -1,0 +1,88 @@
+"""Command line of the reference's `raytracer` binary (`proc main`, raytracer.nim:2817-2865) on top of the GPU path.
+
+    python -m solaraxionraytracing_amd [--ignoreDetWindow] [--ignoreGasAbs] [--ignoreConvProb] [--ignoreReflection]
+        [--xrayTest] [--detectorInstall] [--magnet] [--angularScanMin A --angularScanMax B --numAngularScanPoints N]
+        [--noPlots] [--config FILE | --configPath DIR]  [--rays N] [--seed S] [--outpath DIR]
+
+Same switches, same two modes (full run = calculateFluxFractions, :2755-2776; angular scan, :2778-2815).  What differs:
+`--rays` replaces the compile-time constant NumberOfPointsSun (:251, default 1e6), plots are never made (the numbers
+behind them are written as CSV), and without a config file the setup is that of config_default.toml
+(BabyIAXO / InGridIAXO / vacuum / XMM, config_default.toml:19-22) with the synthetic input tables of tables.py."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from . import _lib, config as cfgmod
+from .raytracer import RayTracer, containment_radii, initFullSetup, performAngularScan, write_image_csv
+
+WINDOW_YEAR = {_lib.DK_INGRID2017: "2017", _lib.DK_INGRID2018: "2018", _lib.DK_INGRIDIAXO: "IAXO"}   # WindowYearKind, :1468-1484
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(prog="python -m solaraxionraytracing_amd", description=__doc__,
+                                 formatter_class=argparse.RawDescriptionHelpFormatter)
+    for name in ("ignoreDetWindow", "ignoreGasAbs", "ignoreConvProb", "ignoreReflection", "xrayTest", "detectorInstall",
+                 "magnet", "noPlots"):
+        ap.add_argument("--" + name, action="store_true")
+    ap.add_argument("--angularScanMin", type=float, default=0.0)
+    ap.add_argument("--angularScanMax", type=float, default=0.0)
+    ap.add_argument("--numAngularScanPoints", type=int, default=50)
+    ap.add_argument("--config", default="", help="path of a config.toml")
+    ap.add_argument("--configPath", default="", help="directory that holds config.toml")
+    ap.add_argument("--rays", type=float, default=1e6, help="NumberOfPointsSun (raytracer.nim:251)")
+    ap.add_argument("--seed", type=int, default=299792458)
+    ap.add_argument("--outpath", default="out")
+    ap.add_argument("--device", type=int, default=0)
+    return ap
+
+
+def setup_from_args(args):
+    flags = cfgmod.flags_from_cli(args.ignoreDetWindow, args.ignoreGasAbs, args.ignoreConvProb, args.ignoreReflection,
+                                  args.xrayTest, args.detectorInstall, args.magnet)
+    path = args.config or (os.path.join(args.configPath, "config.toml") if args.configPath else "")
+    if path:
+        return cfgmod.init_full_setup_from_config(path, flags), flags
+    return initFullSetup(flags=flags), flags
+
+
+def main(argv=None) -> int:
+    args = build_parser().parse_args(argv)
+    full, flags = setup_from_args(args)
+    n = int(args.rays)
+    os.makedirs(args.outpath, exist_ok=True)
+    print("Flags:", [name for name, bit in (("cfIgnoreDetWindow", _lib.CF_IGNORE_DET_WINDOW), ("cfIgnoreGasAbs", _lib.CF_IGNORE_GAS_ABS),
+                                            ("cfIgnoreReflection", _lib.CF_IGNORE_REFLECTION), ("cfIgnoreConvProb", _lib.CF_IGNORE_CONV_PROB),
+                                            ("cfXrayTest", _lib.CF_XRAY_TEST), ("cfReadMagnetConfig", _lib.CF_READ_MAGNET_CONFIG),
+                                            ("cfReadDetInstallConfig", _lib.CF_READ_DET_INSTALL_CONFIG)) if flags & bit])
+    with RayTracer(full, device=args.device) as rt:
+        if args.angularScanMin == args.angularScanMax:
+            # calculateFluxFractions + the numbers of generateResultPlots (:2252-2257, :2459-2527, :885-921)
+            img, s, spec = rt.trace_spectra(n, seed=args.seed, flags=flags)
+            print("Passed axions", int(s["N_PASSED"]))
+            print("Passed axions until the Window", int(s["N_PASSED_TILL_WINDOW"]))
+            print("Number of X-rays hitting nickel:", int(s["N_HIT_NICKEL"]))
+            r1, r2, r1w, r2w = containment_radii(spec)
+            print("rSigma1 %.4f rSigma2 %.4f rSigma1W %.4f rSigma2W %.4f" % (r1, r2, r1w, r2w))
+            year = WINDOW_YEAR.get(full.setup.detector_kind, "IAXO")
+            out = os.path.join(args.outpath, "axion_image_%s.csv" % year)
+            flux = write_image_csv(out, img, full.setup.chip_x_max, r1w, r2w)
+            print("The total flux", flux)
+            print("wrote", out)
+        else:
+            angles, fluxes, rel = performAngularScan(rt, args.angularScanMin, args.angularScanMax, args.numAngularScanPoints, n,
+                                                     seed=args.seed, flags=flags)
+            out = os.path.join(args.outpath, "angular_scan_telescope_y.csv")   # the reference only saves the PDF of this curve
+            with open(out, "w") as f:
+                f.write("Angles [deg],Flux fraction,relative flux\n")
+                for a, fl, r in zip(angles, fluxes, rel):
+                    f.write("%r,%r,%r\n" % (float(a), float(fl), float(r)))
+            print("wrote", out)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

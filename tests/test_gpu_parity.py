@@ -433,3 +433,23 @@ def test_xmm_on_axis_effective_area_matches_published_values():
         assert s["N_SHELL_SELECTED"] / s["N_RAYS"] == pytest.approx(0.672, abs=5e-3)     # geometric open fraction of the aperture
     assert 1400.0 < got[1.5] < 1650.0, got
     assert 550.0 < got[8.0] < 750.0, got
+
+
+def test_command_line_full_run_and_angular_scan(tmp_path):
+    """`python -m solaraxionraytracing_amd` = the reference's `raytracer` binary: full run writes axion_image_IAXO.csv with
+    the reference's columns; --angularScanMin/Max runs performAngularScan."""
+    import subprocess
+    import sys
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, "-m", "solaraxionraytracing_amd", "--rays", "300000", "--outpath", str(out), "--noPlots"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Passed axions" in r.stdout and "The total flux" in r.stdout
+    lines = open(out / "axion_image_IAXO.csv").read().splitlines()
+    assert lines[0].startswith("x,y,photon flux,yr0,yr02") and len(lines) == 1 + 256 * 256
+    r = subprocess.run([sys.executable, "-m", "solaraxionraytracing_amd", "--rays", "200000", "--outpath", str(out), "--ignoreDetWindow",
+                        "--ignoreGasAbs", "--ignoreConvProb", "--angularScanMax", "0.05", "--numAngularScanPoints", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    scan = np.loadtxt(out / "angular_scan_telescope_y.csv", delimiter=",", skiprows=1)
+    assert scan.shape == (3, 3) and scan[0, 2] == 1.0 and scan[2, 2] < 1.0
