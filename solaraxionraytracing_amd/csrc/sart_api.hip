@@ -23,8 +23,6 @@ void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs&
 int histogram_block_of(int variant);
 void launch_trace_records(const HotA& H, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream);
-void set_histogram_block(int block);
-int histogram_block();
 int records_block();
 int histogram_blocks_per_cu(int variant);
 }  // namespace sart
@@ -95,7 +93,14 @@ struct sart_context {
   int device = 0;
   int n_cu = 0;
   int blocks_per_cu_hist[3] = {0, 0, 0}, blocks_per_cu_rec = 0;
-  bool env_read = false;
+  // tuning / experiment knobs, read from the environment once when the context is created
+  struct Knobs {
+    bool no_image_atomics = false;   // SART_DEBUG_NO_IMAGE_ATOMICS: timing experiment only (results are wrong)
+    bool no_early_reject = false;    // SART_NO_EARLY_REJECT: stage A0 off
+    bool force_generic = false;      // SART_FORCE_GENERIC: never use the specialised kernel variant
+    int image_replicas = 0;          // SART_IMAGE_REPLICAS: 0 = chosen from the plate scale
+    int hist_blocks_per_cu = 0;      // SART_HIST_BLOCKS_PER_CU: 0 = occupancy query
+  } knobs;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string device_name;
@@ -404,7 +409,7 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   a.seed_lo = static_cast<uint32_t>(p->seed);
   a.seed_hi = static_cast<uint32_t>(p->seed >> 32);
   a.flags = p->flags;
-  if (std::getenv("SART_DEBUG_NO_IMAGE_ATOMICS")) a.flags |= 0x40000000u;   // timing experiment only
+  if (c->knobs.no_image_atomics) a.flags |= 0x40000000u;
   a.image_nx = p->image_nx;
   a.image_ny = p->image_ny;
   a.image_x_min = p->image_x_min;
@@ -512,7 +517,7 @@ int sync_blob(sart_context* c) {
   b.T = tables_of(c);
   if (int rc = c->d_blob.upload(&b, 1)) return rc;
   c->hot = hot_of(c->params);
-  if (!std::getenv("SART_NO_EARLY_REJECT")) build_zones(c->setup, c->params, c->n_radii, c->hot);
+  if (!c->knobs.no_early_reject) build_zones(c->setup, c->params, c->n_radii, c->hot);
   c->blob_dirty = false;
   return 0;
 }
@@ -590,6 +595,15 @@ int sart_create(int device_ordinal, sart_context** out) {
     return fail(SART_ERR_NO_DEVICE, "hipStreamCreate failed");
   }
   c->stream = c->own_stream;
+  {
+    auto flag = [](const char* name) { return std::getenv(name) != nullptr; };
+    auto number = [](const char* name) { const char* e = std::getenv(name); return e ? std::max(0, std::atoi(e)) : 0; };
+    c->knobs.no_image_atomics = flag("SART_DEBUG_NO_IMAGE_ATOMICS");
+    c->knobs.no_early_reject = flag("SART_NO_EARLY_REJECT");
+    c->knobs.force_generic = flag("SART_FORCE_GENERIC");
+    c->knobs.image_replicas = number("SART_IMAGE_REPLICAS");
+    c->knobs.hist_blocks_per_cu = number("SART_HIST_BLOCKS_PER_CU");
+  }
   *out = c;
   return 0;
 }
@@ -799,7 +813,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
     // 128: 4.4, 512: 4.6 (3.99 ms with the atomics switched off).
     int R = spot_px > 96.0 ? 1 : 64;
     if (s.test_active) R = 64;
-    if (const char* e = std::getenv("SART_IMAGE_REPLICAS")) R = std::max(1, std::min(kMaxImageReplicas, std::atoi(e)));
+    if (c->knobs.image_replicas > 0) R = std::min(kMaxImageReplicas, c->knobs.image_replicas);
     while (R & (R - 1)) R &= R - 1;   // power of two
     if (R > 1) {
       const size_t n_img = static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny);
@@ -823,15 +837,11 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   // hole loop); 1 = generic, not rotated; 2 = generic, rotated
   const DevParams& P = c->params;
   const bool fast = !P.test_active && !P.rotated && !P.stage_gas && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) &&
-                    !std::getenv("SART_FORCE_GENERIC");
+                    !c->knobs.force_generic;
   const int variant = fast ? 0 : (P.rotated ? 2 : 1);
-  if (!c->env_read) {
-    if (const char* e = std::getenv("SART_HIST_BLOCK")) set_histogram_block(std::atoi(e));   // tuning knob
-    c->env_read = true;
-  }
   if (c->blocks_per_cu_hist[variant] == 0) {
     c->blocks_per_cu_hist[variant] = std::max(1, histogram_blocks_per_cu(variant));
-    if (const char* e = std::getenv("SART_HIST_BLOCKS_PER_CU")) c->blocks_per_cu_hist[variant] = std::max(1, std::atoi(e));
+    if (c->knobs.hist_blocks_per_cu > 0) c->blocks_per_cu_hist[variant] = c->knobs.hist_blocks_per_cu;
   }
   const int n_blocks = grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_hist[variant], histogram_block_of(variant));
   if (c->d_partials.n < static_cast<size_t>(n_blocks) * SART_ACC_COUNT) {

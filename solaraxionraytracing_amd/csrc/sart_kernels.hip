@@ -1047,58 +1047,28 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
 }
 
 // ---- launch wrappers (called from sart_api.hip) ----
-static int g_hist_block = 1024;
-void set_histogram_block(int block) { g_hist_block = block; }
-int histogram_block() { return g_hist_block; }
 int records_block() { return kRecBlock; }
-// Variants: 0 = FAST (1024 threads), 1 = generic, telescope not rotated (1024 threads), 2 = generic, rotated (768 threads:
-// ring 1 carries one more field).  SART_HIST_BLOCK overrides the block size of variants 0 / 1 for tuning.
-template <int BLOCK, bool FAST, bool ROT>
-static void launch_variant(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks, hipStream_t stream) {
-  hipLaunchKernelGGL((trace_histogram_kernel<BLOCK, FAST, ROT>), dim3(n_blocks), dim3(BLOCK), 0, stream, H, blob, A, acc);
-}
-int histogram_block_of(int variant) { return variant == 2 ? 768 : g_hist_block; }
+// Variants: 0 = FAST, 1 = generic with the telescope not rotated (both 1024 threads = 4 waves / SIMD: measured fastest of
+// 256 / 512 / 768 / 1024), 2 = generic, rotated (768 threads: ring 1 carries one more field and 16 waves' rings no longer fit).
+int histogram_block_of(int variant) { return variant == 2 ? 768 : 1024; }
 
 int histogram_blocks_per_cu(int variant) {
   int n = 0;
   hipError_t e;
   if (variant == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<768, false, true>, 768, 0);
-  else if (variant == 1) {
-    switch (g_hist_block) {
-      case 256: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<256, false, false>, 256, 0); break;
-      case 512: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<512, false, false>, 512, 0); break;
-      case 768: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<768, false, false>, 768, 0); break;
-      default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, false, false>, 1024, 0); break;
-    }
-  } else {
-    switch (g_hist_block) {
-      case 256: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<256, true, false>, 256, 0); break;
-      case 512: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<512, true, false>, 512, 0); break;
-      case 768: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<768, true, false>, 768, 0); break;
-      default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, true, false>, 1024, 0); break;
-    }
-  }
+  else if (variant == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, false, false>, 1024, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, true, false>, 1024, 0);
   return (e == hipSuccess && n > 0) ? n : 1;
 }
 
 void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
                             hipStream_t stream, int variant) {
-  if (variant == 2) launch_variant<768, false, true>(H, blob, A, acc, n_blocks, stream);
-  else if (variant == 1) {
-    switch (g_hist_block) {
-      case 256: launch_variant<256, false, false>(H, blob, A, acc, n_blocks, stream); break;
-      case 512: launch_variant<512, false, false>(H, blob, A, acc, n_blocks, stream); break;
-      case 768: launch_variant<768, false, false>(H, blob, A, acc, n_blocks, stream); break;
-      default: launch_variant<1024, false, false>(H, blob, A, acc, n_blocks, stream); break;
-    }
-  } else {
-    switch (g_hist_block) {
-      case 256: launch_variant<256, true, false>(H, blob, A, acc, n_blocks, stream); break;
-      case 512: launch_variant<512, true, false>(H, blob, A, acc, n_blocks, stream); break;
-      case 768: launch_variant<768, true, false>(H, blob, A, acc, n_blocks, stream); break;
-      default: launch_variant<1024, true, false>(H, blob, A, acc, n_blocks, stream); break;
-    }
-  }
+  if (variant == 2)
+    hipLaunchKernelGGL((trace_histogram_kernel<768, false, true>), dim3(n_blocks), dim3(768), 0, stream, H, blob, A, acc);
+  else if (variant == 1)
+    hipLaunchKernelGGL((trace_histogram_kernel<1024, false, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc);
+  else
+    hipLaunchKernelGGL((trace_histogram_kernel<1024, true, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc);
   const int n_img = A.image_nx * A.image_ny;
   hipLaunchKernelGGL(fold_scalars_kernel, dim3(1), dim3(256), 0, stream, acc + n_img, A.partials, n_blocks, (double)A.n_rays);
   if (A.replica_mask != 0u)
