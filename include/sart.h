@@ -196,7 +196,8 @@ typedef struct sart_axion_t {
 /* Parameters of one trace call. */
 typedef struct sart_trace_params_t {
   uint64_t n_rays;         /* bufLen of traceAxionWrapper                               */
-  uint64_t seed;           /* Philox4x32-10 key (replaces randomize(299792458), :276)    */
+  uint64_t seed;           /* Philox4x32-10 key (replaces randomize(299792458), :276); the six uniforms of a ray are a
+                              function of (seed, global ray id) only, see oracle/sart_oracle.c: sart_oracle_uniforms */
   uint64_t ray_id_offset;  /* global id of ray 0 of this call: counter = offset + i      */
   uint32_t flags;          /* SART_CF_* bitset                                          */
   int32_t image_nx;        /* columns (x bins) of the focal-plane image, 256 in :2629    */

@@ -91,7 +91,8 @@ static inline real rad_to_deg(real r) { return r / RAD_PER_DEG; }
  * RNG: Philox4x32-10 (Salmon et al., SC'11), key = (seed lo, seed hi),
  * counter = (ray id lo, ray id hi, block, 0).  Uniform k of a ray is built from words
  * (2k, 2k+1) of blocks 0..2 by mantissa fill, exactly as Nim's rand(1.0) turns its 64 random bits
- * into a float in [0, 1).
+ * into a float in [0, 1) — except the high word of u3, which comes from a word stream shared by
+ * consecutive rays (see sart_oracle_uniforms).
  * ---------------------------------------------------------------------------------------- */
 static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                  uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -114,6 +115,16 @@ void sart_oracle_uniforms(uint64_t seed, uint64_t ray_id, double u[6]) {
   for (uint32_t b = 0; b < 3; ++b)
     philox4x32_10((uint32_t)ray_id, (uint32_t)(ray_id >> 32), b, 0u, (uint32_t)seed,
                   (uint32_t)(seed >> 32), &w[4 * b]);
+  /* The high word of u3 (the uniform behind the radius of the point on the bore exit, :418) is word `ray_id` of a
+   * word stream with random access: stream[n] = word (n & 3) of the block with counter (n >> 2, 3, 0).  Four
+   * consecutive rays share that block, which is what lets the HIP kernel's first stage (rays that this word alone
+   * proves dead) cost a quarter of a Philox block per ray.  The low 20 bits stay the ray's own. */
+  {
+    uint32_t sh[4];
+    const uint64_t g = ray_id >> 2;
+    philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 3u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), sh);
+    w[6] = sh[ray_id & 3u];
+  }
   for (int k = 0; k < 6; ++k) {
     /* 52 random mantissa bits under the exponent of 1.0, minus 1.0: Nim's std/random rand(1.0) */
     uint64_t bits = ((uint64_t)w[2 * k] << 32) | (uint64_t)w[2 * k + 1];

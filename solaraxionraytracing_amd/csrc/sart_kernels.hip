@@ -54,6 +54,19 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
   return U4{c0, c1, c2, c3};
 }
 
+// Word n of the shared word stream behind the high word of u3: word (n & 3) of the Philox block with counter
+// (n >> 2, 3, 0).  Four consecutive ray ids share one block (stage A0 computes it once per lane for four rays).
+__device__ __forceinline__ U4 stream_block(uint64_t group, uint32_t k0, uint32_t k1) {
+  return philox4x32_10((uint32_t)group, (uint32_t)(group >> 32), 3u, 0u, k0, k1);
+}
+__device__ __forceinline__ uint32_t word_of(const U4& b, uint32_t k) {
+  return k == 0u ? b.x : (k == 1u ? b.y : (k == 2u ? b.z : b.w));
+}
+
+// Lane mask of a predicate.  HIP's __ballot() materialises the predicate as 0 / 1 and compares again (two VALU
+// instructions); the builtin takes the compare's lane mask as it is.
+__device__ __forceinline__ uint64_t ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 // Uniform in [0, 1) from two words (hi word first): 52 random mantissa bits under the exponent of 1.0,
 // minus 1.0 — the construction of Nim's std/random rand(1.0) (and of the oracle).
 __device__ __forceinline__ double u52(uint32_t hi, uint32_t lo) {
@@ -224,7 +237,7 @@ __device__ __forceinline__ double reflect(double& wx, double& wy, double& wz, do
   wx = fma(-2.0 * f, nx, ox);                // mirror reflection (normal on the far side of the ray: n.w >= 0)
   wy = fma(-2.0 * f, ny, oy);
   wz = fma(-2.0 * f, nz, oz);
-  if (__ballot(dnw < 0.0)) {                 // wave-uniform; practically never taken
+  if (ballot64(dnw < 0.0)) {                 // wave-uniform; practically never taken
     // normal facing the ray: the reference's formula is then not a mirror reflection; keep it
     const double k = 1.0 - 4.0 * c2;
     if (dnw < 0.0) {
@@ -318,7 +331,8 @@ __device__ __forceinline__ double cos_n_phi(int n, double c) {
 // ROT: telescope rotation known at compile time (0 / 1) or read at run time (-1).
 template <bool FAST, int ROT>
 __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const LdsTables& L, uint32_t seed_lo,
-                                        uint32_t seed_hi, uint64_t ray_id, RayState& st, bool& sampled, bool& reached) {
+                                        uint32_t seed_hi, uint64_t ray_id, uint32_t u3_hi, RayState& st, bool& sampled,
+                                        bool& reached) {
   static_assert(!(FAST && ROT != 0), "FAST implies an unrotated telescope");
   const bool cfg_test = FAST ? false : (H.test_active != 0);
   const bool cfg_rotated = (ROT < 0) ? (H.rotated != 0) : (ROT != 0);
@@ -328,7 +342,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, seed_lo, seed_hi);
   const U4 b2 = philox4x32_10(id_lo, id_hi, 2u, 0u, seed_lo, seed_hi);
   const double u0 = u52(b0.x, b0.y), u1 = u52(b0.z, b0.w);
-  const double u2 = u52(b1.x, b1.y), u3 = u52(b1.z, b1.w);
+  const double u2 = u52(b1.x, b1.y), u3 = u52(u3_hi, b1.w);   // u3_hi = word ray_id of the shared stream
   const double u4 = u52(b2.x, b2.y);
   st.u5 = u52(b2.z, b2.w);
   st.r_idx = 0;
@@ -397,7 +411,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   const double x0 = fma(-H.length_b, sx, ex), y0 = fma(-H.length_b, sy, ey);
   const bool hits_entrance = fma(x0, x0, y0 * y0) < H.radius_cb_sq;
   double path_cb = H.length_b * norm;          // |exit point - entrance-plane point| (:1836-1843)
-  if (__ballot(ok && !hits_entrance)) {        // wave-uniform: some ray entered through the bore wall
+  if (ballot64(ok && !hits_entrance)) {        // wave-uniform: some ray entered through the bore wall
     // lineIntersectsCylinderOnce (:591-604): intersections of the line with the bore wall,
     // t = z - lengthB:  A2 t^2 + 2 Dm t + (Qm - R^2) = 0.  inter1 = larger z, inter2 = smaller z.
     const double Dm = fma(ex, sx, ey * sy);
@@ -558,7 +572,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const double m1x = fma(z1, tsx, X0), m1y = fma(z1, tsy, Y0);
   // on the surface the normal's z-component is closed-form: cone tan(b) rho(z); paraboloid r3 tan(b)
   double n1z = wolter ? sh.n1_r3t : sh.n1_tan * fma(-sh.n1_tan, z1, sh.r1);
-  if (__ballot(live && !hit1)) {              // wave-uniform: the normal at the (off-surface) input point
+  if (ballot64(live && !hit1)) {              // wave-uniform: the normal at the (off-surface) input point
     const double g = normal_z_general(P, sh, 1, m1x, m1y, z1);
     n1z = hit1 ? n1z : g;
   }
@@ -571,7 +585,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   {
     const double lz = P.l_mirror - z1, num = sh.nickel_num;
     bool nick = sin2_a1 * fma(lz, lz, num * num) > num * num;
-    if (__ballot(!(lz > 0.0))) {               // wave-uniform; only for a missed mirror with z1 >= l (never in practice)
+    if (ballot64(!(lz > 0.0))) {               // wave-uniform; only for a missed mirror with z1 >= l (never in practice)
       if (!(lz > 0.0)) nick = fsqrt(sin2_a1 / (1.0 - sin2_a1)) > num / lz;
     }
     out.hit_nickel = live && (st.shell > 0) && nick;
@@ -741,7 +755,8 @@ struct __align__(16) QueueLds {
   double path[WAVES][kQueue], u5[WAVES][kQueue];
   double zcb[ROT ? WAVES : 1][kQueue];    // z of pointExitCB: constant unless the telescope is rotated
   int idx[WAVES][kQueue];                 // r_idx | shell << 16
-  uint32_t ray[WAVES][kQueue];            // ring 0: launch indices of rays that passed stage A0
+  uint32_t ray[WAVES][kQueue];            // ring 0: rays that passed stage A0 (ray id relative to the launch's first chunk)
+  uint32_t u3hi[WAVES][kQueue];           //         and their word of the shared stream (high word of u3)
 };
 
 template <int BLOCK>
@@ -761,10 +776,12 @@ __device__ __forceinline__ void stage_tables(TablesLds& S, const DevParams& P, c
 // Fused trace + accumulate (traceAxionWrapper + prepareHeatmap + flux sum + counters) as a three-stage
 // pipeline inside one persistent wave, with wavefront compaction (ballot + prefix count into per-wave LDS
 // rings) between the stages:
-//   A0  one Philox block -> radius of the point on the bore exit -> provably dead rays leave (HotA zones)
+//   A0  word of the shared stream -> radius of the point on the bore exit -> provably dead rays leave (HotA zones)
 //   A1  phase A (full sampling + cuts + shell selection) on full waves of A0 survivors
 //   B   phase B (mirrors + weights + accumulation) on full waves of A1 survivors
-// Ray i of this launch has the global id ray_id_offset + i; n_rays < 2^32 per launch.
+// Rays are taken in chunks of 256 consecutive global ids, aligned to 256: lane l of the wave that owns a chunk handles
+// ids 4l .. 4l+3 of it in four successive passes, so that the one block of the shared word stream it computes (stage A0's
+// only Philox block) serves all four.  Ray i of this launch has the global id ray_id_offset + i; n_rays < 2^31 per launch.
 // FAST: solar source, vacuum, no hole loop, telescope not rotated (all known at compile time).  ROT: rotated telescope
 // (ring 1 then also carries z of pointExitCB; 768 threads so that the rings still fit the LDS).
 // Re-reads the HotA block (the first kernel argument) from the kernel-argument segment with scalar loads.  The pointer
@@ -777,6 +794,23 @@ __device__ __forceinline__ void reload_hot(HotA& dst) {
   uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
 #pragma unroll
   for (int k = 0; k < (int)(sizeof(HotA) / 4); ++k) d[k] = p[k];
+}
+
+// Same for the zone table of stage A0 (the tail of HotA): ten scalar registers that would otherwise be spilled and
+// reloaded through VGPR lanes in every pass.
+struct ZoneTable {
+  int32_t n_zones;
+  uint32_t zone_reached;
+  uint32_t lo[kMaxZones], hi[kMaxZones];
+};
+static_assert(sizeof(ZoneTable) == sizeof(HotA) - offsetof(HotA, n_zones), "ZoneTable mirrors the tail of HotA");
+__device__ __forceinline__ void reload_zones(ZoneTable& dst) {
+  typedef const __attribute__((address_space(4))) uint32_t* kernarg_ptr;
+  kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(HotA, n_zones) / 4;
+  asm volatile("" : "+s"(p));
+  uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(ZoneTable) / 4); ++k) d[k] = p[k];
 }
 
 template <int BLOCK, bool FAST, bool ROT>
@@ -806,6 +840,12 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   const uint64_t waves_total = (uint64_t)gridDim.x * (BLOCK / 64);
   const uint64_t wave_global = (uint64_t)blockIdx.x * (BLOCK / 64) + wave;
   const bool early_reject = H.n_zones > 0;   // wave-uniform; the host builds no zones for the X-ray test source
+  // chunks of 256 ids aligned in global-id space; `rel` = id - id_base (fits 32 bits: n_rays < 2^31)
+  const uint64_t first_chunk = A.ray_id_offset >> 8;
+  const uint64_t id_base = first_chunk << 8;
+  const uint32_t rel_begin = (uint32_t)(A.ray_id_offset & 255u);
+  const uint32_t rel_end = rel_begin + (uint32_t)A.n_rays;          // one past the last ray (n_rays < 2^31)
+  const uint32_t n_chunks = (rel_end + 255u) >> 8;
   // this wave's replica of the image
   double* const img = A.replicas + (size_t)((uint32_t)wave_global & A.replica_mask) * (size_t)A.replica_stride;
 
@@ -825,16 +865,16 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
   };
 
-  // stage A1 for the ray with launch index i (valid lanes only count)
-  auto run_phase_a = [&](uint64_t i, bool valid) {
+  // stage A1 for the ray with id id_base + rel (valid lanes only count); u3_hi = its word of the shared stream
+  auto run_phase_a = [&](uint32_t rel, bool valid, uint32_t u3_hi) {
     RayState st;
     bool sampled = false, reached = false;
     HotA Hl;
     reload_hot(Hl);
-    const bool ok = phase_a<FAST, ROT ? 1 : 0>(Hl, Pb, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
+    const bool ok = phase_a<FAST, ROT ? 1 : 0>(Hl, Pb, L, A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi, st, sampled, reached);
     const bool alive = valid && ok;
-    n_reached += (uint32_t)__popcll(__ballot(valid && reached));
-    const uint64_t mask = __ballot(alive);
+    n_reached += (uint32_t)__popcll(ballot64(valid && reached));
+    const uint64_t mask = ballot64(alive);
     const uint32_t cnt = (uint32_t)__popcll(mask);
     n_shell += cnt;
     if (alive) {
@@ -867,10 +907,10 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       phase_b<false, FAST>(Pb, L, Tb, Ab, st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
     }
     h1 += n_valid;
-    n_nickel += (uint32_t)__popcll(__ballot(out.hit_nickel));
-    n_till += (uint32_t)__popcll(__ballot(out.till_window));
+    n_nickel += (uint32_t)__popcll(ballot64(out.hit_nickel));
+    n_till += (uint32_t)__popcll(ballot64(out.till_window));
     const bool passed = out.finished && out.weight != 0.0;
-    n_passed += (uint32_t)__popcll(__ballot(passed));
+    n_passed += (uint32_t)__popcll(ballot64(passed));
     if (passed) {
       sum_w += out.weight;
       sum_w2 = fma(out.weight, out.weight, sum_w2);
@@ -897,36 +937,47 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         unsafeAtomicAdd(&en[2 * ne1 + out.e_idx], out.reflect);
       }
     }
-    n_outside += (uint32_t)__popcll(__ballot(out.outside));
+    n_outside += (uint32_t)__popcll(ballot64(out.outside));
   };
 
-  uint64_t base = wave_global * 64;
+  uint32_t chunk = (uint32_t)wave_global;                            // relative to first_chunk (wave-uniform)
+  const uint32_t lane4 = 4u * (uint32_t)lane;
+  uint32_t pass = 0;                                                 // 0..3: which of its four ids a lane handles now
+  U4 stream = U4{0u, 0u, 0u, 0u};                                    // this lane's block of the shared word stream
   for (;;) {
-    const bool have_new = base < A.n_rays;   // wave-uniform
+    const bool have_new = chunk < n_chunks;   // wave-uniform
     if (have_new) {
-      const uint64_t i = base + (uint64_t)lane;
-      const bool valid = i < A.n_rays;
+      if (pass == 0u) stream = stream_block(((first_chunk + (uint64_t)chunk) << 6) + (uint64_t)lane, A.seed_lo, A.seed_hi);
+      const uint32_t w = word_of(stream, pass);                      // high word of u3 (:418) of this pass' ray
+      const uint32_t rel = ((chunk << 8) + pass) + lane4;
+      const bool valid = rel >= rel_begin && rel < rel_end;
       if (early_reject) {
-        // ---- stage A0: hi word of u3 (word 2 of Philox block 1) against the zones ----
-        const uint64_t ray_id = A.ray_id_offset + i;
-        const U4 b1 = philox4x32_10((uint32_t)ray_id, (uint32_t)(ray_id >> 32), 1u, 0u, A.seed_lo, A.seed_hi);
-        const uint32_t w = b1.z;
-        bool dead = false, dead_reached = false;
+        // ---- stage A0: the word against the zones (lane masks and scalar arithmetic only) ----
+        ZoneTable Z;
+        reload_zones(Z);
+        // lane masks of direct compares (v_cmp writes them) and scalar arithmetic on the masks
+        uint64_t dead_m = 0, reached_m = 0;
 #pragma unroll
-        for (int z = 0; z < kMaxZones; ++z) {   // fully unrolled: the zone bounds stay in SGPRs (unused zones are empty: lo > hi)
-          const bool in = (w >= H.zone_lo[z]) && (w <= H.zone_hi[z]);
-          dead = dead || in;
-          dead_reached = dead_reached || (in && ((H.zone_reached >> z) & 1u));
+        for (int z = 0; z < kMaxZones; ++z) {   // unused zones are empty: lo > hi
+          const uint64_t in = ballot64(w >= Z.lo[z]) & ballot64(w <= Z.hi[z]);
+          dead_m |= in;
+          reached_m |= ((Z.zone_reached >> z) & 1u) ? in : 0ull;      // wave-uniform select
         }
-        n_reached += (uint32_t)__popcll(__ballot(valid && dead_reached));
-        const bool go = valid && !dead;
-        const uint64_t mask = __ballot(go);
-        if (go) Q.ray[wave][(t0 + prefix_of(mask)) % kQueue] = (uint32_t)i;
+        const uint64_t valid_m = ballot64(rel >= rel_begin) & ballot64(rel < rel_end);
+        n_reached += (uint32_t)__popcll(valid_m & reached_m);
+        const uint64_t mask = valid_m & ~dead_m;
+        const bool go = (mask >> lane) & 1ull;
+        if (go) {
+          const uint32_t slot = (t0 + prefix_of(mask)) % kQueue;
+          Q.ray[wave][slot] = rel;
+          Q.u3hi[wave][slot] = w;
+        }
         t0 += (uint32_t)__popcll(mask);
       } else {
-        run_phase_a(i, valid);   // no early-rejection stage for this configuration
+        run_phase_a(rel, valid, w);   // no early-rejection stage for this configuration
       }
-      base += waves_total * 64;
+      pass = (pass + 1u) & 3u;
+      if (pass == 0u) chunk += (uint32_t)waves_total;
       ring_sync();
     }
     if (early_reject) {
@@ -935,9 +986,11 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       if (n0 >= 64u || (!have_new && n0 > 0u)) {
         const uint32_t m = min(n0, 64u);
         const bool v = (uint32_t)lane < m;
-        const uint32_t idx = v ? Q.ray[wave][(h0 + (uint32_t)lane) % kQueue] : 0u;
+        const uint32_t slot = (h0 + (uint32_t)lane) % kQueue;
+        const uint32_t rel = v ? Q.ray[wave][slot] : 0u;
+        const uint32_t w = v ? Q.u3hi[wave][slot] : 0u;
         h0 += m;
-        run_phase_a((uint64_t)idx, v);
+        run_phase_a(rel, v, w);
         ring_sync();
       }
     }
@@ -1030,14 +1083,16 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
     sart_axion_t rec = {};   // newSeq[Axion] zero-initialises (:2760)
     RayState st;
     bool sampled, reached;
-    const bool alive = phase_a<false, -1>(H, P, L, A.seed_lo, A.seed_hi, A.ray_id_offset + i, st, sampled, reached);
+    const uint64_t ray_id = A.ray_id_offset + i;
+    const uint32_t u3_hi = word_of(stream_block(ray_id >> 2, A.seed_lo, A.seed_hi), (uint32_t)ray_id & 3u);
+    const bool alive = phase_a<false, -1>(H, P, L, A.seed_lo, A.seed_hi, ray_id, u3_hi, st, sampled, reached);
     int e_idx = -1;
     if (sampled) {
       e_idx = H.test_active ? P.n_energies : sample_energy_index(P, T, st.r_idx, st.u5);
       rec.emratesPre = 1.0;                          // :1818
       rec.energiesPre = load_energy_row(T, e_idx).energy;  // :1819
     }
-    if (__ballot(alive)) {
+    if (ballot64(alive)) {
       RayOut ro;
       if (!sampled) { st.u5 = 0.0; st.r_idx = 0; }
       phase_b<true, false>(P, L, T, A, st, e_idx >= 0 ? e_idx : 0, alive, ro, &rec);

@@ -48,7 +48,7 @@ def test_records_match_f64_oracle_within_its_noise(name):
     with sa.RayTracer(full) as rt:
         rec = rt.traceAxionWrapper(N_REC, seed=42)
     ref = Oracle(full, "f64").trace_records(N_REC, seed=42)
-    compare_records(rec, _as_gold(ref), POS_TOL_MM, WEIGHT_RTOL, FLAG_MISMATCH_MAX)
+    compare_records(rec, _as_gold(ref), POS_TOL_MM, WEIGHT_RTOL, FLAG_MISMATCH_MAX, pos_outliers=2e-5)
 
 
 @pytest.mark.parametrize("name", SETUP_NAMES)
@@ -408,8 +408,9 @@ def test_high_resolution_heatmap_and_y_slice():
     want, _ = np.histogram(y[sel], bins=edges, weights=w[sel])
     assert flux.size == 14000 and sel.sum() > 50
     assert flux.sum() == pytest.approx(want.sum(), rel=2e-2)          # rays within the oracle's f64 noise of the slice edge may flip
-    # same rays land in the same 0.001 mm bins up to that noise: compare on 0.05 mm bins
-    np.testing.assert_allclose(flux.reshape(280, 50).sum(axis=1), want.reshape(280, 50).sum(axis=1), atol=0.06 * want.max() + 1e-300, rtol=0.1)
+    # same rays land in the same 0.001 mm bins up to that noise: the two cumulative distributions along y never differ
+    # by more than a few rays' weight
+    assert np.abs(np.cumsum(flux) - np.cumsum(want)).max() <= 4.0 * w[sel].max()
 
 
 def test_xmm_on_axis_effective_area_matches_published_values():
