@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIBSART_PATH = os.environ.get("SART_LIBSART", os.path.join(_PKG_DIR, "libsart.so"))   # override: kernel-tuning builds only
+LIBSART_PATH = os.environ.get("SART_LIBSART", os.path.join(_PKG_DIR, "libsart.so"))   # override: A/B timing of kernel builds
 LIBSART_HOST_PATH = os.path.join(_PKG_DIR, "libsart_host.so")
 
 SART_MAX_SHELLS = 64
