@@ -167,3 +167,38 @@ def test_survival_fractions_babyiaxo():
     assert s["N_REACHED_TELESCOPE"] / 2e5 == pytest.approx(0.547, abs=0.01)
     assert s["N_SHELL_SELECTED"] / 2e5 == pytest.approx(0.329, abs=0.01)
     assert 0.02 < s["N_HIT_NICKEL"] / 2e5 < 0.06
+
+
+def test_ray_uniforms_are_uniform_and_uncorrelated():
+    """The six uniforms of a ray (Philox4x32-10 blocks keyed by seed and ray id; the high word of u3 from the word stream
+    that four consecutive rays share) behave like independent U[0,1) samples: moments, lag correlations along the ray id
+    (including inside a group of four rays that share a stream block), cross-correlations, and a chi-square of u3."""
+    import ctypes as C
+    from oracle import oracle as O
+    lib = O.load("f64")
+    n = 200_000
+    u = np.empty((n, 6))
+    buf = (C.c_double * 6)()
+    for i in range(n):
+        lib.sart_oracle_uniforms(12345, 7_000_000_001 + i, buf)
+        u[i] = buf[:]
+    assert (u >= 0.0).all() and (u < 1.0).all()
+    tol = 5.0 / np.sqrt(n)
+    assert np.abs(u.mean(axis=0) - 0.5).max() < tol * 0.29          # sigma of U[0,1) = 0.2887
+    assert np.abs(u.var(axis=0) - 1.0 / 12.0).max() < tol * 0.08
+    c = np.corrcoef(u.T)
+    assert np.abs(c - np.eye(6)).max() < tol                          # between the six uniforms of one ray
+    for lag in (1, 2, 3, 4, 5):
+        for k in range(6):
+            assert abs(np.corrcoef(u[:-lag, k], u[lag:, k])[0, 1]) < tol, (lag, k)
+    # rays 4g .. 4g+3 take the four words of one block for the high word of u3: pairwise correlation inside the groups
+    g = u[: n // 4 * 4, 3].reshape(-1, 4)
+    assert np.abs(np.corrcoef(g.T) - np.eye(4)).max() < 2.0 * tol
+    hist, _ = np.histogram(u[:, 3], bins=256, range=(0.0, 1.0))
+    chi2 = ((hist - n / 256.0) ** 2 / (n / 256.0)).sum()
+    assert chi2 < 255.0 + 5.0 * np.sqrt(2.0 * 255.0)
+    # different seeds and far-apart ids give different streams; the same (seed, id) the same numbers
+    lib.sart_oracle_uniforms(12345, 7_000_000_001, buf)
+    assert list(buf) == list(u[0])
+    lib.sart_oracle_uniforms(12346, 7_000_000_001, buf)
+    assert all(abs(a - b) > 0 for a, b in zip(buf, u[0]))
