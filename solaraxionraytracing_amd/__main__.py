@@ -65,6 +65,8 @@ def main(argv=None) -> int:
             print("Passed axions", int(s["N_PASSED"]))
             print("Passed axions until the Window", int(s["N_PASSED_TILL_WINDOW"]))
             print("Number of X-rays hitting nickel:", int(s["N_HIT_NICKEL"]))
+            if s["N_PASSED"] > 0:   # means of the passed rays' detector coordinates (:2276-2278)
+                print("mean x %.6f mean y %.6f mean r %.6f" % tuple(s[k] / s["N_PASSED"] for k in ("SUM_X", "SUM_Y", "SUM_R")))
             r1, r2, r1w, r2w = containment_radii(spec)
             print("rSigma1 %.4f rSigma2 %.4f rSigma1W %.4f rSigma2W %.4f" % (r1, r2, r1w, r2w))
             year = WINDOW_YEAR.get(full.setup.detector_kind, "IAXO")
