@@ -454,3 +454,24 @@ def test_command_line_full_run_and_angular_scan(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     scan = np.loadtxt(out / "angular_scan_telescope_y.csv", delimiter=",", skiprows=1)
     assert scan.shape == (3, 3) and scan[0, 2] == 1.0 and scan[2, 2] < 1.0
+
+
+@pytest.mark.parametrize("name", ["babyiaxo_xmm", "cast_llnl"])
+def test_specialised_and_generic_kernel_variants_agree(name):
+    """The compile-time specialised instantiation (solar source, telescope not rotated, vacuum, no hole loop) and the generic
+    one are the same source: same rays, same counters, same image (SART_FORCE_GENERIC is read when a context is created)."""
+    import os
+    full = make_setup(name)
+    n = 5_000_000
+    with sa.RayTracer(full) as rt:
+        img_a, s_a = rt.trace_histogram(n, seed=23, ray_id_offset=777)
+    os.environ["SART_FORCE_GENERIC"] = "1"
+    try:
+        with sa.RayTracer(full) as rt:
+            img_b, s_b = rt.trace_histogram(n, seed=23, ray_id_offset=777)
+    finally:
+        del os.environ["SART_FORCE_GENERIC"]
+    for k in ("N_RAYS", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW", "N_PASSED", "N_OUTSIDE_IMAGE"):
+        assert s_a[k] == s_b[k], k
+    assert s_a["SUM_WEIGHTS"] == pytest.approx(s_b["SUM_WEIGHTS"], rel=1e-12)
+    np.testing.assert_allclose(img_a, img_b, rtol=1e-9, atol=img_b.max() * 1e-13)
