@@ -102,6 +102,38 @@ def test_emission_entry_points_fail_without_context():
     assert rc == L.SART_ERR_INVALID_ARGUMENT and b"ctx" in lib.sart_last_error()
 
 
+GOLD = tables.DATA_DIR + "/../../tests/golden/emission_agss09.npz"
+
+
+def test_emission_oracle_reproduces_golden():
+    """tests/golden/emission_agss09.npz (tools/make_golden.py): guards the oracle and the solar-profile data against drift."""
+    g = np.load(GOLD)
+    rs, es = int(g["r_stride"]), int(g["e_stride"])
+    zones = em.solar_zones()
+    _, energies = tables.solar_grid()
+    np.testing.assert_array_equal(np.array([z.temp_index for z in zones])[::rs], g["zone_temp_index"])
+    np.testing.assert_allclose(np.array([z.n_e for z in zones])[::rs], g["zone_n_e"], rtol=1e-14)
+    total, comp = O.emission_table(zones, energies, em.default_params(), components=True, r_stride=rs, e_stride=es)
+    np.testing.assert_allclose(comp[:, ::rs, ::es], g["components"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(total[::rs, ::es], g["total"], rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+def test_emission_kernel_matches_golden():
+    g = np.load(GOLD)
+    rs, es = int(g["r_stride"]), int(g["e_stride"])
+    zones = em.solar_zones()
+    _, energies = tables.solar_grid()
+    total, comp = em.emission_table(zones, energies, components=True)
+    want = g["components"]
+    for k, name in enumerate(L.EM_TERMS):
+        tol = RTOL_PRIMAKOFF if name == "primakoff" else (RTOL_FNEW_TERMS if name in ("ee_brems", "free_free") else RTOL_CLOSED_FORM)
+        scale = np.abs(want[k]).max()
+        err = np.abs(comp[k][::rs, ::es] - want[k]) / np.maximum(np.abs(want[k]), scale * 1e-30 + 1e-300)
+        assert err.max() < tol, (name, float(err.max()))
+    np.testing.assert_allclose(total[::rs, ::es], g["total"], rtol=RTOL_FNEW_TERMS, atol=0)
+
+
 # ---------------------------------------------------------------------------------------------------------------- GPU
 def _compare(got, want, sel_r, sel_e):
     worst = {}
