@@ -521,3 +521,28 @@ def test_randomised_geometries_against_binary128_oracle(case):
     _, osum, _ = Oracle(full, "f64").trace_histogram(n, seed=seed, ray_id_offset=off)
     for k in ("N_REACHED_TELESCOPE", "N_SHELL_SELECTED"):
         assert abs(summ[k] - osum[k]) <= 2, (k, summ[k], osum[k])      # f64 oracle: a ray within its noise of an edge may flip
+
+
+@pytest.mark.parametrize("hole_type,n_holes,size", [("HT_CIRCLE", 1, 20.0), ("HT_CROSS", 5, 3.0), ("HT_STAR", 3, 4.0),
+                                                    ("HT_SQUARE", 1, 25.0), ("HT_DIAMOND", 5, 15.0)])
+def test_hole_loop_of_the_xmm_inner_disc(hole_type, n_holes, size):
+    """The hole loop of lineIntersectsOpaqueTelescopeStructures (:1675-1688, lineIntersectsObject :494-527) only runs for an
+    XMM-type optic with a hole type other than htNone — no shipped setup has one, so it is exercised here with each type:
+    rays through a hole in the inner disc go on (and then miss every shell), all others behave as before."""
+    from oracle.oracle import Oracle
+    full = make_setup("babyiaxo_xmm")
+    full.setup.hole_type = getattr(L, hole_type)
+    full.setup.number_of_holes = n_holes
+    full.setup.hole_in_optics = size
+    n = 60_000
+    with sa.RayTracer(full) as rt:
+        rec = rt.traceAxionWrapper(n, seed=31)
+        _, summ = rt.trace_histogram(n, seed=31)
+    with sa.RayTracer(make_setup("babyiaxo_xmm")) as rt:
+        _, closed = rt.trace_histogram(n, seed=31)
+    assert summ["N_SHELL_SELECTED"] > closed["N_SHELL_SELECTED"]      # some rays do go through the hole(s)
+    ref = Oracle(full, "q").trace_records(n, seed=31)
+    compare_records(rec, _as_gold(ref), 1e-9, 2e-8, 0.0)
+    for f in ("passed", "passedTillWindow", "hitNickel"):
+        np.testing.assert_array_equal(rec[f], ref[f])
+    assert summ["N_PASSED"] == int(ref["passed"].sum())
