@@ -25,6 +25,11 @@ pytestmark = pytest.mark.gpu
 N_REC = 60_000
 
 
+def _small():
+    from tests.conftest import SMALL
+    return dict(SMALL)
+
+
 def _as_gold(rec):
     return {"rec_" + n: rec[n] for n in rec.dtype.names}
 
@@ -546,3 +551,39 @@ def test_hole_loop_of_the_xmm_inner_disc(hole_type, n_holes, size):
     for f in ("passed", "passedTillWindow", "hitNickel"):
         np.testing.assert_array_equal(rec[f], ref[f])
     assert summ["N_PASSED"] == int(ref["passed"].sum())
+
+
+@pytest.mark.parametrize("variant", ["divergent", "divergent_collimated", "cast_parallel_on_axis", "flags_all_ignored"])
+def test_xray_test_source_variants(variant):
+    """The branches of the X-ray test source (:1765-1806) the shipped defaults do not reach: a divergent source (points on
+    the source disc joined to points on the bore exit, :1794-1797), the collimator cut (:1800), the CAST source moved onto
+    the axis, and every ignore-flag at once."""
+    from oracle.oracle import Oracle
+    src = L.TestSourceConfig()
+    src.active, src.activity = 1, 0.125
+    flags = L.CF_XRAY_TEST
+    if variant == "divergent":
+        src.parallel, src.energy, src.distance, src.radius, src.lengthCol = 0, 2.5, 1.0e6, 100.0, 0.0
+        full = sa.initFullSetup(flags=flags, source_cfg=src, **_small())
+    elif variant == "divergent_collimated":
+        src.parallel, src.energy, src.distance, src.radius, src.lengthCol = 0, 1.0, 5.0e5, 300.0, 2.5e5
+        full = sa.initFullSetup(flags=flags, source_cfg=src, **_small())
+    elif variant == "cast_parallel_on_axis":
+        src.parallel, src.energy, src.distance, src.radius, src.lengthCol = 1, 3.0, 100.0, 10.0, 50.0
+        full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, flags=flags, source_cfg=src, **_small())
+    else:
+        flags |= L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS | L.CF_IGNORE_CONV_PROB | L.CF_IGNORE_REFLECTION
+        src.parallel, src.energy, src.distance, src.radius, src.lengthCol = 1, 4.0, 2000.0, 350.0, 0.0
+        full = sa.initFullSetup(flags=flags, source_cfg=src, **_small())
+    n = 50_000
+    with sa.RayTracer(full) as rt:
+        rec = rt.traceAxionWrapper(n, seed=77, flags=flags)
+        _, summ = rt.trace_histogram(n, seed=77, flags=flags)
+    ref = Oracle(full, "q").trace_records(n, seed=77, flags=flags)
+    assert ref["passed"].sum() > 500, int(ref["passed"].sum())          # the variant does send rays to the detector
+    compare_records(rec, _as_gold(ref), 1e-9, 2e-8, 0.0)
+    for f in ("passed", "passedTillWindow", "hitNickel"):
+        np.testing.assert_array_equal(rec[f], ref[f])
+    assert summ["N_PASSED"] == int(ref["passed"].sum())
+    if variant == "flags_all_ignored":
+        np.testing.assert_allclose(rec["weights"][rec["passed"] == 1], 1.0, rtol=1e-5)   # only cos(yaw) is left (:1598)
