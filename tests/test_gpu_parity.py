@@ -587,3 +587,38 @@ def test_xray_test_source_variants(variant):
     assert summ["N_PASSED"] == int(ref["passed"].sum())
     if variant == "flags_all_ignored":
         np.testing.assert_allclose(rec["weights"][rec["passed"] == 1], 1.0, rtol=1e-5)   # only cos(yaw) is left (:1598)
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_randomised_detector_side_against_binary128_oracle(case):
+    """Same idea for the detector side: detector kind (window angle 30 / 20 degrees), number of strongback strips and open
+    aperture (calcWindowVals), window radius, distance window - focal plane, pipe turn angle (LLNL), detector depth."""
+    import ctypes as C
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(2000 + case)
+    tel, exp = [(L.TK_XMM, L.ES_BABYIAXO), (L.TK_LLNL, L.ES_CAST), (L.TK_ABRIXAS, L.ES_CAST)][case % 3]
+    det = [L.DK_INGRID2017, L.DK_INGRID2018, L.DK_INGRIDIAXO][int(rng.integers(0, 3))]
+    full = sa.initFullSetup(exp, det, L.SK_VACUUM, tel, **_small())
+    s = full.setup
+    s.radius_window = rng.uniform(4.0, 9.0)
+    s.number_of_strips = int(rng.integers(2, 9))
+    s.open_aperture_ratio = rng.uniform(0.7, 0.95)
+    w, d = C.c_double(), C.c_double()
+    assert L.load_host().sart_host_calc_window_vals(s.radius_window, s.number_of_strips, s.open_aperture_ratio, C.byref(w), C.byref(d)) == 0
+    s.strip_width_window, s.strip_dist_window = w.value, d.value
+    s.distance_window_focal_plane = rng.uniform(-5.0, 5.0)
+    s.depth_det = rng.uniform(10.0, 40.0)
+    if tel == L.TK_LLNL:
+        s.pipes_turned_deg = rng.uniform(2.0, 3.5)
+    n, seed = 40_000, 300 + case
+    with sa.RayTracer(full) as rt:
+        rec = rt.traceAxionWrapper(n, seed=seed)
+        _, summ = rt.trace_histogram(n, seed=seed)
+    ref = Oracle(full, "q").trace_records(n, seed=seed)
+    assert ref["passedTillWindow"].sum() > 1000
+    compare_records(rec, _as_gold(ref), 1e-9, 2e-8, 0.0)
+    for f in ("passed", "passedTillWindow", "hitNickel", "kindsWindow"):
+        np.testing.assert_array_equal(rec[f], ref[f])
+    assert summ["N_PASSED"] == int(ref["passed"].sum()) and summ["N_PASSED_TILL_WINDOW"] == int(ref["passedTillWindow"].sum())
+    if ref["passed"].sum() > 2000:    # (a shifted window may sit beside the focus)
+        assert len(np.unique(ref["kindsWindow"][ref["passed"] == 1])) == 2   # both materials (strongback, window) occur
