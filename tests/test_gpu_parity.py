@@ -622,3 +622,33 @@ def test_randomised_detector_side_against_binary128_oracle(case):
     assert summ["N_PASSED"] == int(ref["passed"].sum()) and summ["N_PASSED_TILL_WINDOW"] == int(ref["passedTillWindow"].sum())
     if ref["passed"].sum() > 2000:    # (a shifted window may sit beside the focus)
         assert len(np.unique(ref["kindsWindow"][ref["passed"] == 1])) == 2   # both materials (strongback, window) occur
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_randomised_gas_stage_against_binary128_oracle(case):
+    """Gas stage (computeMagnetTransmission :1599-1625, axionMassforMagnet.nim:4-113) with random pressure, temperature,
+    field, axion mass and coupling: conversion probability and absorption through the per-energy tables."""
+    from oracle.oracle import Oracle
+    rng = np.random.default_rng(3000 + case)
+    full = make_setup("babyiaxo_xmm_gas")
+    s = full.setup
+    s.magnet_pGasRoom = rng.uniform(0.2, 3.0)
+    s.magnet_tGas = rng.uniform(1.7, 293.0)
+    s.magnet_B = rng.uniform(1.0, 9.0)
+    s.m_axion = rng.uniform(0.0, 0.03)
+    s.g_agamma = 10.0 ** rng.uniform(-13.0, -10.0)
+    n, seed = 40_000, 500 + case
+    with sa.RayTracer(full) as rt:
+        rec = rt.traceAxionWrapper(n, seed=seed)
+        _, summ = rt.trace_histogram(n, seed=seed)
+        rt.set_axion_mass(0.5 * s.m_axion)                    # the scan entry point re-hoists the per-energy tables
+        rec2 = rt.traceAxionWrapper(n, seed=seed)
+    o = Oracle(full, "q")
+    ref = o.trace_records(n, seed=seed)
+    compare_records(rec, _as_gold(ref), 1e-9, 2e-8, 0.0)
+    assert summ["SUM_WEIGHTS"] == pytest.approx(float(ref["weights"][ref["passed"] == 1].sum()), rel=1e-9)
+    s.m_axion *= 0.5
+    ref2 = Oracle(full, "q").trace_records(n, seed=seed)
+    compare_records(rec2, _as_gold(ref2), 1e-9, 2e-8, 0.0)
+    both = (ref["passed"] == 1) & (ref2["passed"] == 1)
+    assert not np.allclose(ref["weights"][both], ref2["weights"][both], rtol=1e-6)    # the mass does matter
