@@ -749,14 +749,20 @@ struct __align__(16) TablesLds {
 };
 
 // per-wave survivor rings (structure of arrays: lane i reads slot (head + i) % 128 -> conflict-free)
+// One wave's rings side by side (7.7 KB): every field is then reachable from a single per-wave base address with an
+// immediate offset, instead of one base register per array.
+template <bool ROT>
+struct __align__(16) WaveRings {
+  double X0[kQueue], Y0[kQueue], tsx[kQueue], tsy[kQueue];
+  double path[kQueue], u5[kQueue];
+  double zcb[ROT ? kQueue : 1];           // z of pointExitCB: constant unless the telescope is rotated
+  int idx[kQueue];                        // r_idx | shell << 16
+  uint32_t ray[kQueue];                   // ring 0: rays that passed stage A0 (ray id relative to the launch's first chunk)
+  uint32_t u3hi[kQueue];                  //         and their word of the shared stream (high word of u3)
+};
 template <int WAVES, bool ROT>
 struct __align__(16) QueueLds {
-  double X0[WAVES][kQueue], Y0[WAVES][kQueue], tsx[WAVES][kQueue], tsy[WAVES][kQueue];
-  double path[WAVES][kQueue], u5[WAVES][kQueue];
-  double zcb[ROT ? WAVES : 1][kQueue];    // z of pointExitCB: constant unless the telescope is rotated
-  int idx[WAVES][kQueue];                 // r_idx | shell << 16
-  uint32_t ray[WAVES][kQueue];            // ring 0: rays that passed stage A0 (ray id relative to the launch's first chunk)
-  uint32_t u3hi[WAVES][kQueue];           //         and their word of the shared stream (high word of u3)
+  WaveRings<ROT> w[WAVES];
 };
 
 template <int BLOCK>
@@ -879,11 +885,11 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     n_shell += cnt;
     if (alive) {
       const uint32_t slot = (t1 + prefix_of(mask)) % kQueue;
-      Q.X0[wave][slot] = st.X0; Q.Y0[wave][slot] = st.Y0;
-      Q.tsx[wave][slot] = st.tsx; Q.tsy[wave][slot] = st.tsy;
-      Q.path[wave][slot] = st.path_cb; Q.u5[wave][slot] = st.u5;
-      if (ROT) Q.zcb[wave][slot] = st.zcb;
-      Q.idx[wave][slot] = st.r_idx | (st.shell << 16);
+      Q.w[wave].X0[slot] = st.X0; Q.w[wave].Y0[slot] = st.Y0;
+      Q.w[wave].tsx[slot] = st.tsx; Q.w[wave].tsy[slot] = st.tsy;
+      Q.w[wave].path[slot] = st.path_cb; Q.w[wave].u5[slot] = st.u5;
+      if (ROT) Q.w[wave].zcb[slot] = st.zcb;
+      Q.w[wave].idx[slot] = st.r_idx | (st.shell << 16);
     }
     t1 += cnt;
   };
@@ -896,11 +902,11 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     {
       // slots beyond n_valid hold stale (or never written) data: lanes compute on them predicated off,
       // with their indices clamped into range
-      st.X0 = Q.X0[wave][slot]; st.Y0 = Q.Y0[wave][slot];
-      st.tsx = Q.tsx[wave][slot]; st.tsy = Q.tsy[wave][slot];
-      st.path_cb = Q.path[wave][slot]; st.u5 = Q.u5[wave][slot];
-      st.zcb = ROT ? Q.zcb[ROT ? wave : 0][slot] : -(H.dz3 - H.dz1);
-      const int packed = valid ? Q.idx[wave][slot] : 0;
+      st.X0 = Q.w[wave].X0[slot]; st.Y0 = Q.w[wave].Y0[slot];
+      st.tsx = Q.w[wave].tsx[slot]; st.tsy = Q.w[wave].tsy[slot];
+      st.path_cb = Q.w[wave].path[slot]; st.u5 = Q.w[wave].u5[slot];
+      st.zcb = ROT ? Q.w[wave].zcb[ROT ? slot : 0] : -(H.dz3 - H.dz1);
+      const int packed = valid ? Q.w[wave].idx[slot] : 0;
       st.r_idx = min(packed & 0xFFFF, Pb.n_radii - 1);
       st.shell = min(packed >> 16, H.n_shells - 1);
       st.u5 = valid ? st.u5 : 0.0;
@@ -969,8 +975,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const bool go = (mask >> lane) & 1ull;
         if (go) {
           const uint32_t slot = (t0 + prefix_of(mask)) % kQueue;
-          Q.ray[wave][slot] = rel;
-          Q.u3hi[wave][slot] = w;
+          Q.w[wave].ray[slot] = rel;
+          Q.w[wave].u3hi[slot] = w;
         }
         t0 += (uint32_t)__popcll(mask);
       } else {
@@ -987,8 +993,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const uint32_t m = min(n0, 64u);
         const bool v = (uint32_t)lane < m;
         const uint32_t slot = (h0 + (uint32_t)lane) % kQueue;
-        const uint32_t rel = v ? Q.ray[wave][slot] : 0u;
-        const uint32_t w = v ? Q.u3hi[wave][slot] : 0u;
+        const uint32_t rel = v ? Q.w[wave].ray[slot] : 0u;
+        const uint32_t w = v ? Q.w[wave].u3hi[slot] : 0u;
         h0 += m;
         run_phase_a(rel, v, w);
         ring_sync();
