@@ -171,6 +171,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(full, int(args.cpu_sample), seed)
             if args.workload == "babyiaxo_xmm":
                 out["other_workloads"] = [other_workload_rate()]
+                out["effective_area_rms"] = effective_area_rms()
         print(json.dumps(out))
     rt.close()
     if world > 1:
@@ -193,6 +194,33 @@ def other_workload_rate():
         ms, n_launch = rt.kernel_timing()
     return {"workload": "CAST magnet + LLNL 14 shells, gold_0.25microns reflectivities, 1e8 rays (BASELINE configs[1])",
             "rays_per_s": n / (ms / n_launch) * 1e3, "ms_per_launch": ms / n_launch, "passed_fraction": s["N_PASSED"] / s["N_RAYS"]}
+
+
+def effective_area_rms(points: int = 8, rays_per_angle: int = 1_000_000):
+    """BASELINE's second metric (configs[3]): RMS between the max-normalised angular-scan curves (raytracer.nim:2791-2802) of
+    the HIP path and of the CPU oracle for the same seed family; XMM shells, telescope_turned_y 0 .. 0.3 deg, effective-area
+    flags, chip 100 mm.  tools/effarea_rms.py is the stand-alone version (profiles/r01_effective_area_rms.json)."""
+    import numpy as np
+    import solaraxionraytracing_amd as sa
+    from solaraxionraytracing_amd import _lib as L
+    from oracle.oracle import Oracle
+    full = sa.initFullSetup()
+    full.setup.chip_x_max = full.setup.chip_y_max = 100.0
+    flags = L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS | L.CF_IGNORE_CONV_PROB
+    angles = np.linspace(0.0, 0.3, points)
+    with sa.RayTracer(full) as rt:
+        _, _, gpu_rel = sa.performAngularScan(rt, 0, 0, 1, rays_per_angle, flags=flags, angles=angles)
+    o = Oracle(full)
+    cpu = np.empty(points)
+    for i, a in enumerate(angles):
+        s = full.setup.copy()
+        s.telescope_turned_y_deg = float(a)
+        _, summ, _ = o.trace_histogram(rays_per_angle, ray_id_offset=i * rays_per_angle, flags=flags, setup=s,
+                                       n_threads=available_cpus())
+        cpu[i] = summ["SUM_WEIGHTS"]
+    cpu_rel = cpu / cpu.max()
+    return {"value": float(np.sqrt(np.mean((gpu_rel - cpu_rel) ** 2))), "points": points, "rays_per_angle": rays_per_angle,
+            "gpu_relative_flux": [round(float(x), 6) for x in gpu_rel], "cpu_relative_flux": [round(float(x), 6) for x in cpu_rel]}
 
 
 def available_cpus() -> int:
