@@ -751,18 +751,16 @@ struct __align__(16) TablesLds {
 // per-wave survivor rings (structure of arrays: lane i reads slot (head + i) % 128 -> conflict-free)
 // One wave's rings side by side (7.7 KB): every field is then reachable from a single per-wave base address with an
 // immediate offset, instead of one base register per array.
-template <bool ROT>
 struct __align__(16) WaveRings {
   double X0[kQueue], Y0[kQueue], tsx[kQueue], tsy[kQueue];
   double path[kQueue], u5[kQueue];
-  double zcb[ROT ? kQueue : 1];           // z of pointExitCB: constant unless the telescope is rotated
   int idx[kQueue];                        // r_idx | shell << 16
   uint32_t ray[kQueue];                   // ring 0: rays that passed stage A0 (ray id relative to the launch's first chunk)
   uint32_t u3hi[kQueue];                  //         and their word of the shared stream (high word of u3)
 };
-template <int WAVES, bool ROT>
+template <int WAVES>
 struct __align__(16) QueueLds {
-  WaveRings<ROT> w[WAVES];
+  WaveRings w[WAVES];
 };
 
 template <int BLOCK>
@@ -789,7 +787,7 @@ __device__ __forceinline__ void stage_tables(TablesLds& S, const DevParams& P, c
 // ids 4l .. 4l+3 of it in four successive passes, so that the one block of the shared word stream it computes (stage A0's
 // only Philox block) serves all four.  Ray i of this launch has the global id ray_id_offset + i; n_rays < 2^31 per launch.
 // FAST: solar source, vacuum, no hole loop, telescope not rotated (all known at compile time).  ROT: rotated telescope
-// (ring 1 then also carries z of pointExitCB; 768 threads so that the rings still fit the LDS).
+// (phase B then recomputes z of pointExitCB from the ray instead of carrying it through ring 1).
 // Re-reads the HotA block (the first kernel argument) from the kernel-argument segment with scalar loads.  The pointer
 // is laundered so that the loads stay where they are written (the start of a phase-A pass) instead of being hoisted
 // out of the persistent loop: ~50 SGPRs held across stage B get spilled through VGPR lanes (v_readlane = VALU slots).
@@ -823,7 +821,7 @@ template <int BLOCK, bool FAST, bool ROT>
 __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
                                                                 double* __restrict__ acc) {
   __shared__ TablesLds S;
-  __shared__ QueueLds<BLOCK / 64, ROT> Q;
+  __shared__ QueueLds<BLOCK / 64> Q;
   // Only the ~20 scalars phase A needs for every ray travel in the kernel arguments (SGPRs); everything
   // else is read from an LDS copy of the parameter blob (broadcast ds_read).  All of them together do not
   // fit the 102 SGPRs of a wave and would be spilled through VGPR lanes (v_readlane = VALU slots).
@@ -888,7 +886,6 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       Q.w[wave].X0[slot] = st.X0; Q.w[wave].Y0[slot] = st.Y0;
       Q.w[wave].tsx[slot] = st.tsx; Q.w[wave].tsy[slot] = st.tsy;
       Q.w[wave].path[slot] = st.path_cb; Q.w[wave].u5[slot] = st.u5;
-      if (ROT) Q.w[wave].zcb[slot] = st.zcb;
       Q.w[wave].idx[slot] = st.r_idx | (st.shell << 16);
     }
     t1 += cnt;
@@ -905,7 +902,17 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       st.X0 = Q.w[wave].X0[slot]; st.Y0 = Q.w[wave].Y0[slot];
       st.tsx = Q.w[wave].tsx[slot]; st.tsy = Q.w[wave].tsy[slot];
       st.path_cb = Q.w[wave].path[slot]; st.u5 = Q.w[wave].u5[slot];
-      st.zcb = ROT ? Q.w[wave].zcb[ROT ? slot : 0] : -(H.dz3 - H.dz1);
+      if (!ROT) {
+        st.zcb = -(H.dz3 - H.dz1);
+      } else {
+        // z of pointExitCB in the rotated telescope frame (z0 of :2051): the point of the ray whose z *before* the rotation
+        // (rotateInY(rotateInX(.)) about (0, 0, lT/2), :1888-1894) is -Lp.  With m = third column of that rotation and
+        // q(Z) = (X0 + entrance_x + tsx Z, Y0 + entrance_y + tsy Z, Z):  m . (q - c) + lT/2 = -Lp, linear in Z.
+        const double mx = Pb.rx_s, my = -Pb.rx_c * Pb.ry_s, mz = Pb.rx_c * Pb.ry_c, h = Pb.half_length_telescope;
+        const double qx = st.X0 + Pb.entrance_x, qy = st.Y0 + Pb.entrance_y;
+        const double num = -(H.dz3 - H.dz1) - h - fma(mx, qx, fma(my, qy, -mz * h));
+        st.zcb = num * frcp(fma(mx, st.tsx, fma(my, st.tsy, mz)));
+      }
       const int packed = valid ? Q.w[wave].idx[slot] : 0;
       st.r_idx = min(packed & 0xFFFF, Pb.n_radii - 1);
       st.shell = min(packed >> 16, H.n_shells - 1);
@@ -1109,14 +1116,14 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
 
 // ---- launch wrappers (called from sart_api.hip) ----
 int records_block() { return kRecBlock; }
-// Variants: 0 = FAST, 1 = generic with the telescope not rotated (both 1024 threads = 4 waves / SIMD: measured fastest of
-// 256 / 512 / 768 / 1024), 2 = generic, rotated (768 threads: ring 1 carries one more field and 16 waves' rings no longer fit).
-int histogram_block_of(int variant) { return variant == 2 ? 768 : 1024; }
+// Variants: 0 = FAST, 1 = generic with the telescope not rotated, 2 = generic, rotated; all with 1024 threads = 4 waves /
+// SIMD (measured fastest of 256 / 512 / 768 / 1024).
+int histogram_block_of(int) { return 1024; }
 
 int histogram_blocks_per_cu(int variant) {
   int n = 0;
   hipError_t e;
-  if (variant == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<768, false, true>, 768, 0);
+  if (variant == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, false, true>, 1024, 0);
   else if (variant == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, false, false>, 1024, 0);
   else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, true, false>, 1024, 0);
   return (e == hipSuccess && n > 0) ? n : 1;
@@ -1125,7 +1132,7 @@ int histogram_blocks_per_cu(int variant) {
 void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
                             hipStream_t stream, int variant) {
   if (variant == 2)
-    hipLaunchKernelGGL((trace_histogram_kernel<768, false, true>), dim3(n_blocks), dim3(768), 0, stream, H, blob, A, acc);
+    hipLaunchKernelGGL((trace_histogram_kernel<1024, false, true>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc);
   else if (variant == 1)
     hipLaunchKernelGGL((trace_histogram_kernel<1024, false, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc);
   else
