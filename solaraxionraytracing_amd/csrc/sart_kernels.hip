@@ -649,11 +649,13 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
         const double q = fabs((P.gas_m_gamma_sq - P.m_axion_sq) / en.two_e_ev);
         const double g = en.gamma;
         const double term2 = 1.0 / fma(q, q, g * g * 0.25);
-        const double term3 = 1.0 + exp(-g * Lnat) - 2.0 * exp(-g * Lnat * 0.5) * cos(q * Lnat);
+        const double eh = exp(-g * Lnat * 0.5);                        // exp(-Gamma L) = eh^2: one exp for both terms
+        const double term3 = fma(eh, eh, 1.0) - 2.0 * eh * cos(q * Lnat);
         prob = P.gas_term1 * term2 * term3;
       }
       const double distance_pipe_m = (pdz - zcb) * 1e-3;             // :2116
-      absorb = exp(-en.mu_pipe * distance_pipe_m) * exp(-en.mu_magnet * (path_cb * 1e-3));
+      // intensitySuppression2 (axionMassforMagnet.nim:100-113): exp(-mu_pipe d) exp(-mu_magnet L) as one exponential
+      absorb = exp(-fma(en.mu_pipe, distance_pipe_m, en.mu_magnet * (path_cb * 1e-3)));
     }
     trans_magnet = cos_small(ya) * prob * absorb;   // cos of a degree value taken as radians — sic (:1598)
   }
