@@ -652,3 +652,27 @@ def test_randomised_gas_stage_against_binary128_oracle(case):
     compare_records(rec2, _as_gold(ref2), 1e-9, 2e-8, 0.0)
     both = (ref["passed"] == 1) & (ref2["passed"] == 1)
     assert not np.allclose(ref["weights"][both], ref2["weights"][both], rtol=1e-6)    # the mass does matter
+
+
+def test_interleaved_contexts_and_extreme_seeds_and_ids():
+    """Two contexts with different setups used alternately give what each gives alone (no shared state between contexts);
+    64-bit seeds and ray ids are used in full (seed 2^64 - 1, ids beyond 2^63, offsets that are not multiples of 4 or 256)."""
+    from oracle.oracle import Oracle
+    fa, fb = make_setup("babyiaxo_xmm"), make_setup("cast_llnl")
+    seed, off = 2 ** 64 - 1, 2 ** 63 + 123
+    with sa.RayTracer(fa) as ra, sa.RayTracer(fb) as rb:
+        ia1, sa1 = ra.trace_histogram(300_000, seed=seed, ray_id_offset=off)
+        ib1, sb1 = rb.trace_histogram(300_000, seed=seed, ray_id_offset=off)
+        ia2, sa2 = ra.trace_histogram(300_000, seed=seed, ray_id_offset=off)
+        rec = ra.traceAxionWrapper(20_001, seed=seed, ray_id_offset=off + 77)
+        ib2, sb2 = rb.trace_histogram(300_000, seed=seed, ray_id_offset=off)
+    for k in ("N_PASSED", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_HIT_NICKEL"):
+        assert sa1[k] == sa2[k] and sb1[k] == sb2[k]
+    np.testing.assert_allclose(ia1, ia2, rtol=1e-10, atol=ia1.max() * 1e-14)
+    np.testing.assert_allclose(ib1, ib2, rtol=1e-10, atol=ib1.max() * 1e-14)
+    assert sa1["N_PASSED"] != sb1["N_PASSED"]
+    ref = Oracle(fa, "q").trace_records(20_001, seed=seed, ray_id_offset=off + 77)
+    compare_records(rec, _as_gold(ref), 1e-9, 2e-8, 0.0)
+    np.testing.assert_array_equal(rec["passed"], ref["passed"])
+    _, so, _ = Oracle(fa).trace_histogram(300_000, seed=seed, ray_id_offset=off)
+    assert abs(sa1["N_PASSED"] - so["N_PASSED"]) <= 2 and abs(sa1["N_REACHED_TELESCOPE"] - so["N_REACHED_TELESCOPE"]) <= 2
