@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BASELINE configs[2] at full size on both sides: the 256 x 256 focal-plane image and the counters of N rays (default 1e9)
+"""BASELINE configs[2] (or configs[1]: --workload cast_llnl_gold --rays 1e8) at full size on both sides: the 256 x 256 focal-plane image and the counters of N rays (default 1e9)
 from the HIP path and from the CPU oracle (same seeds and ray ids), compared directly.  Prints one JSON line."""
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,9 +10,14 @@ from oracle.oracle import Oracle
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=float, default=1e9)
 ap.add_argument("--chunk", type=float, default=2.5e8, help="rays per oracle call (progress lines in between)")
+ap.add_argument("--workload", default="babyiaxo_xmm", choices=["babyiaxo_xmm", "cast_llnl_gold"], help="BASELINE configs[2] / configs[1]")
 args = ap.parse_args()
 n, chunk = int(args.rays), int(args.chunk)
-full = sa.initFullSetup()
+if args.workload == "babyiaxo_xmm":
+    full = sa.initFullSetup()
+else:
+    from solaraxionraytracing_amd import _lib as L
+    full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
 t = time.perf_counter()
 with sa.RayTracer(full) as rt:
     img, s = rt.trace_histogram(n, seed=299792458)
@@ -32,7 +37,7 @@ t_cpu = time.perf_counter() - t
 keys = ("N_RAYS", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW", "N_PASSED")
 lit = oimg > 0.01 * oimg.max()
 coarse = lambda a: a.reshape(32, 8, 32, 8).sum(axis=(1, 3))
-out = {"rays": n, "seconds": {"gpu_call_incl_copies": t_gpu, "cpu_oracle": t_cpu},
+out = {"workload": args.workload, "rays": n, "seconds": {"gpu_call_incl_copies": t_gpu, "cpu_oracle": t_cpu},
        "counters_gpu": {k: s[k] for k in keys}, "counters_oracle": {k: osum[k] for k in keys},
        "counter_differences": {k: s[k] - osum[k] for k in keys},
        "sum_weights_rel_diff": s["SUM_WEIGHTS"] / osum["SUM_WEIGHTS"] - 1.0,
