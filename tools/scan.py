@@ -5,7 +5,8 @@
             effective-area style scan of telescope_turned_y, angle bins sharded over the ranks (BASELINE config 4).
             Writes a CSV (the reference only makes a PDF) and compares with the two curves the reference overlays
             (xmm_newton_angular_effective_area.csv, McXtrace_angular_xmm.csv; :2805-2813).
-  mass      gas-stage axion-mass scan (BASELINE config 5): masses sharded over the ranks.
+  mass      gas-stage axion-mass scan (BASELINE config 5): masses sharded over the ranks, or (--shard rays) the rays of
+            every mass point sharded over the ranks with one reduce of the fused accumulator per point.
 
 Examples
   python tools/scan.py angular --angularScanMin 0 --angularScanMax 0.3 --numAngularScanPoints 16 --rays 1e7
@@ -30,6 +31,9 @@ def main():
     ap.add_argument("--massMax", type=float, default=0.02, help="eV; the literal-units gas stage has m_gamma = 0.008235 eV")
     ap.add_argument("--rays", type=float, default=1e7, help="rays per scan point")
     ap.add_argument("--chip", type=float, default=100.0, help="chip size in mm for the angular scan (SURVEY App. C)")
+    ap.add_argument("--shard", default="bins", choices=["bins", "rays"],
+                    help="bins: every scan point is a full run on one rank (BASELINE config 4); rays: every rank traces its "
+                         "share of the ray ids of every point and the accumulators are reduced once per point (config 5)")
     ap.add_argument("--out", default="gpurun_out/scan.csv")
     args = ap.parse_args()
 
@@ -50,15 +54,45 @@ def main():
         full = sa.initFullSetup(stage=L.SK_GAS)
         flags = 0
         xs = np.linspace(args.massMin, args.massMax, args.points)
-    mine = D.shard_angles(len(xs), rank, world)
+    if args.shard == "rays":
+        # Every point: rank r traces ray ids [lo_r, hi_r) of the point's id block into a device accumulator, then ONE
+        # reduce of the fused accumulator (image + scalars) over the ranks — the RCCL histogram reduce of config 5.
+        use_cuda = not (world > 1 and torch.distributed.get_backend() != "nccl")
+        acc = torch.zeros(sa.accumulator_len(256), dtype=torch.float64, device=torch.device("cuda", local_rank))
+        curve = np.zeros(len(xs))
+        lo, hi = D.shard_range(n_rays, rank, world)
+        with sa.RayTracer(full, device=local_rank) as rt:
+            stream = torch.cuda.Stream(device=acc.device)
+            torch.cuda.set_stream(stream)
+            rt.set_stream(stream.cuda_stream)
+            for i, x in enumerate(xs):
+                if args.mode == "angular":
+                    rt.set_telescope_angles(float("nan"), float(x))
+                else:
+                    rt.set_axion_mass(float(x))
+                acc.zero_()
+                p = rt.trace_params(hi - lo, ray_id_offset=i * n_rays + lo, flags=flags, accumulate=True)
+                rt.trace_histogram_device(p, acc.data_ptr())
+                red = acc if use_cuda else acc.cpu()
+                D.reduce_accumulator(red, dst=0)
+                curve[i] = float(red[256 * 256 + L.ACC["SUM_WEIGHTS"]].item())
+                if rank == 0:
+                    assert float(red[256 * 256 + L.ACC["N_RAYS"]].item()) == n_rays
+            rt.synchronize()
+        mine = None
+    else:
+        mine = D.shard_angles(len(xs), rank, world)
     with sa.RayTracer(full, device=local_rank) as rt:
-        if args.mode == "angular":
+        if mine is None:
+            pass
+        elif args.mode == "angular":
             # every bin keeps its own ray-id block so that the result does not depend on the number of ranks
             vals = [sa.performAngularScan(rt, 0, 0, 1, n_rays, flags=flags, angles=[xs[i]], ray_id_offset=i * n_rays)[1][0] for i in mine]
         else:
             vals = [sa.performAxionMassScan(rt, [xs[i]], n_rays, flags=flags, ray_id_offset=i * n_rays)[0] for i in mine]
-    dev = torch.device("cuda", local_rank) if (world > 1 and torch.distributed.get_backend() == "nccl") else "cpu"
-    curve = D.gather_scan(torch.tensor(vals, dtype=torch.float64, device=dev), mine, len(xs)).cpu().numpy()
+    if mine is not None:
+        dev = torch.device("cuda", local_rank) if (world > 1 and torch.distributed.get_backend() == "nccl") else "cpu"
+        curve = D.gather_scan(torch.tensor(vals, dtype=torch.float64, device=dev), mine, len(xs)).cpu().numpy()
     if rank == 0:
         rel = curve / curve.max()
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
