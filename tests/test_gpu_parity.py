@@ -676,3 +676,23 @@ def test_interleaved_contexts_and_extreme_seeds_and_ids():
     np.testing.assert_array_equal(rec["passed"], ref["passed"])
     _, so, _ = Oracle(fa).trace_histogram(300_000, seed=seed, ray_id_offset=off)
     assert abs(sa1["N_PASSED"] - so["N_PASSED"]) <= 2 and abs(sa1["N_REACHED_TELESCOPE"] - so["N_REACHED_TELESCOPE"]) <= 2
+
+
+def test_scan_driver_sharded_by_rays_equals_sharded_by_bins(tmp_path):
+    """tools/scan.py: the axion-mass scan with every point's rays sharded over 2 ranks (one accumulator reduce per point,
+    BASELINE config 5; gloo on this one GPU) gives the curve of the bin-sharded single-process scan."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a, b = str(tmp_path / "bins.csv"), str(tmp_path / "rays.csv")
+    common = ["mass", "--points", "4", "--rays", "500000"]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "scan.py")] + common + ["--out", a], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, SART_BENCH_BACKEND="gloo", SART_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29571", os.path.join(root, "tools", "scan.py")] + common + ["--shard", "rays", "--out", b],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ca, cb = np.loadtxt(a, delimiter=",", skiprows=1), np.loadtxt(b, delimiter=",", skiprows=1)
+    np.testing.assert_allclose(cb[:, 1], ca[:, 1], rtol=1e-9)
