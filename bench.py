@@ -7,10 +7,22 @@ Workload = BASELINE.json configs[2]: BabyIAXO magnet + XMM-Newton shells (58), v
 256x256 focal-plane image; one step = one 1e9-ray image per GPU.  Inputs are the documented synthetic tables
 (E1 Primakoff emission on AGSS09, G1 Henke gold reflectivity; the reference's own input files are not shipped).
 
-Multi-GPU (weak scaling): one process per GPU (torchrun contract), rays shard by global ray id, every rank
-accumulates its own image and ONE RCCL reduce of the fused accumulator closes the timed region.
+Multi-GPU: one process per GPU (torchrun contract), rays shard by global ray id, every rank accumulates its own
+image and ONE RCCL reduce of the fused accumulator closes the timed region.  --scaling weak (default): every rank
+traces --rays-per-step rays per step; --scaling strong: --rays-per-step is the total per step, split over the ranks
+by distributed.shard_range (BASELINE configs[4]: "1e10 rays across 8 MI355X" = --scaling strong --rays-per-step 1e9
+--steps 10 on 8 ranks).
 
-Prints one JSON line on rank 0.  --profile-run skips the CPU baseline (for use under rocprofv3).
+Roofline block: the kernel is bound by f64 VALU issue, not by HBM.  PMC counters cannot be read from
+inside this process, so the per-ray counter figures come from the committed separate-pass profile of the SAME build
+and workload (profiles/pmc_current.json -> profiles/r02_*_pmc_summary.json, made by tools/pmc_profile.sh +
+tools/pmc_summary.py) and are combined with the kernel duration measured live here with HIP events on the launch
+stream:
+    achieved  [TFLOP/s] = f64_flop_per_ray x rays per launch / avg kernel duration      (peak 78.6: f64 vector)
+    hbm.achieved [GB/s] = fabric_bytes_per_ray x rays per launch / avg kernel duration  (peak 8000)
+    valu_issue_utilisation = fraction of the SIMDs' cycles in which a VALU instruction issues (from the profile run)
+
+Prints one JSON line on rank 0.  --profile-run skips the CPU baseline and the side workloads (for use under rocprofv3).
 """
 from __future__ import annotations
 
@@ -24,11 +36,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic bytes per ray of the reference's formulation (f64 tables, no cache credit)
-BYTES_KILLED, BYTES_MIRROR, BYTES_DETECTOR = 184.0, 184.0 + 64.0, 456.0
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-F64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
-FLOPS_DETECTOR, FLOPS_KILLED = 2000.0, 300.0   # SURVEY.md 8(d) secondary figure
+F64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 16 f64 lanes / clk x 2 flop x 2.4 GHz
+# algorithmic bytes per ray of the REFERENCE's formulation (f64 tables, 11-probe searches, no cache
+# credit).  Informational only: the redesigned path (stage A0, guide tables, LDS-resident tables) needs far fewer bytes,
+# so this figure does not bound the kernel and is no longer used as `achieved`.
+BYTES_KILLED, BYTES_MIRROR, BYTES_DETECTOR = 184.0, 184.0 + 64.0, 456.0
+
+WORKLOADS = {
+    "babyiaxo_xmm": "BabyIAXO magnet + XMM-Newton 58 shells, vacuum, InGridIAXO, 256x256 focal-plane image (BASELINE configs[2])",
+    "cast_llnl_gold": "CAST magnet + LLNL 14 shells, gold_0.25microns reflectivities (BASELINE configs[1])",
+    "babyiaxo_xmm_gas": "BabyIAXO magnet + XMM-Newton shells, gas stage (the m_a-scan kernel variant of BASELINE configs[4])",
+    "babyiaxo_xmm_rot": "BabyIAXO magnet + XMM-Newton shells, telescope turned 0.1 deg, effective-area flags, chip 100 mm "
+                        "(one angle bin of BASELINE configs[3])",
+}
 
 
 def parse():
@@ -36,14 +57,99 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rays-per-step", type=float, default=1e9, help="rays per step and GPU (one BabyIAXO image of BASELINE configs[2])")
-    ap.add_argument("--workload", default="babyiaxo_xmm", choices=["babyiaxo_xmm", "cast_llnl_gold"])
+    ap.add_argument("--rays-per-step", type=float, default=1e9,
+                    help="rays per step: per GPU (--scaling weak) or in total (--scaling strong); 1e9 = one BabyIAXO image of "
+                         "BASELINE configs[2]")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--workload", default="babyiaxo_xmm", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=float, default=6e8, help="rays of the CPU-baseline sample")
-    ap.add_argument("--profile-run", action="store_true", help="no CPU baseline (run under rocprofv3)")
-    ap.add_argument("--traffic-bytes-per-launch", type=float, default=None,
-                    help="fabric bytes per launch from a separate rocprofv3 --pmc pass; default: profiles/pmc_traffic.json "
-                         "if it was measured for the same workload and launch size")
+    ap.add_argument("--profile-run", action="store_true", help="no CPU baseline / side workloads (run under rocprofv3)")
     return ap.parse_args()
+
+
+def make_setup(workload: str):
+    """The FullRaytraceSetup and trace flags of a named workload (default full-size tables: 1968 x 1500 emission CDFs,
+    1000 x 1000 reflectivity)."""
+    import solaraxionraytracing_amd as sa
+    from solaraxionraytracing_amd import _lib as L
+    flags = 0
+    if workload == "babyiaxo_xmm":
+        full = sa.initFullSetup()
+    elif workload == "cast_llnl_gold":
+        full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
+    elif workload == "babyiaxo_xmm_gas":
+        full = sa.initFullSetup(stage=L.SK_GAS)
+    elif workload == "babyiaxo_xmm_rot":
+        full = sa.initFullSetup()
+        full.setup.chip_x_max = full.setup.chip_y_max = 100.0
+        full.setup.telescope_turned_y_deg = 0.1
+        flags = L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS | L.CF_IGNORE_CONV_PROB
+    else:
+        raise ValueError(workload)
+    return full, flags
+
+
+def active_knobs():
+    """SART_* environment variables that change what the library does (libsart reads them in sart_create)."""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("SART_")}
+
+
+def load_pmc(workload: str):
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
+            return json.load(f).get(workload)
+    except Exception:
+        return None
+
+
+def roofline_block(workload: str, rays_per_launch: float, avg_kernel_s: float, n_launch: int, summ: dict, total_rays: float):
+    """Counter-derived roofline of the trace kernel (see the module docstring for the formulas)."""
+    pmc = load_pmc(workload)
+    frac_det = summ["N_PASSED_TILL_WINDOW"] / total_rays
+    frac_mirror = summ["N_SHELL_SELECTED"] / total_rays - frac_det
+    frac_killed = 1.0 - summ["N_SHELL_SELECTED"] / total_rays
+    ref_bytes_per_ray = frac_killed * BYTES_KILLED + frac_mirror * BYTES_MIRROR + frac_det * BYTES_DETECTOR
+    blk = {"bound": "f64-valu-issue", "achieved": None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
+           "traffic": None, "kernel": "trace_histogram_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": n_launch,
+           "rays_per_launch": rays_per_launch,
+           "reference_formulation_bytes_per_ray": ref_bytes_per_ray,
+           "note": "achieved = measured f64 flop per ray (PMC: (2 FMA + MUL + ADD + TRANS) x 64 lanes / rays, "
+                   "profiles/pmc_current.json) x rays per launch / live HIP-event kernel duration; traffic = fabric bytes per "
+                   "launch (TCC_EA0 requests by size + WRITE_SIZE, Infinity-Cache hits included).  "
+                   "reference_formulation_bytes_per_ray is SURVEY 8(d)'s probe count of the reference's formulation; the "
+                   "redesigned path does not move those bytes, so it is informational only."}
+    if pmc is None:
+        blk["note"] += "  NO committed PMC profile for this workload: counter-derived fields are null."
+        return blk
+    tflops = pmc["f64_flop_per_ray"] * rays_per_launch / avg_kernel_s / 1e12
+    blk["achieved"] = tflops
+    blk["frac"] = tflops / F64_VALU_PEAK_TFLOPS
+    blk["valu_issue_utilisation"] = pmc.get("valu_issue_utilisation")
+    blk["valu_insts_per_64_rays"] = pmc.get("valu_insts_per_64_rays")
+    blk["f64_flop_per_ray"] = pmc["f64_flop_per_ray"]
+    blk["pmc_source"] = pmc.get("source")
+    if pmc.get("fabric_bytes_per_ray") is not None:
+        traffic = pmc["fabric_bytes_per_ray"] * rays_per_launch
+        gbs = traffic / avg_kernel_s / 1e9
+        blk["traffic"] = traffic
+        blk["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                      "fabric_bytes_per_ray": pmc["fabric_bytes_per_ray"]}
+        assert blk["hbm"]["frac"] <= 1.0, blk["hbm"]
+    assert blk["frac"] <= 1.0, blk
+    assert blk["valu_issue_utilisation"] is None or blk["valu_issue_utilisation"] <= 1.0, blk
+    return blk
+
+
+def check_image(host, n_img: int, summ: dict):
+    """The image must hold the weights the scalars say were accumulated: guards against a timed region with the
+    accumulation skipped."""
+    img_sum = float(host[:n_img].sum())
+    if summ["N_OUTSIDE_IMAGE"] == 0:
+        assert abs(img_sum - summ["SUM_WEIGHTS"]) <= 1e-9 * abs(summ["SUM_WEIGHTS"]), (img_sum, summ["SUM_WEIGHTS"])
+    else:
+        assert 0.0 < img_sum <= summ["SUM_WEIGHTS"] * (1.0 + 1e-9), (img_sum, summ["SUM_WEIGHTS"])
+    assert summ["N_PASSED"] > 0 and img_sum > 0.0
+    return img_sum
 
 
 def main():
@@ -65,25 +171,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    if args.workload == "babyiaxo_xmm":
-        full = sa.initFullSetup()
-        wl_name = "BabyIAXO magnet + XMM-Newton 58 shells, vacuum, InGridIAXO, 256x256 focal-plane image (BASELINE configs[2])"
+    full, flags = make_setup(args.workload)
+    wl_name = WORKLOADS[args.workload]
+    rays_step = int(args.rays_per_step)
+    if args.scaling == "weak":
+        rays_rank, step_total = rays_step, rays_step * world
+        lo_in_step = rank * rays_step
     else:
-        full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
-        wl_name = "CAST magnet + LLNL 14 shells, gold_0.25microns reflectivities (BASELINE configs[1])"
-
-    rays = int(args.rays_per_step)
-    traffic = args.traffic_bytes_per_launch
-    traffic_note = None
-    if traffic is None:
-        try:   # PMC counters cannot be collected from inside this process; use the committed separate-pass measurement
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                t = json.load(f)
-            if t["workload"] == args.workload:
-                traffic = t["bytes_per_ray"] * rays
-                traffic_note = t["note"]
-        except Exception:
-            pass
+        lo_in_step, hi_in_step = D.shard_range(rays_step, rank, world)
+        rays_rank, step_total = hi_in_step - lo_in_step, rays_step
     rt = sa.RayTracer(full, device=local_rank)
     # Launches, torch ops on the accumulator and the RCCL reduce are ordered by ONE explicit stream.  (torch's
     # default stream has handle 0, which sart_set_stream reads as "the context's own stream".)
@@ -96,8 +192,8 @@ def main():
 
     def step(k: int):
         # global ray ids: step-major, rank-minor => the union over ranks and steps is a contiguous id range
-        offset = (k * world + rank) * rays
-        p = rt.trace_params(rays, seed=seed, ray_id_offset=offset, accumulate=True)
+        offset = k * step_total + lo_in_step
+        p = rt.trace_params(rays_rank, seed=seed, ray_id_offset=offset, accumulate=True, flags=flags)
         rt.trace_histogram_device(p, acc.data_ptr())
 
     def barrier():
@@ -130,17 +226,11 @@ def main():
         host = acc.cpu().numpy()
         n_img = 256 * 256
         summ = {k: float(host[n_img + i]) for k, i in L.ACC.items()}
-        total_rays = float(world) * args.steps * rays
+        total_rays = float(args.steps) * step_total
         assert summ["N_RAYS"] == total_rays, (summ["N_RAYS"], total_rays)
+        img_sum = check_image(host, n_img, summ)
         value = total_rays / elapsed_s
-        # roofline of the dominant (only) kernel, per launch on this rank: algorithmic bytes of SURVEY 8(d)
-        frac_det = summ["N_PASSED_TILL_WINDOW"] / total_rays
-        frac_mirror = summ["N_SHELL_SELECTED"] / total_rays - frac_det
-        frac_killed = 1.0 - summ["N_SHELL_SELECTED"] / total_rays
-        bytes_per_ray = frac_killed * BYTES_KILLED + frac_mirror * BYTES_MIRROR + frac_det * BYTES_DETECTOR
         avg_kernel_s = kernel_ms / 1e3 / max(1, n_launch)
-        achieved_gbs = bytes_per_ray * rays / avg_kernel_s / 1e9
-        flops_per_ray = frac_killed * FLOPS_KILLED + (1.0 - frac_killed) * FLOPS_DETECTOR
         out = {
             "metric": "rays/sec",
             "value": value,
@@ -150,27 +240,22 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed_s / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": wl_name, "rays_per_step_per_gpu": rays, "total_rays": total_rays,
+            "config": {"workload": wl_name, "rays_per_step_per_gpu": rays_rank, "total_rays": total_rays,
                        "tables": full.meta, "sharding": "global ray id, 1 RCCL reduce of image+scalars",
-                       "device": rt.device_info()},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "trace_histogram_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": n_launch,
-                         "algorithmic_bytes_per_ray": bytes_per_ray, "headline_bytes_per_ray_upper_bound": BYTES_DETECTOR,
-                         "secondary_f64_valu": {"achieved_tflops": flops_per_ray * rays / avg_kernel_s / 1e12,
-                                                "peak_tflops": F64_VALU_PEAK_TFLOPS}},
-            "results": {"flux": summ["SUM_WEIGHTS"], "passed_fraction": summ["N_PASSED"] / total_rays,
+                       "device": rt.device_info(), "knobs": active_knobs()},
+            "roofline": roofline_block(args.workload, float(rays_rank), avg_kernel_s, n_launch, summ, total_rays),
+            "results": {"flux": summ["SUM_WEIGHTS"], "image_sum": img_sum, "passed_fraction": summ["N_PASSED"] / total_rays,
                         "reached_telescope_fraction": summ["N_REACHED_TELESCOPE"] / total_rays,
                         "shell_selected_fraction": summ["N_SHELL_SELECTED"] / total_rays},
         }
         if world == 1 and not args.profile_run:
             out["cpu_baseline"] = cpu_baseline(full, int(args.cpu_sample), seed)
             if args.workload == "babyiaxo_xmm":
-                out["other_workloads"] = [other_workload_rate()]
+                out["other_workloads"] = [other_workload_rate(w) for w in ("cast_llnl_gold", "babyiaxo_xmm_gas", "babyiaxo_xmm_rot")]
                 out["effective_area_rms"] = effective_area_rms()
         print(json.dumps(out))
     rt.close()
@@ -179,21 +264,27 @@ def main():
         dist.destroy_process_group()
 
 
-def other_workload_rate():
-    """BASELINE configs[1] (CAST magnet + LLNL telescope, gold reflectivities, 1e8 rays) beside the headline workload:
-    three 1e8-ray launches, HIP-event kernel time.  Informational; `value` is the BabyIAXO workload."""
+def other_workload_rate(workload: str, n: int = 100_000_000, launches: int = 3):
+    """The other kernel variants / BASELINE configs beside the headline workload: `launches` 1e8-ray launches each,
+    HIP-event kernel time, own roofline block from that workload's committed PMC profile.  Informational; `value` is the
+    BabyIAXO workload."""
     import solaraxionraytracing_amd as sa
     from solaraxionraytracing_amd import _lib as L
-    full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
-    n = 100_000_000
+    full, flags = make_setup(workload)
     with sa.RayTracer(full) as rt:
-        rt.trace_histogram(n // 10, seed=1)
+        rt.trace_histogram(n // 10, seed=1, flags=flags)
         rt.enable_kernel_timing(True)
-        for k in range(3):
-            _, s = rt.trace_histogram(n, seed=1, ray_id_offset=k * n, accumulate=(k > 0))
+        for k in range(launches):
+            img, s = rt.trace_histogram(n, seed=1, ray_id_offset=k * n, accumulate=(k > 0), flags=flags)
         ms, n_launch = rt.kernel_timing()
-    return {"workload": "CAST magnet + LLNL 14 shells, gold_0.25microns reflectivities, 1e8 rays (BASELINE configs[1])",
-            "rays_per_s": n / (ms / n_launch) * 1e3, "ms_per_launch": ms / n_launch, "passed_fraction": s["N_PASSED"] / s["N_RAYS"]}
+    total = float(n) * launches
+    assert s["N_RAYS"] == total, (s["N_RAYS"], total)
+    import numpy as np
+    host = np.concatenate([img.ravel(), np.array([s[k] for k in sorted(L.ACC, key=L.ACC.get)])])
+    check_image(host, img.size, s)
+    avg_s = ms / 1e3 / n_launch
+    return {"workload": WORKLOADS[workload], "rays_per_s": n / avg_s, "ms_per_launch": ms / n_launch,
+            "passed_fraction": s["N_PASSED"] / s["N_RAYS"], "roofline": roofline_block(workload, float(n), avg_s, n_launch, s, total)}
 
 
 def effective_area_rms(points: int = 8, rays_per_angle: int = 1_000_000):
@@ -250,10 +341,16 @@ def available_cpus() -> int:
 
 def cpu_baseline(full, n_sample: int, seed: int):
     """The CPU oracle (restatement of the Nim path; the Nim binary cannot be built) timed on this host's cores on a
-    bounded sample of the same workload."""
+    bounded sample of the same workload.  Timed with the -O3 -march=native build (oracle/libsart_oracle_native.so, SURVEY
+    8(d)); the parity tests use the portable -O2 build."""
     from oracle.oracle import Oracle
     cores = available_cpus()
-    o = Oracle(full)
+    try:
+        o = Oracle(full, variant="native")
+        build = "gcc -O3 -march=native -fopenmp -ffp-contract=off"
+    except Exception:
+        o = Oracle(full)
+        build = "gcc -O2 -fopenmp -ffp-contract=off"
     o.trace_histogram(200_000, seed=seed, n_threads=cores)   # warm up threads / page in tables
     t0 = time.perf_counter()
     _, summ, used = o.trace_histogram(n_sample, seed=seed, n_threads=cores)
@@ -263,8 +360,8 @@ def cpu_baseline(full, n_sample: int, seed: int):
     o.trace_histogram(n1, seed=seed, n_threads=1)
     dt1 = time.perf_counter() - t0
     return {"value": n_sample / dt, "unit": "rays/s", "cores": used, "kind": "port",
-            "sample": "%d rays of the same workload, C restatement of traceAxion (oracle/sart_oracle.c, gcc -O2 -fopenmp), "
-                      "%.1f s; single thread: %.3g rays/s" % (n_sample, dt, n1 / dt1)}
+            "sample": "%d rays of the same workload, C restatement of traceAxion (oracle/sart_oracle.c, %s), "
+                      "%.1f s; single thread: %.3g rays/s" % (n_sample, build, dt, n1 / dt1)}
 
 
 if __name__ == "__main__":

@@ -30,8 +30,30 @@ class OracleTables(C.Structure):
 _TARGETS = {"f64": "libsart_oracle.so", "ld": "libsart_oracle_ld.so", "q": "libsart_oracle_q.so"}
 
 
+def _native_target() -> str:
+    """File name of the -O3 -march=native build for THIS host's CPU (bench.py's timed CPU baseline).  Built
+    .so files travel with the repository snapshot to other machines, and a -march=native object must never run on a CPU
+    it was not built for, so the name carries a hash of the CPU's model and flags."""
+    import hashlib
+    ident = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith(("model name", "flags")):
+                    ident += line
+                if line.strip() == "" and ident:
+                    break
+    except OSError:
+        ident = "unknown"
+    return "libsart_oracle_native_%s.so" % hashlib.sha1(ident.encode()).hexdigest()[:10]
+
+
 def build(variant: str = "f64") -> str:
     """Compiles the oracle with gcc if needed; returns the library path."""
+    if variant == "native":
+        target = _native_target()
+        subprocess.run(["make", "-s", "-C", _DIR, "native", "NATIVE_TARGET=" + target], check=True)
+        return os.path.join(_DIR, target)
     target = _TARGETS[variant]
     subprocess.run(["make", "-s", "-C", _DIR, target], check=True)
     return os.path.join(_DIR, target)
@@ -42,7 +64,7 @@ _libs = {}
 
 def load(variant: str = "f64") -> C.CDLL:
     if variant not in _libs:
-        path = os.path.join(_DIR, _TARGETS[variant])
+        path = os.path.join(_DIR, _native_target() if variant == "native" else _TARGETS[variant])
         if not os.path.exists(path):
             build(variant)
         lib = C.CDLL(path)

@@ -428,15 +428,22 @@ int sart_host_perform_angular_scan(sart_context* ctx, const double* angles_deg, 
   p.flags = flags;
   p.image_nx = 256; p.image_ny = 256;  // heatmaptable2 :2629, over 0 .. ChipXMax / ChipYMax :2622-2625
   p.image_x_min = 0.0; p.image_x_max = setup.chip_x_max; p.image_y_min = 0.0; p.image_y_max = setup.chip_y_max;
-  for (int32_t i = 0; i < n_angles; ++i) {  // raytracer.nim:2791-2800
-    int rc = sart_set_telescope_angles(ctx, std::nan(""), angles_deg[i]);  // tel.telescope_turned_y = angle :2796
-    if (rc) { g_err = sart_last_error(); return rc; }
+  // The reference scans a copy of fullSetup (`var tel = fullSetup.expSetup.telescope`, :2794-2797): the caller's setup is
+  // unchanged afterwards.  Here the context is the setup, so the original angle is put back on every way out.
+  int rc_scan = 0;
+  for (int32_t i = 0; i < n_angles && rc_scan == 0; ++i) {  // raytracer.nim:2791-2800
+    rc_scan = sart_set_telescope_angles(ctx, std::nan(""), angles_deg[i]);  // tel.telescope_turned_y = angle :2796
+    if (rc_scan) { g_err = sart_last_error(); break; }
     p.ray_id_offset = ray_id_offset + static_cast<uint64_t>(i) * n_rays_per_angle;
     sart_summary_t sum;
-    rc = sart_trace_histogram(ctx, &p, nullptr, &sum);
-    if (rc) { g_err = sart_last_error(); return rc; }
+    rc_scan = sart_trace_histogram(ctx, &p, nullptr, &sum);
+    if (rc_scan) { g_err = sart_last_error(); break; }
     fluxes_out[i] = sum.v[SART_ACC_SUM_WEIGHTS];
   }
+  if (int rc = sart_set_telescope_angles(ctx, std::nan(""), setup.telescope_turned_y_deg)) {
+    if (!rc_scan) { g_err = sart_last_error(); rc_scan = rc; }
+  }
+  if (rc_scan) return rc_scan;
   if (rel_fluxes_out) {  // :2801-2802
     double maxFlux = fluxes_out[0];
     for (int32_t i = 1; i < n_angles; ++i) maxFlux = std::max(maxFlux, fluxes_out[i]);
@@ -458,16 +465,20 @@ int sart_host_perform_axion_mass_scan(sart_context* ctx, const double* masses_ev
   p.flags = flags;
   p.image_nx = 256; p.image_ny = 256;
   p.image_x_min = 0.0; p.image_x_max = setup.chip_x_max; p.image_y_min = 0.0; p.image_y_max = setup.chip_y_max;
-  for (int32_t i = 0; i < n_masses; ++i) {
-    int rc = sart_set_axion_mass(ctx, masses_ev[i]);
-    if (rc) { g_err = sart_last_error(); return rc; }
+  int rc_scan = 0;   // the context's axion mass is put back on every way out (the scan works on a copy in spirit)
+  for (int32_t i = 0; i < n_masses && rc_scan == 0; ++i) {
+    rc_scan = sart_set_axion_mass(ctx, masses_ev[i]);
+    if (rc_scan) { g_err = sart_last_error(); break; }
     p.ray_id_offset = ray_id_offset + static_cast<uint64_t>(i) * n_rays_per_mass;
     sart_summary_t sum;
-    rc = sart_trace_histogram(ctx, &p, nullptr, &sum);
-    if (rc) { g_err = sart_last_error(); return rc; }
+    rc_scan = sart_trace_histogram(ctx, &p, nullptr, &sum);
+    if (rc_scan) { g_err = sart_last_error(); break; }
     fluxes_out[i] = sum.v[SART_ACC_SUM_WEIGHTS];
   }
-  return 0;
+  if (int rc = sart_set_axion_mass(ctx, setup.m_axion)) {
+    if (!rc_scan) { g_err = sart_last_error(); rc_scan = rc; }
+  }
+  return rc_scan;
 }
 
 int sart_host_h5_reflectivity_info(const char* path, int32_t* n_coatings, int32_t* n_angles, int32_t* n_energies,

@@ -95,7 +95,9 @@ struct sart_context {
   int blocks_per_cu_hist[3] = {0, 0, 0}, blocks_per_cu_rec = 0;
   // tuning / experiment knobs, read from the environment once when the context is created
   struct Knobs {
+#ifdef SART_DEBUG_KNOBS              // experiment builds only (make DEBUG_KNOBS=1); compiled out of the shipped library
     bool no_image_atomics = false;   // SART_DEBUG_NO_IMAGE_ATOMICS: timing experiment only (results are wrong)
+#endif
     bool no_early_reject = false;    // SART_NO_EARLY_REJECT: stage A0 off
     bool force_generic = false;      // SART_FORCE_GENERIC: never use the specialised kernel variant
     int image_replicas = 0;          // SART_IMAGE_REPLICAS: 0 = chosen from the plate scale
@@ -386,6 +388,9 @@ int refresh_derived(sart_context* c) {
   const sart_setup_t& s = c->setup;
   if (s.reflectivity_kind == SART_RK_MULTI_COATING && c->refl_nc < s.n_coatings)
     return fail(SART_ERR_INVALID_ARGUMENT, "multi-coating telescope needs one reflectivity grid per coating");
+  // Launches still running on the context's stream read the tables that are overwritten below (blocking copies on the
+  // null stream do not wait for a non-blocking stream).
+  SART_HIP(hipStreamSynchronize(c->stream));
   if (int rc = hoist_setup(c)) return rc;
   if (int rc = c->d_shells.upload(c->shells.data(), c->shells.size())) return rc;
   if (int rc = c->d_lut.upload(c->shell_lut.data(), c->shell_lut.size())) return rc;
@@ -400,6 +405,8 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   if (!p) return fail(SART_ERR_INVALID_ARGUMENT, "params is NULL");
   if (p->image_nx < 1 || p->image_ny < 1 || !(p->image_x_max > p->image_x_min) || !(p->image_y_max > p->image_y_min))
     return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
+  if (static_cast<int64_t>(p->image_nx) * static_cast<int64_t>(p->image_ny) > static_cast<int64_t>(INT32_MAX) - SART_ACC_COUNT)
+    return fail(SART_ERR_INVALID_ARGUMENT, "image_nx * image_ny must be below 2^31 (pixel indices are 32-bit on the device)");
   a.replicas = nullptr;
   a.partials = nullptr;
   a.replica_mask = 0u;
@@ -409,7 +416,9 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   a.seed_lo = static_cast<uint32_t>(p->seed);
   a.seed_hi = static_cast<uint32_t>(p->seed >> 32);
   a.flags = p->flags;
+#ifdef SART_DEBUG_KNOBS
   if (c->knobs.no_image_atomics) a.flags |= 0x40000000u;
+#endif
   a.image_nx = p->image_nx;
   a.image_ny = p->image_ny;
   a.image_x_min = p->image_x_min;
@@ -598,7 +607,9 @@ int sart_create(int device_ordinal, sart_context** out) {
   {
     auto flag = [](const char* name) { return std::getenv(name) != nullptr; };
     auto number = [](const char* name) { const char* e = std::getenv(name); return e ? std::max(0, std::atoi(e)) : 0; };
+#ifdef SART_DEBUG_KNOBS
     c->knobs.no_image_atomics = flag("SART_DEBUG_NO_IMAGE_ATOMICS");
+#endif
     c->knobs.no_early_reject = flag("SART_NO_EARLY_REJECT");
     c->knobs.force_generic = flag("SART_FORCE_GENERIC");
     c->knobs.image_replicas = number("SART_IMAGE_REPLICAS");
@@ -620,7 +631,14 @@ int sart_destroy(sart_context* c) {
 
 int sart_set_stream(sart_context* c, void* hip_stream) {
   if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
-  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  if (next != c->stream) {
+    // the scratch buffers of the context (image replicas, per-workgroup partials, parameter blob) are shared by all
+    // launches: work queued on the old stream must have finished before launches on the new one reuse them
+    SART_HIP(hipSetDevice(c->device));
+    SART_HIP(hipStreamSynchronize(c->stream));
+  }
+  c->stream = next;
   return 0;
 }
 
@@ -670,7 +688,8 @@ int sart_set_telescope_angles(sart_context* c, double tx, double ty) {
   if (!std::isnan(tx)) c->setup.telescope_turned_x_deg = tx;
   if (!std::isnan(ty)) c->setup.telescope_turned_y_deg = ty;
   if (c->derived_dirty) return 0;
-  // cheap path: only the parameter blob changes (the shell table does not depend on the angles)
+  // cheap path: only the parameter blob changes (the shell table does not depend on the angles); sync_blob() waits
+  // for the launches that still read the old blob before it uploads the new one
   c->blob_dirty = true;
   return hoist_setup(c);
 }
@@ -844,9 +863,10 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
     if (c->knobs.hist_blocks_per_cu > 0) c->blocks_per_cu_hist[variant] = c->knobs.hist_blocks_per_cu;
   }
   const int n_blocks = grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_hist[variant], histogram_block_of(variant));
-  if (c->d_partials.n < static_cast<size_t>(n_blocks) * SART_ACC_COUNT) {
+  if (c->d_partials.n < static_cast<size_t>(n_blocks) * SART_ACC_COUNT) {   // one row of scalars per workgroup
     SART_HIP(hipStreamSynchronize(c->stream));
-    if (int rc = c->d_partials.resize(static_cast<size_t>(c->n_cu) * 16 * SART_ACC_COUNT)) return rc;
+    const size_t rows = std::max<size_t>(static_cast<size_t>(n_blocks), static_cast<size_t>(c->n_cu) * 4);
+    if (int rc = c->d_partials.resize(rows * SART_ACC_COUNT)) return rc;
   }
   a.partials = c->d_partials.p;
   {

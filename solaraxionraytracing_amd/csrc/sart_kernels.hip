@@ -937,7 +937,11 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       const double fy = floor((out.py - Ab.image_y_min) * Ab.image_inv_step_y);
       const int nx = A.image_nx, ny = A.image_ny;
       const bool inside = fx >= 0.0 && fx < (double)nx && fy >= 0.0 && fy < (double)ny;
-      if (inside && !(A.flags & 0x40000000u))
+#ifdef SART_DEBUG_KNOBS
+      if (inside && !(A.flags & 0x40000000u))   // SART_DEBUG_NO_IMAGE_ATOMICS (experiment builds only)
+#else
+      if (inside)
+#endif
         unsafeAtomicAdd(&img[(size_t)((int)fy) * (size_t)nx + (size_t)((int)fx)], out.weight);
       out.outside = !inside;
       if (A.spectra) {   // wave-uniform: radial and per-energy histograms behind the scalars

@@ -1,0 +1,33 @@
+#!/bin/bash
+# One measurement round on the GPU box:  bash tools/gpu_round.sh <tag> [tests] [bench] [stats] [pmc] [pmc_side]
+#   tests     pytest -m gpu                                  -> gpurun_out/pytest_gpu_<tag>.log
+#   bench     python bench.py                                -> gpurun_out/bench_<tag>.json
+#   stats     rocprofv3 --kernel-trace --stats on bench.py   -> gpurun_out/prof_<tag>/
+#   pmc       PMC passes, headline workload (1e9-ray launches) -> gpurun_out/pmc_<tag>_babyiaxo_xmm/
+#   pmc_side  PMC passes, CAST / gas / rotated (1e8-ray launches)
+# Steps are joined with && semantics (set -e): nothing runs after a failed GPU step.
+set -e -o pipefail
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $ROOT/gpurun_out
+for STEP in "$@"; do
+  case $STEP in
+    tests)
+      (cd $ROOT && timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1) || { tail -30 $ROOT/gpurun_out/pytest_gpu_$TAG.log; exit 1; }
+      tail -3 $ROOT/gpurun_out/pytest_gpu_$TAG.log ;;
+    bench)
+      (cd $ROOT && timeout -k 10 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err) || { tail -20 $ROOT/gpurun_out/bench_$TAG.err; exit 1; }
+      cat $ROOT/gpurun_out/bench_$TAG.json | python3 -c "import json,sys; d=json.load(sys.stdin); print(d['value'], d['ms_per_step'], json.dumps(d['roofline'])[:600]); [print(w['workload'][:40], w['rays_per_s']) for w in d.get('other_workloads',[])]; print(d.get('cpu_baseline'))" ;;
+    stats)
+      (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -- python3 $ROOT/bench.py --profile-run --steps 5 --warmup 2 > $ROOT/gpurun_out/prof_$TAG.log 2>&1) || { tail -20 $ROOT/gpurun_out/prof_$TAG.log; exit 1; }
+      find $ROOT/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs head -5 ;;
+    pmc)
+      (cd $ROOT && timeout -k 10 900 bash tools/pmc_profile.sh ${TAG}_babyiaxo_xmm --workload babyiaxo_xmm) ;;
+    pmc_side)
+      for W in cast_llnl_gold babyiaxo_xmm_gas babyiaxo_xmm_rot; do
+        (cd $ROOT && timeout -k 10 900 bash tools/pmc_profile.sh ${TAG}_$W --workload $W --rays-per-step 1e8)
+      done ;;
+    *) echo "unknown step $STEP"; exit 2 ;;
+  esac
+  echo "== step $STEP done"
+done

@@ -2,6 +2,8 @@
 # Collects rocprofv3 PMC counters for the hot-path kernel in separate passes (never combined with
 # tracing, see the gpurun rules).  Usage on the GPU box:  bash tools/pmc_profile.sh <tag> [bench args...]
 # Output: gpurun_out/pmc_<tag>/pass*/...counter_collection.csv ; summarise with tools/pmc_summary.py.
+# Passes 1-3: SQ (instruction mix, issue, waits, LDS); 4-9: TCC (fabric traffic by request size, FETCH_SIZE /
+# WRITE_SIZE, L2 hit rate); 10: GRBM (clock).
 set -e
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -12,8 +14,10 @@ PASSES=(
  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"
  "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_LDS"
  "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_CVT"
+ "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
+ "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_ATOMIC_sum TCC_EA0_RDREQ_DRAM_sum"
  "FETCH_SIZE"
- "WRITE_SIZE TCC_EA0_ATOMIC_sum"
+ "WRITE_SIZE TCC_EA0_WRREQ_DRAM_sum"
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum"
  "GRBM_GUI_ACTIVE GRBM_COUNT"
 )

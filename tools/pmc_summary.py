@@ -1,27 +1,111 @@
 #!/usr/bin/env python3
-"""Summarises the per-dispatch PMC CSVs of tools/pmc_profile.sh for one kernel: mean counter value per launch."""
-import csv, glob, os, sys, json
-d = sys.argv[1]
-kernel = sys.argv[2] if len(sys.argv) > 2 else "trace_histogram"
-res = {}
-for f in sorted(glob.glob(os.path.join(d, "pass*", "**", "*counter_collection.csv"), recursive=True)):
-    acc = {}
-    for r in csv.DictReader(open(f)):
-        if kernel not in r["Kernel_Name"]:
-            continue
-        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        res[k] = sum(v) / len(v)
-for k in sorted(res):
-    print("%-28s %.6g" % (k, res[k]))
-if "SQ_WAVE_CYCLES" in res:
-    w = res
+"""Summarises the per-dispatch PMC CSVs of tools/pmc_profile.sh for the hot-path kernel: mean counter value per launch
+plus the derived per-ray figures `bench.py` turns into its `roofline` block.
+
+  python tools/pmc_summary.py gpurun_out/pmc_<tag> --workload babyiaxo_xmm --rays 1e9 [--publish r02_v16]
+
+--publish NAME copies the summary to profiles/NAME_<workload>_pmc_summary.json and points profiles/pmc_current.json's entry
+for <workload> at it (bench.py reads pmc_current.json; it cannot collect PMC counters from inside its own process).
+
+Derived figures and their formulas (all per launch of `rays` rays, counters are means over the profiled launches):
+  valu_insts_per_64_rays  = SQ_INSTS_VALU * 64 / rays
+  f64_flop_per_ray        = (2 FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) * 64 lanes / rays      (wave instructions x 64 lanes)
+  valu_issue_utilisation  = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES * waves_per_simd, waves_per_simd = SQ_WAVES / (4 n_cu)
+                            (both counters are quad-cycles summed over waves; every wave lives for the whole launch)
+  fabric_read_bytes       = 32 RDREQ_32B + 64 RDREQ_64B + 128 RDREQ_128B   (TCC_EA0_RDREQ by size; cross-check: 2 x FETCH_SIZE
+                            x 1024, the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md)
+  fabric_write_bytes      = WRITE_SIZE x 1024
+  fabric_bytes_per_ray    = (read + write) / rays        (L2 <-> fabric; Infinity-Cache hits included: upper bound on HBM)
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def collect(d, kernel):
+    res = {}
+    for f in sorted(glob.glob(os.path.join(d, "pass*", "**", "*counter_collection.csv"), recursive=True)):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if kernel not in r["Kernel_Name"]:
+                continue
+            acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            res[k] = sum(v) / len(v)
+    return res
+
+
+def derive(w, rays, n_cu):
     g = lambda k: w.get(k, float("nan"))
-    print("--- derived (per launch)")
-    print("VALU insts / wave            %.1f" % (g("SQ_INSTS_VALU") / g("SQ_WAVES")))
-    print("VALU lane utilisation        %.3f" % (g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))))
-    print("wave-cycles/wave (x4 = clk)  %.0f" % (g("SQ_WAVE_CYCLES") / g("SQ_WAVES")))
-    print("WAIT_ANY / WAVE_CYCLES       %.3f" % (g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")))
-    print("WAIT_INST_ANY / WAVE_CYCLES  %.3f" % (g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")))
-    print("ACTIVE_INST_VALU / WAVE_CYC  %.3f" % (g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES")))
-json.dump(res, open(os.path.join(d, "summary.json"), "w"), indent=1)
+    out = {}
+    if "SQ_WAVE_CYCLES" in w:
+        wps = g("SQ_WAVES") / (4.0 * n_cu)
+        out["waves_per_simd"] = wps
+        out["valu_insts_per_64_rays"] = g("SQ_INSTS_VALU") * 64.0 / rays
+        out["valu_issue_utilisation"] = g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES") * wps
+        out["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
+        out["wait_any_fraction"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
+        out["wait_inst_any_fraction"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
+        out["cycles_per_valu_inst"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / g("SQ_INSTS_VALU")
+    if "SQ_INSTS_VALU_FMA_F64" in w:
+        f64 = g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_TRANS_F64")
+        out["f64_flop_per_ray"] = (2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_ADD_F64") +
+                                   g("SQ_INSTS_VALU_TRANS_F64")) * 64.0 / rays
+        if "SQ_INSTS_VALU" in w:
+            out["f64_share_of_valu_insts"] = f64 / g("SQ_INSTS_VALU")
+            out["int_share_of_valu_insts"] = (g("SQ_INSTS_VALU_INT32") + g("SQ_INSTS_VALU_INT64")) / g("SQ_INSTS_VALU")
+    if "SQ_LDS_BANK_CONFLICT" in w:
+        out["lds_conflict_cycles_per_active_lds_cycle"] = g("SQ_LDS_BANK_CONFLICT") / max(1.0, g("SQ_ACTIVE_INST_LDS"))
+    if "TCC_EA0_RDREQ_128B_sum" in w:
+        rd = 32 * g("TCC_EA0_RDREQ_32B_sum") + 64 * g("TCC_EA0_RDREQ_64B_sum") + 128 * g("TCC_EA0_RDREQ_128B_sum")
+        out["fabric_read_bytes_per_ray"] = rd / rays
+        if "FETCH_SIZE" in w:
+            out["fabric_read_bytes_per_ray_from_2x_fetch_size"] = 2.0 * g("FETCH_SIZE") * 1024.0 / rays
+        if "WRITE_SIZE" in w:
+            out["fabric_write_bytes_per_ray"] = g("WRITE_SIZE") * 1024.0 / rays
+            out["fabric_bytes_per_ray"] = out["fabric_read_bytes_per_ray"] + out["fabric_write_bytes_per_ray"]
+    if "TCC_HIT_sum" in w:
+        out["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dir")
+    ap.add_argument("--kernel", default="trace_histogram")
+    ap.add_argument("--workload", default="babyiaxo_xmm")
+    ap.add_argument("--rays", type=float, default=1e9, help="rays per profiled launch (bench.py --rays-per-step)")
+    ap.add_argument("--n-cu", type=int, default=256)
+    ap.add_argument("--publish", default=None)
+    args = ap.parse_args()
+    res = collect(args.dir, args.kernel)
+    der = derive(res, args.rays, args.n_cu)
+    for k in sorted(res):
+        print("%-32s %.6g" % (k, res[k]))
+    print("--- derived")
+    for k, v in der.items():
+        print("%-48s %.6g" % (k, v))
+    out = {"workload": args.workload, "kernel": args.kernel, "rays_per_launch": args.rays, "n_cu": args.n_cu,
+           "derived": der, "counters": res,
+           "how": "rocprofv3 --pmc in separate passes (tools/pmc_profile.sh), mean over the profiled launches; formulas in "
+                  "tools/pmc_summary.py"}
+    json.dump(out, open(os.path.join(args.dir, "summary.json"), "w"), indent=1)
+    if args.publish:
+        name = "%s_%s_pmc_summary.json" % (args.publish, args.workload)
+        json.dump(out, open(os.path.join(ROOT, "profiles", name), "w"), indent=1)
+        cur_path = os.path.join(ROOT, "profiles", "pmc_current.json")
+        try:
+            cur = json.load(open(cur_path))
+        except Exception:
+            cur = {}
+        cur[args.workload] = {"source": "profiles/" + name, "rays_per_launch": args.rays, **der}
+        json.dump(cur, open(cur_path, "w"), indent=1)
+        print("published profiles/%s" % name)
+
+
+if __name__ == "__main__":
+    main()
