@@ -27,6 +27,12 @@ for STEP in "$@"; do
       for W in cast_llnl_gold babyiaxo_xmm_gas babyiaxo_xmm_rot; do
         (cd $ROOT && timeout -k 10 900 bash tools/pmc_profile.sh ${TAG}_$W --workload $W --rays-per-step 1e8)
       done ;;
+    quick)   # iteration loop: throughput table + instruction-count PMC passes (1-2) for the headline workload and CAST
+      (cd $ROOT && timeout -k 10 300 python tools/throughput_table.py > gpurun_out/tt_$TAG.txt 2>&1) || { tail -20 $ROOT/gpurun_out/tt_$TAG.txt; exit 1; }
+      cat $ROOT/gpurun_out/tt_$TAG.txt
+      (cd $ROOT && PMC_PASSES="1 2" timeout -k 10 600 bash tools/pmc_profile.sh ${TAG}_babyiaxo_xmm --workload babyiaxo_xmm)
+      (cd $ROOT && PMC_PASSES="1 2" timeout -k 10 600 bash tools/pmc_profile.sh ${TAG}_cast_llnl_gold --workload cast_llnl_gold --rays-per-step 1e8)
+      (cd $ROOT && python tools/pmc_summary.py gpurun_out/pmc_${TAG}_babyiaxo_xmm --rays 1e9 | tail -12 && python tools/pmc_summary.py gpurun_out/pmc_${TAG}_cast_llnl_gold --rays 1e8 | tail -12) ;;
     *) echo "unknown step $STEP"; exit 2 ;;
   esac
   echo "== step $STEP done"

@@ -24,6 +24,7 @@ PASSES=(
 i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
+  if [ -n "$PMC_PASSES" ] && ! echo " $PMC_PASSES " | grep -q " $i "; then continue; fi   # PMC_PASSES="1 2": only those passes
   rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --profile-run --steps 2 --warmup 1 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
   echo "pass $i done: $P"
 done
