@@ -83,6 +83,31 @@ double linear1d(const std::vector<double>& xs, const std::vector<double>& ys, do
   return ys[lo] + (x - xs[lo]) * (ys[lo + 1] - ys[lo]) / (xs[lo + 1] - xs[lo]);
 }
 
+// (cos, sin)(pi k / 64) for k = 0 .. 128, rounded from long double.  Only the first octant is evaluated (arguments
+// <= pi/4, where sinl / cosl lose nothing); the rest follows by symmetry, so the zeros and ones at the multiples of
+// pi/2 are exact and sin^2 + cos^2 has the same rounding in every octant.
+std::vector<double> sincos_table() {
+  std::vector<double> t(2 * static_cast<size_t>(kSinCosEntries));
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int k = 0; k < kSinCosEntries; ++k) {
+    const int q = k / 32, j = k % 32;          // angle = q pi/2 + j pi/64
+    long double c, sn;
+    if (j <= 16) { c = cosl(pi * j / 64); sn = sinl(pi * j / 64); }
+    else { c = sinl(pi * (32 - j) / 64); sn = cosl(pi * (32 - j) / 64); }
+    if (j == 0) { c = 1.0L; sn = 0.0L; }
+    double cd = static_cast<double>(c), sd = static_cast<double>(sn);
+    switch (q & 3) {                            // rotate by q quarter turns
+      case 0: t[2 * k] = cd; t[2 * k + 1] = sd; break;
+      case 1: t[2 * k] = -sd; t[2 * k + 1] = cd; break;
+      case 2: t[2 * k] = -cd; t[2 * k + 1] = -sd; break;
+      default: t[2 * k] = sd; t[2 * k + 1] = -cd; break;
+    }
+    if (t[2 * k] == 0.0) t[2 * k] = 0.0;        // no negative zeros
+    if (t[2 * k + 1] == 0.0) t[2 * k + 1] = 0.0;
+  }
+  return t;
+}
+
 size_t lower_bound_idx(const double* a, size_t n, double key) {
   return static_cast<size_t>(std::lower_bound(a, a + n, key) - a);
 }
@@ -126,6 +151,7 @@ struct sart_context {
   std::vector<uint8_t> shell_lut;
   int radius_span = 0;
   DevBuf<ShellDev> d_shells;
+  DevBuf<double> d_sincos;     // (cos, sin)(pi k / 64), k = 0 .. 128 (sampling angles, sart_kernels.hip: sincos_turns)
   DevBuf<uint8_t> d_lut;
   DevBuf<double> d_rcdf, d_ecdf, d_refl;
   DevBuf<uint16_t> d_rguide, d_eguide;
@@ -533,6 +559,7 @@ int sync_blob(sart_context* c) {
 
 DevTables tables_of(sart_context* c) {
   DevTables t;
+  t.sincos_tab = c->d_sincos.p;
   t.shells = c->d_shells.p;
   t.shell_lut = c->d_lut.p;
   t.flux_radius_cdf = c->d_rcdf.p;
@@ -604,6 +631,14 @@ int sart_create(int device_ordinal, sart_context** out) {
     return fail(SART_ERR_NO_DEVICE, "hipStreamCreate failed");
   }
   c->stream = c->own_stream;
+  {
+    const std::vector<double> sc = sincos_table();
+    if (int rc = c->d_sincos.upload(sc.data(), sc.size())) {
+      (void)hipStreamDestroy(c->own_stream);
+      delete c;
+      return rc;
+    }
+  }
   {
     auto flag = [](const char* name) { return std::getenv(name) != nullptr; };
     auto number = [](const char* name) { const char* e = std::getenv(name); return e ? std::max(0, std::atoi(e)) : 0; };

@@ -21,6 +21,7 @@ constexpr int kRadiusGuide = 2048;   // buckets of the guide table in front of f
 constexpr int kEnergyGuide = 2048;    // buckets per radius row in front of diffFluxCDFs
 constexpr int kShellLutMax = 1024;   // cells of the radial look-up table of the shell selection
 constexpr int kMaxRadii = 2048;      // fluxRadiusCDF entries that fit the LDS stage
+constexpr int kSinCosEntries = 129;  // (cos, sin)(pi k / 64), k = 0 .. 128: table behind the sampling angles
 
 // Per-shell constants (Wolter-I pair j).  Quadratics are expressed in the telescope frame with
 // the ray parametrised by z:  X(z) = X0 + sx z,  Y(z) = Y0 + sy z, so that with
@@ -141,6 +142,7 @@ constexpr int kMaxZones = 4;
 
 // Device pointers of one context.
 struct DevTables {
+  const double* sincos_tab;           // [kSinCosEntries][2]: (cos, sin)(pi k / 64), correctly rounded
   const ShellDev* shells;             // [n_shells]
   const uint8_t* shell_lut;           // [lut_n]: first shell with R1 > k * lut_step
   const double* flux_radius_cdf;      // [n_radii]

@@ -67,70 +67,80 @@ __device__ __forceinline__ uint32_t word_of(const U4& b, uint32_t k) {
 // instructions); the builtin takes the compare's lane mask as it is.
 __device__ __forceinline__ uint64_t ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 
+// A compile-time f64 constant in a scalar register pair.  LLVM otherwise materialises a polynomial coefficient with two
+// v_mov_b32 into the destination of a two-address v_fmac_f64 (three vector instructions per Horner step instead of
+// one); s_mov_b32 issues on the scalar unit beside other waves' vector instructions.  `volatile` keeps the moves next to
+// their use (hoisted out of the persistent loop the registers would be spilled through VGPR lanes).
+template <uint64_t BITS>
+__device__ __forceinline__ double scalar_const() {
+  uint32_t lo, hi;
+  asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "n"((uint32_t)BITS), "n"((uint32_t)(BITS >> 32)));
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | (uint64_t)lo));
+}
+#define SC(x) (scalar_const<__builtin_bit_cast(uint64_t, (double)(x))>())
+
 // Uniform in [0, 1) from two words (hi word first): 52 random mantissa bits under the exponent of 1.0,
 // minus 1.0 — the construction of Nim's std/random rand(1.0) (and of the oracle).
 __device__ __forceinline__ double u52(uint32_t hi, uint32_t lo) {
-  const uint64_t bits = ((uint64_t)hi << 32) | (uint64_t)lo;
-  return __longlong_as_double((long long)(0x3FF0000000000000ull | (bits >> 12))) - 1.0;
+  // 0x3FF0000000000000 | ((hi:lo) >> 12) as two funnel shifts (v_alignbit_b32): low word = (hi:lo) >> 12, high word =
+  // (0x3FF:hi) >> 12 = 0x3FF00000 | (hi >> 12)
+  const uint32_t mlo = __builtin_amdgcn_alignbit(hi, lo, 12u);
+  const uint32_t mhi = __builtin_amdgcn_alignbit(0x3FFu, hi, 12u);
+  return __longlong_as_double((long long)(((uint64_t)mhi << 32) | (uint64_t)mlo)) - 1.0;
 }
 
 // ------------------------------------------------------------------------------------------------
 // small math helpers
 // ------------------------------------------------------------------------------------------------
-// 1/x and sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~26 bits) plus two Newton steps:
-// <= 1 ulp, without the scaling / fix-up sequence of the IEEE-exact expansions (the path never meets
-// denormals or infinities here, and every consumer is tolerance-compared, never bit-compared).
+// 1/x, 1/sqrt(x) and sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64, relative error e0 <= ~2^-23) plus ONE
+// third-order step (error ~e0^3 < 2^-68, i.e. the result is the seed-independent f64 rounding, <= 1 ulp) instead of
+// the scaling / fix-up sequence of the IEEE-exact expansions: the path never meets denormals or infinities here, and
+// every consumer is tolerance-compared, never bit-compared.  tests/test_gpu_math.py measures the errors on the device.
 __device__ __forceinline__ double frcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return fma(fma(-x, r, 1.0), r, r);
+  const double r = __builtin_amdgcn_rcp(x);
+  const double e = fma(-x, r, 1.0);           // 1/x = r / (1 - e) = r (1 + e + e^2 + ...)
+  return fma(r, fma(e, e, e), r);
 }
 __device__ __forceinline__ double frsq(double x) {   // 1/sqrt(x), x > 0
-  double y = __builtin_amdgcn_rsq(x);
-  y = fma(y * fma(-x * y, y, 1.0), 0.5, y);
-  return fma(y * fma(-x * y, y, 1.0), 0.5, y);
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-(x * y), y, 1.0);     // 1/sqrt(x) = y / sqrt(1 - e) = y (1 + e/2 + 3 e^2 / 8 + ...)
+  return fma(y, e * fma(0.375, e, 0.5), y);
+}
+// sqrt(x) for x > 0: Goldschmidt step from the seed + one Newton correction of the residual.  x < 0 gives NaN (every
+// comparison downstream is then false: a miss); x == 0 also gives NaN (0 * inf) - use fsqrt() where an exact zero can occur.
+__device__ __forceinline__ double fsqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  const double h = 0.5 * y;
+  g = fma(g, fma(-h, g, 0.5), g);             // error ~ 3/8 e0^2
+  return fma(fma(-g, g, x), h, g);            // g + (x - g^2) / (2 sqrt x); h's own error only enters at e0^3
 }
 __device__ __forceinline__ double fsqrt(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;
-  const double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  g = fma(fma(-g, g, x), h, g);
+  const double g = fsqrt_pos(x);
   return (x > 0.0) ? g : ((x == 0.0) ? 0.0 : __builtin_nan(""));   // rsq(0) = inf would give NaN; negative -> NaN
 }
 
-// sin(pi a), cos(pi a) for a in [0, 2] (a = 2u or u with u uniform in [0, 1)): n = rint(2a), r = a - n/2 in
-// [-1/4, 1/4], Taylor series in (pi r) (truncation < 6e-17 relative), quadrant from n.  The library sincospi carries
-// range reduction and inf/NaN handling for arbitrary arguments that this path never needs.
-__device__ __forceinline__ void sincospi_02(double a, double* sn, double* cs) {
-  const double n = __builtin_rint(a + a);
-  const double r = fma(-0.5, n, a);
-  const int q = (int)n;                          // 0 .. 4
+// sin and cos of pi a, a = TURNS * u for u in [0, 1) (TURNS = 2: a full turn, 1: half a turn), to <= ~1.5 ulp:
+// k = rint(64 a), r = a - k / 64 exactly (|r| <= 1/128), (C, S) = (cos, sin)(pi k / 64) from the 129-entry table in LDS
+// (correctly rounded on the host, exact zeros and ones at the multiples of pi/2), short Taylor polynomials in r
+// (truncation < 4e-17 relative for |pi r| <= pi/128) and the angle-addition formulas.  No quadrant selects, and 7
+// polynomial coefficients (scalar registers, shared by the three evaluations of a ray) instead of 16.
+struct SinCosCoef { double s3, s2, s1, s0, d3, d2, d1; };   // sin(pi r) = r (s0 + y (s1 + y (s2 + y s3))), cos(pi r) = 1 + y (d1 + ...)
+__device__ __forceinline__ SinCosCoef sincos_coef() {
+  return SinCosCoef{SC(-0.5992645293207921), SC(2.5501640398773455), SC(-5.16771278004997), SC(3.141592653589793),
+                    SC(-1.3352627688545895), SC(4.0587121264167685), SC(-4.934802200544679)};
+}
+template <int TURNS>
+__device__ __forceinline__ void sincos_turns(double u, const double* __restrict__ table, const SinCosCoef& K, double* sn, double* cs) {
+  constexpr double T = (double)TURNS;
+  const double kf = __builtin_rint(u * (64.0 * T));          // 0 .. 64 TURNS
+  const double r = fma(-1.0 / 64.0, kf, u * T);              // T u - k / 64, exact (T is a power of two)
+  const double2 t = reinterpret_cast<const double2*>(table)[(int)kf];   // one ds_read_b128: (C, S)
   const double x = r * r;
-  double ps = -2.1915353447830204e-05;           // coefficients (-1)^k pi^(2k+1) / (2k+1)!, k = 7 .. 0
-  ps = fma(ps, x, 4.6630280576761234e-04);
-  ps = fma(ps, x, -7.370430945714348e-03);
-  ps = fma(ps, x, 8.214588661112819e-02);
-  ps = fma(ps, x, -5.992645293207919e-01);
-  ps = fma(ps, x, 2.550164039877345e+00);
-  ps = fma(ps, x, -5.167712780049969e+00);
-  ps = fma(ps, x, 3.141592653589793e+00);
-  const double sr = ps * r;                      // sin(pi r)
-  double pc = 4.303069587032944e-06;             // coefficients (-1)^k pi^(2k) / (2k)!, k = 8 .. 1
-  pc = fma(pc, x, -1.0463810492484565e-04);
-  pc = fma(pc, x, 1.929574309403922e-03);
-  pc = fma(pc, x, -2.580689139001405e-02);
-  pc = fma(pc, x, 2.3533063035889312e-01);
-  pc = fma(pc, x, -1.3352627688545893e+00);
-  pc = fma(pc, x, 4.058712126416768e+00);
-  pc = fma(pc, x, -4.934802200544679e+00);
-  const double cr = fma(pc, x, 1.0);             // cos(pi r)
-  // a = n/2 + r:  sin(pi a) = sin(n pi/2) cos(pi r) + cos(n pi/2) sin(pi r), etc.
-  const bool odd = (q & 1) != 0;
-  const double s0 = odd ? cr : sr, c0 = odd ? sr : cr;
-  *sn = (q & 2) ? -s0 : s0;                      // n = 0: s, 1: c, 2: -s, 3: -c, 4: s
-  *cs = ((q + 1) & 2) ? -c0 : c0;                // n = 0: c, 1: -s, 2: -c, 3: s, 4: c
+  const double sr = fma(fma(fma(K.s3, x, K.s2), x, K.s1), x, K.s0) * r;
+  const double cr = fma(fma(fma(K.d3, x, K.d2), x, K.d1), x, 1.0);
+  *sn = fma(t.x, sr, t.y * cr);                               // sin(a + b) = S cr + C sr
+  *cs = fma(-t.y, sr, t.x * cr);                              // cos(a + b) = C cr - S sr
 }
 
 // asin for the grazing angles of the path (|x| < ~0.03): odd Taylor series
@@ -139,13 +149,13 @@ __device__ __forceinline__ void sincospi_02(double a, double* sn, double* cs) {
 __device__ __forceinline__ double asin_small(double x) {
   if (fabs(x) < 0.06) {
     const double x2 = x * x;
-    double p = 0.01396484375;               // 143/10240
-    p = fma(p, x2, 0.017352764423076924);   // 231/13312
-    p = fma(p, x2, 0.022372159090909092);   // 63/2816
-    p = fma(p, x2, 0.030381944444444444);   // 35/1152
-    p = fma(p, x2, 0.044642857142857144);   // 5/112
-    p = fma(p, x2, 0.075);                  // 3/40
-    p = fma(p, x2, 0.16666666666666666);    // 1/6
+    double p = SC(0.01396484375);               // 143/10240
+    p = fma(p, x2, SC(0.017352764423076924));   // 231/13312
+    p = fma(p, x2, SC(0.022372159090909092));   // 63/2816
+    p = fma(p, x2, SC(0.030381944444444444));   // 35/1152
+    p = fma(p, x2, SC(0.044642857142857144));   // 5/112
+    p = fma(p, x2, SC(0.075));                  // 3/40
+    p = fma(p, x2, SC(0.16666666666666666));    // 1/6
     return fma(x * x2, p, x);
   }
   return asin(x);
@@ -186,6 +196,23 @@ __device__ __forceinline__ double cos_small(double x) {
   return cos(x);
 }
 
+// cos(ya) for the yaw angle ya = -deg(atan(t)) of a ray with slope t, the degree value taken as radians - sic
+// (:1598, :2101-2115): cos((180 / pi) atan t) as ONE even power series in t (composed at 60 digits, mpmath), valid for
+// |t| < 0.006 (every ray from the Sun: |slope| < 4.7e-3), truncation error < 7e-18; the two-step evaluation outside.
+__device__ __forceinline__ double cos_yaw_of_slope(double t) {
+  if (fabs(t) < 0.006) {
+    const double x = t * t;
+    double p = SC(2976939695167.2104);           // t^12
+    p = fma(p, x, SC(-112889008417.68803));      // t^10
+    p = fma(p, x, SC(2979383355.295581));        // t^8
+    p = fma(p, x, SC(-49735946.89381117));       // t^6
+    p = fma(p, x, SC(450128.3326032301));        // t^4
+    p = fma(p, x, SC(-1641.403175005872));       // t^2 : -(180 / pi)^2 / 2
+    return fma(p, x, 1.0);
+  }
+  return cos_small(-atan_small(t) * 57.29577951308232);
+}
+
 // The table pointers of a launch are read from the LDS copy of the parameter blob, where the compiler cannot see
 // their address space and would emit flat_load (which counts on both vmcnt and lgkmcnt and so serialises against the
 // LDS traffic of the same wave).  They always point to global memory: say so.
@@ -194,6 +221,17 @@ using global_ptr = const __attribute__((address_space(1))) T*;
 template <typename T>
 __device__ __forceinline__ global_ptr<T> as_global(const T* p) {
   return (global_ptr<T>)p;
+}
+
+// An object in LDS seen through an address the compiler cannot fold: field accesses become ds_read with ONE base register
+// and immediate offsets.  With the address known at compile time every access to a field beyond the 64 KB immediate range
+// gets its own v_mov_b32 of the absolute address (one vector instruction per parameter read).
+template <typename T>
+__device__ __forceinline__ const T& lds_opaque(const T& obj) {
+  typedef const __attribute__((address_space(3))) T* lds_ptr;
+  uint32_t a = (uint32_t)(uintptr_t)(lds_ptr)&obj;
+  asm volatile("" : "+v"(a));
+  return *(const T*)(lds_ptr)(uintptr_t)a;
 }
 
 // lowerBound(a, key) with the answer known to lie in [lo, hi] (guide-table bracket):
@@ -212,15 +250,18 @@ __device__ __forceinline__ int lower_bound_bracket(Ptr a, int lo, int hi, double
 // evaluated without cancellation (q-form); root1 is preferred, then root2, else miss (:651-656).
 __device__ __forceinline__ bool pick_root(double a, double hb, double c, double zlo, double zhi, double& z) {
   const double disc = fma(hb, hb, -a * c);
-  const double sq = fsqrt(disc);  // NaN for disc < 0 -> every comparison below is false -> miss
-  const double q = (hb >= 0.0) ? (-hb - sq) : (-hb + sq);
+  const double sq = fsqrt_pos(disc);  // NaN for disc <= 0 -> every comparison below is false -> miss (disc == 0: tangent ray, measure zero)
+  // q = -(hb + sign(hb) sq); the two roots are q / a and c / q.  With hb >= 0 (sign bit clear) q / a is the reference's
+  // root1 and c / q its root2, with hb < 0 the other way round.
+  const double q = -hb - copysign(sq, hb);
   const double raq = frcp(a * q);            // one reciprocal: 1/a = q raq, 1/q = a raq
-  const double qa = q * q * raq, cq = c * a * raq;
-  const double root1 = (hb >= 0.0) ? qa : cq;
-  const double root2 = (hb >= 0.0) ? cq : qa;
-  if (root1 > zlo && root1 < zhi) { z = root1; return true; }
-  if (root2 > zlo && root2 < zhi) { z = root2; return true; }
-  return false;
+  const double ra = q * q * raq, rb = c * a * raq;
+  const bool in_a = (ra > zlo) & (ra < zhi), in_b = (rb > zlo) & (rb < zhi);
+  // root1 if it lies in the mirror's z range, else root2, else miss (:651-656): only when both roots are in range does
+  // the order matter, and then root1 is q / a exactly when the sign bit of hb is clear
+  const bool a_first = __double2hiint(hb) >= 0;
+  z = (in_b & !(in_a & a_first)) ? rb : ra;
+  return in_a | in_b;
 }
 
 // Reflection of the (un-normalised) direction w, |w|^2 = L, at a surface with (un-normalised)
@@ -237,14 +278,13 @@ __device__ __forceinline__ double reflect(double& wx, double& wy, double& wz, do
   wx = fma(-2.0 * f, nx, ox);                // mirror reflection (normal on the far side of the ray: n.w >= 0)
   wy = fma(-2.0 * f, ny, oy);
   wz = fma(-2.0 * f, nz, oz);
-  if (ballot64(dnw < 0.0)) {                 // wave-uniform; practically never taken
+  if (dnw < 0.0) {                           // practically never taken (skipped when no lane needs it)
     // normal facing the ray: the reference's formula is then not a mirror reflection; keep it
+    asm volatile("; rare: normal facing the ray");   // keeps LLVM from turning the block into always-executed selects
     const double k = 1.0 - 4.0 * c2;
-    if (dnw < 0.0) {
-      wx = fma(2.0 * f, nx, k * ox);
-      wy = fma(2.0 * f, ny, k * oy);
-      wz = fma(2.0 * f, nz, k * oz);
-    }
+    wx = fma(2.0 * f, nx, k * ox);
+    wy = fma(2.0 * f, ny, k * oy);
+    wz = fma(2.0 * f, nz, k * oz);
   }
   return c2;
 }
@@ -265,6 +305,7 @@ __device__ __forceinline__ double normal_z_general(const DevParams& P, const She
 // LDS-resident tables of one workgroup
 // ------------------------------------------------------------------------------------------------
 struct LdsTables {
+  const double* sincos;      // (cos, sin)(pi k / 64), k = 0 .. 128
   const double* rcdf;        // fluxRadiusCDF
   const uint16_t* rguide;    // guide table in front of it
   const ShellDev* shells;
@@ -353,8 +394,9 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   if (!cfg_test) {
     // getRandomPointFromSolarModel (:425-442): theta1 = 360 u0 deg, theta2 = 180 u1 deg (uniform in theta)
     double s1, c1, s2, c2;
-    sincospi_02(2.0 * u0, &s1, &c1);
-    sincospi_02(u1, &s2, &c2);
+    const SinCosCoef K = sincos_coef();   // one set of scalar constants for the three evaluations
+    sincos_turns<2>(u0, L.sincos, K, &s1, &c1);
+    sincos_turns<1>(u1, L.sincos, K, &s2, &c2);
     {
       // lowerBound(fluxRadiusCDF, u2) (:437) inside the guide bracket; bounded, branch-free walk
       const int k = (int)(u2 * (double)kRadiusGuide);
@@ -371,7 +413,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
     const double ox = c1 * s2 * r, oy = s1 * s2 * r, oz = c2 * r - H.sun_distance;
     // getRandomPointOnDisk (:412-422)
     double sp, cp;
-    sincospi_02(2.0 * u4, &sp, &cp);
+    sincos_turns<2>(u4, L.sincos, K, &sp, &cp);
     const double rr = H.radius_cb * fsqrt(u3);
     ex = cp * rr;
     ey = sp * rr;
@@ -381,7 +423,8 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   } else {
     // X-ray test source (:1765-1806)
     double sp, cp;
-    sincospi_02(2.0 * u1, &sp, &cp);
+    const SinCosCoef K = sincos_coef();
+    sincos_turns<2>(u1, L.sincos, K, &sp, &cp);
     const double rr = P.test_radius * fsqrt(u0);
     const double ox = cp * rr + P.test_x, oy = sp * rr + P.test_y, oz = P.test_z;
     if (P.test_parallel) {
@@ -389,7 +432,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
       ey = oy + (u3 * 0.5) - 0.25;
     } else {
       double sq, cq;
-      sincospi_02(2.0 * u3, &sq, &cq);
+      sincos_turns<2>(u3, L.sincos, K, &sq, &cq);
       const double r2 = H.radius_cb * fsqrt(u2);
       ex = cq * r2;
       ey = sq * r2;
@@ -406,12 +449,12 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
 
   // ---- bore (:1813-1848) ----
   const double A2 = fma(sx, sx, sy * sy);     // slope^2
-  const double norm = fsqrt(1.0 + A2);
+  const double norm = FAST ? 1.0 : fsqrt_pos(1.0 + A2);   // FAST: phase B applies the factor (1 + A2) to pathCB^2 itself
   // entrance plane z = 0
   const double x0 = fma(-H.length_b, sx, ex), y0 = fma(-H.length_b, sy, ey);
   const bool hits_entrance = fma(x0, x0, y0 * y0) < H.radius_cb_sq;
-  double path_cb = H.length_b * norm;          // |exit point - entrance-plane point| (:1836-1843)
-  if (ballot64(ok && !hits_entrance)) {        // wave-uniform: some ray entered through the bore wall
+  double path_cb = H.length_b * norm;          // |exit point - entrance-plane point| (:1836-1843); FAST: its z extent
+  if (ok & !hits_entrance) {                   // divergent, skipped when no lane needs it: the ray entered through the bore wall
     // lineIntersectsCylinderOnce (:591-604): intersections of the line with the bore wall,
     // t = z - lengthB:  A2 t^2 + 2 Dm t + (Qm - R^2) = 0.  inter1 = larger z, inter2 = smaller z.
     const double Dm = fma(ex, sx, ey * sy);
@@ -424,10 +467,8 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
     const bool v1 = (z_hi > 0.0) && (z_hi < H.length_coldbore);
     const bool v2 = (z_lo > 0.0) && (z_lo < H.length_coldbore);
     const double t = v1 ? t_hi : t_lo;         // :616
-    if (!hits_entrance) {
-      ok = ok && (v1 != v2);                   // exactly one valid intersection (:598-600, :1825)
-      path_cb = fabs(t) * norm;
-    }
+    ok = (v1 != v2);                           // exactly one valid intersection (:598-600, :1825)
+    path_cb = fabs(t) * norm;
   }
   st.path_cb = path_cb;
   // exit of the cold bore (:1846), pipe CB -> VT3 (:1856), VT3 -> XRT (:1866; same radius — sic)
@@ -572,10 +613,8 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const double m1x = fma(z1, tsx, X0), m1y = fma(z1, tsy, Y0);
   // on the surface the normal's z-component is closed-form: cone tan(b) rho(z); paraboloid r3 tan(b)
   double n1z = wolter ? sh.n1_r3t : sh.n1_tan * fma(-sh.n1_tan, z1, sh.r1);
-  if (ballot64(live && !hit1)) {              // wave-uniform: the normal at the (off-surface) input point
-    const double g = normal_z_general(P, sh, 1, m1x, m1y, z1);
-    n1z = hit1 ? n1z : g;
-  }
+  if (live & !hit1)                           // divergent, skipped when no lane needs it: the normal at the (off-surface) input point
+    n1z = normal_z_general(P, sh, 1, m1x, m1y, z1);
   double wx = tsx, wy = tsy, wz = 1.0;
   const double N1 = fma(m1x, m1x, fma(m1y, m1y, n1z * n1z));
   const double sin2_a1 = reflect(wx, wy, wz, L0, m1x, m1y, n1z, N1);
@@ -619,8 +658,10 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const double nwin = (sh.dist_det - pmz) * inv_vz;
   double pdx = fma(nwin, vx, pmx), pdy = fma(nwin, wy, m2y), pdz = sh.dist_det;
 
-  // yaw angle (:2101-2115): ya = deg(atan2(-v_z, -v_y)) + 90 = -deg(atan(v_y / v_z))
-  const double ya = -atan_small(tsy) * 57.29577951308232;
+  // yaw angle (:2101-2115): ya = deg(atan2(-v_z, -v_y)) + 90 = -deg(atan(v_y / v_z)); only its cosine is used unless
+  // the record is written
+  const double ya = RECORDS ? -atan_small(tsy) * 57.29577951308232 : 0.0;
+  const double cos_ya = RECORDS ? cos_small(ya) : cos_yaw_of_slope(tsy);
 
   if (RECORDS && live) {
     const double nend = (sh.dist_det_end - pmz) * inv_vz;
@@ -641,7 +682,8 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     double prob = 1.0;
     double absorb = 1.0;
     if (!stage_gas) {
-      if (!(flags & SART_CF_IGNORE_CONV_PROB)) prob = P.conv_k * path_cb * path_cb;   // conversionProb (:363-365)
+      // conversionProb (:363-365) = conv_k pathCB^2; FAST carries the z extent of the path: pathCB^2 = z^2 (1 + slope^2)
+      if (!(flags & SART_CF_IGNORE_CONV_PROB)) prob = FAST ? (P.conv_k * L0) * (path_cb * path_cb) : P.conv_k * path_cb * path_cb;
     } else {
       // axionConversionProb2 / intensitySuppression2 (axionMassforMagnet.nim:75-113) with pathCB as length
       const double Lnat = path_cb * P.gas_inv_hbarc_m;               // length / 1.97e-7, length in m
@@ -657,7 +699,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
       // intensitySuppression2 (axionMassforMagnet.nim:100-113): exp(-mu_pipe d) exp(-mu_magnet L) as one exponential
       absorb = exp(-fma(en.mu_pipe, distance_pipe_m, en.mu_magnet * (path_cb * 1e-3)));
     }
-    trans_magnet = cos_small(ya) * prob * absorb;   // cos of a degree value taken as radians — sic (:1598)
+    trans_magnet = cos_ya * prob * absorb;          // cos of a degree value taken as radians — sic (:1598)
   }
   double reflectv = 1.0, weight = trans_magnet;
   if (!(flags & SART_CF_IGNORE_REFLECTION)) {
@@ -667,7 +709,9 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     const int na2 = P.refl_n_angles - 2;
     const double amin = P.refl_angle_min, inv_da = P.refl_inv_dangle, da = P.refl_dangle;
     auto refl_at = [&](double sin2a) {
-      const double alpha = asin_small(fsqrt(sin2a)) * 57.29577951308232;   // getMirrorAngle (:782-795), degrees
+      // getMirrorAngle (:782-795), degrees; sin^2 is clamped away from an exact zero (n.v == 0: measure zero) so that the
+      // seed-based square root cannot produce a NaN weight
+      const double alpha = asin_small(fsqrt_pos(fmax(sin2a, 1e-300))) * 57.29577951308232;
       const double t = (alpha - amin) * inv_da;
       int i = (int)t;                 // = floor(t) for t >= 0; negative or NaN t ends in cell 0 through the clamp
       i = max(min(i, na2), 0);
@@ -713,7 +757,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   out.finished = live;
   out.reflect = reflectv;
   out.e_idx = e_idx;
-  out.rdet = fsqrt(rdet2);
+  out.rdet = fsqrt_pos(fmax(rdet2, 1e-300));
   out.px = -pdx + P.chip_cx;                                          // :2203-2204
   out.py = pdy + P.chip_cy;
   out.weight = weight;
@@ -744,6 +788,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
 constexpr int kQueue = 128;   // ring capacity per wave: < 64 left over + <= 64 new survivors
 
 struct __align__(16) TablesLds {
+  double sincos[2 * kSinCosEntries];
   double rcdf[kMaxRadii];
   ShellDev shells[kMaxShells];
   uint16_t rguide[kRadiusGuide + 8];
@@ -767,6 +812,7 @@ struct __align__(16) QueueLds {
 
 template <int BLOCK>
 __device__ __forceinline__ void stage_tables(TablesLds& S, const DevParams& P, const DevTables& T) {
+  for (int i = threadIdx.x; i < 2 * kSinCosEntries; i += BLOCK) S.sincos[i] = as_global(T.sincos_tab)[i];
   for (int i = threadIdx.x; i < P.n_radii; i += BLOCK) S.rcdf[i] = as_global(T.flux_radius_cdf)[i];
   for (int i = threadIdx.x; i <= kRadiusGuide; i += BLOCK) S.rguide[i] = as_global(T.radius_guide)[i];
   {
@@ -838,8 +884,13 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   }
   const DevParams& Pb = B.P;
   const DevTables& Tb = B.T;
+  {
+    // zeroed rings: a slot that was never written reads as ray 0 / shell 0 / radius 0 / u = 0 instead of arbitrary bits
+    uint64_t* q = reinterpret_cast<uint64_t*>(&Q);
+    for (int i = threadIdx.x; i < (int)(sizeof(Q) / 8); i += BLOCK) q[i] = 0ull;
+  }
   stage_tables<BLOCK>(S, Pb, Tb);
-  const LdsTables L{S.rcdf, S.rguide, S.shells, S.lut};
+  const LdsTables L{S.sincos, S.rcdf, S.rguide, S.shells, S.lut};
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: scalar addressing of the rings
@@ -899,8 +950,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     const uint32_t slot = (h1 + (uint32_t)lane) % kQueue;
     RayOut out;
     {
-      // slots beyond n_valid hold stale (or never written) data: lanes compute on them predicated off,
-      // with their indices clamped into range
+      // slots beyond n_valid hold the state of earlier rays (or the zeros the rings start with): lanes compute on them
+      // predicated off; every index they lead to is one a real ray produced
       st.X0 = Q.w[wave].X0[slot]; st.Y0 = Q.w[wave].Y0[slot];
       st.tsx = Q.w[wave].tsx[slot]; st.tsy = Q.w[wave].tsy[slot];
       st.path_cb = Q.w[wave].path[slot]; st.u5 = Q.w[wave].u5[slot];
@@ -915,11 +966,11 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const double num = -(H.dz3 - H.dz1) - h - fma(mx, qx, fma(my, qy, -mz * h));
         st.zcb = num * frcp(fma(mx, st.tsx, fma(my, st.tsy, mz)));
       }
-      const int packed = valid ? Q.w[wave].idx[slot] : 0;
-      st.r_idx = min(packed & 0xFFFF, Pb.n_radii - 1);
-      st.shell = min(packed >> 16, H.n_shells - 1);
-      st.u5 = valid ? st.u5 : 0.0;
-      phase_b<false, FAST>(Pb, L, Tb, Ab, st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
+      const int packed = Q.w[wave].idx[slot];
+      st.r_idx = packed & 0xFFFF;
+      st.shell = packed >> 16;
+      const DevBlob& Bo = lds_opaque(B);
+      phase_b<false, FAST>(Bo.P, L, Bo.T, lds_opaque(Ab), st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
     }
     h1 += n_valid;
     n_nickel += (uint32_t)__popcll(ballot64(out.hit_nickel));
@@ -933,8 +984,9 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       sum_y += out.py;
       sum_r += out.rdet;
       // prepareHeatmap (:838-842): img[floor(y / step_y), floor(x / step_x)] += w
-      const double fx = floor((out.px - Ab.image_x_min) * Ab.image_inv_step_x);
-      const double fy = floor((out.py - Ab.image_y_min) * Ab.image_inv_step_y);
+      // floor(t) in [0, n) <=> 0 <= t < n, and the conversion to int truncates = floor for t >= 0
+      const double fx = (out.px - Ab.image_x_min) * Ab.image_inv_step_x;
+      const double fy = (out.py - Ab.image_y_min) * Ab.image_inv_step_y;
       const int nx = A.image_nx, ny = A.image_ny;
       const bool inside = fx >= 0.0 && fx < (double)nx && fy >= 0.0 && fy < (double)ny;
 #ifdef SART_DEBUG_KNOBS
@@ -969,12 +1021,12 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       if (pass == 0u) stream = stream_block(((first_chunk + (uint64_t)chunk) << 6) + (uint64_t)lane, A.seed_lo, A.seed_hi);
       const uint32_t w = word_of(stream, pass);                      // high word of u3 (:418) of this pass' ray
       const uint32_t rel = ((chunk << 8) + pass) + lane4;
-      const bool valid = rel >= rel_begin && rel < rel_end;
       if (early_reject) {
         // ---- stage A0: the word against the zones (lane masks and scalar arithmetic only) ----
         ZoneTable Z;
         reload_zones(Z);
-        // lane masks of direct compares (v_cmp writes them) and scalar arithmetic on the masks
+        // lane masks of direct compares (v_cmp writes them) and scalar arithmetic on the masks; the final mask becomes the
+        // EXEC mask of the ring write as it is (inverse ballot), with no per-lane 0 / 1 in between
         uint64_t dead_m = 0, reached_m = 0;
 #pragma unroll
         for (int z = 0; z < kMaxZones; ++z) {   // unused zones are empty: lo > hi
@@ -985,15 +1037,14 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const uint64_t valid_m = ballot64(rel >= rel_begin) & ballot64(rel < rel_end);
         n_reached += (uint32_t)__popcll(valid_m & reached_m);
         const uint64_t mask = valid_m & ~dead_m;
-        const bool go = (mask >> lane) & 1ull;
-        if (go) {
+        if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
           const uint32_t slot = (t0 + prefix_of(mask)) % kQueue;
           Q.w[wave].ray[slot] = rel;
           Q.w[wave].u3hi[slot] = w;
         }
         t0 += (uint32_t)__popcll(mask);
       } else {
-        run_phase_a(rel, valid, w);   // no early-rejection stage for this configuration
+        run_phase_a(rel, (rel >= rel_begin) & (rel < rel_end), w);   // no early-rejection stage for this configuration
       }
       pass = (pass + 1u) & 3u;
       if (pass == 0u) chunk += (uint32_t)waves_total;
@@ -1002,12 +1053,13 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     if (early_reject) {
       // ---- stage A1 on a full wave of A0 survivors (or on the remainder once the input is exhausted) ----
       const uint32_t n0 = t0 - h0;
-      if (n0 >= 64u || (!have_new && n0 > 0u)) {
+      if ((n0 >= 64u) | (!have_new & (n0 > 0u))) {   // bitwise on purpose: `||` would become a per-lane select of 0 / 1
         const uint32_t m = min(n0, 64u);
         const bool v = (uint32_t)lane < m;
         const uint32_t slot = (h0 + (uint32_t)lane) % kQueue;
-        const uint32_t rel = v ? Q.w[wave].ray[slot] : 0u;
-        const uint32_t w = v ? Q.w[wave].u3hi[slot] : 0u;
+        // slots beyond m hold ids of earlier rays (the rings are zeroed at the start): lanes there trace a ray nobody counts
+        const uint32_t rel = Q.w[wave].ray[slot];
+        const uint32_t w = Q.w[wave].u3hi[slot];
         h0 += m;
         run_phase_a(rel, v, w);
         ring_sync();
@@ -1015,12 +1067,12 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     }
     // ---- stage B on a full wave of A1 survivors (or on the remainder at the very end) ----
     const uint32_t n1 = t1 - h1;
-    const bool draining = !have_new && (t0 == h0);
-    if (n1 >= 64u || (draining && n1 > 0u)) {
+    const bool draining = !have_new & (t0 == h0);
+    if ((n1 >= 64u) | (draining & (n1 > 0u))) {
       run_phase_b(min(n1, 64u));
       ring_sync();
     }
-    if (draining && t1 == h1) break;
+    if (draining & (t1 == h1)) break;
   }
 
   // scalars: wave reduction -> LDS -> one plain store per workgroup and quantity (folded by fold_scalars_kernel)
@@ -1095,7 +1147,7 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
   const DevParams& P = B.P;
   const DevTables& T = B.T;
   stage_tables<kRecBlock>(S, P, T);
-  const LdsTables L{S.rcdf, S.rguide, S.shells, S.lut};
+  const LdsTables L{S.sincos, S.rcdf, S.rguide, S.shells, S.lut};
 
   const uint64_t stride = (uint64_t)gridDim.x * kRecBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kRecBlock + threadIdx.x; i < A.n_rays; i += stride) {
