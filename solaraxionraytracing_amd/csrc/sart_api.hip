@@ -18,10 +18,10 @@
 #include "sart_device.h"
 
 namespace sart {
-void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
+void launch_trace_histogram(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
                             hipStream_t stream, int variant);
 int histogram_block_of(int variant);
-void launch_trace_records(const HotA& H, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
+void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream);
 int records_block();
 int histogram_blocks_per_cu(int variant);
@@ -145,6 +145,7 @@ struct sart_context {
   // device state
   DevParams params;  // host mirror of the blob's parameter block
   HotA hot;          // passed by value to every launch
+  HotB hotb;         // table bases of phase B's gathers, by value too
   DevBuf<DevBlob> d_blob;
   bool blob_dirty = true;
   std::vector<ShellDev> shells;
@@ -281,6 +282,7 @@ int hoist_setup(sart_context* c) {
     sh.coating = 0;
     if (s.reflectivity_kind == SART_RK_MULTI_COATING)  // layers.lowerBound(hitLayer) :1573 (first boundary >= hitLayer)
       sh.coating = static_cast<int>(std::lower_bound(s.coating_layers, s.coating_layers + s.n_coatings, j) - s.coating_layers);
+    sh.refl_row0 = sh.coating * (c->n_energies + 1);
     const double r1 = s.all_r1[j], l = s.l_mirror, xSep = s.all_xsep[j];
     const double beta = deg2rad(s.all_angles_deg[j]), beta3 = 3.0 * beta;
     const double distanceMirrors = std::cos(beta) * (xSep + l);  // :1973
@@ -386,6 +388,9 @@ int hoist_energy_tables(sart_context* c) {
 // the energy axis, leaving g[i] with  R(alpha, E_idx) = g[i] + xUnit (g[i+1] - g[i]).
 int hoist_reflectivity(sart_context* c) {
   const int nE = c->n_energies, nA = c->refl_na, nEr = c->refl_ne, nC = c->refl_nc;
+  // the kernel addresses the re-tabulated grid with 32-bit byte offsets built from 24-bit multiplicands
+  if (nA >= (1 << 24) || static_cast<size_t>(nC) * (nE + 1) * nA >= (size_t(1) << 29))
+    return fail(SART_ERR_UNSUPPORTED, "reflectivity grid too large: n_coatings * (n_energies + 1) * n_angles must stay below 2^29");
   std::vector<double> out(static_cast<size_t>(nC) * (nE + 1) * nA);
   const double dy = (c->refl_emax - c->refl_emin) / static_cast<double>(nEr - 1);
   for (int e = 0; e <= nE; ++e) {
@@ -431,8 +436,8 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   if (!p) return fail(SART_ERR_INVALID_ARGUMENT, "params is NULL");
   if (p->image_nx < 1 || p->image_ny < 1 || !(p->image_x_max > p->image_x_min) || !(p->image_y_max > p->image_y_min))
     return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
-  if (static_cast<int64_t>(p->image_nx) * static_cast<int64_t>(p->image_ny) > static_cast<int64_t>(INT32_MAX) - SART_ACC_COUNT)
-    return fail(SART_ERR_INVALID_ARGUMENT, "image_nx * image_ny must be below 2^31 (pixel indices are 32-bit on the device)");
+  if (static_cast<int64_t>(p->image_nx) * static_cast<int64_t>(p->image_ny) >= (int64_t(1) << 29))
+    return fail(SART_ERR_INVALID_ARGUMENT, "image_nx * image_ny must be below 2^29 (pixel byte offsets are 32-bit on the device)");
   a.replicas = nullptr;
   a.partials = nullptr;
   a.replica_mask = 0u;
@@ -552,6 +557,14 @@ int sync_blob(sart_context* c) {
   b.T = tables_of(c);
   if (int rc = c->d_blob.upload(&b, 1)) return rc;
   c->hot = hot_of(c->params);
+  c->hotb.diff_flux_cdfs = c->d_ecdf.p;
+  c->hotb.energy_guide = c->d_eguide.p;
+  c->hotb.energy_tab = c->d_etab.p;
+  c->hotb.refl = c->d_refl.p;
+  c->hotb.n_energies = c->n_energies;
+  c->hotb.refl_n_angles = c->refl_na;
+  c->hotb.cdf_stride = c->n_energies + kEnergyCdfPad;
+  c->hotb._pad = 0;
   if (!c->knobs.no_early_reject) build_zones(c->setup, c->params, c->n_radii, c->hot);
   c->blob_dirty = false;
   return 0;
@@ -756,18 +769,39 @@ int sart_set_solar_tables(sart_context* c, const double* rcdf, const double* ecd
   int span = 0;
   for (int k = 0; k < kRadiusGuide; ++k) span = std::max(span, static_cast<int>(rg[k + 1]) - static_cast<int>(rg[k]));
   c->radius_span = span;
-  std::vector<uint16_t> eg(static_cast<size_t>(nR) * (kEnergyGuide + 1));
+  // Energy guide (sart_device.h: kEnergyGuide*): entry k of a row brackets bucket k from below, entry k + 1 from above.
+  //   k <= 1984:      lowerBound(row, k / 2048)                       buckets [k / 2048, (k + 1) / 2048)
+  //   k = 1984 + j:   upperBound(row, 1 - decode(code0 - j + 1))      buckets (1 - v_hi, 1 - v_lo] of the codes of v = 1 - u
+  // (a bucket open from below needs the upper bound of its lower edge: lowerBound(u) >= upperBound(a) for every u > a.)
+  // lowerBound(row, u) of any u in bucket k then lies in [entry k, entry k + 1].  The last entry is n_energies - 1.
+  auto decode = [](uint32_t code) {   // the double whose high word is code << 14
+    const uint64_t bits = static_cast<uint64_t>(code) << (14 + 32);
+    double d;
+    std::memcpy(&d, &bits, sizeof d);
+    return d;
+  };
+  const size_t stride = static_cast<size_t>(nE) + kEnergyCdfPad;
+  std::vector<uint16_t> eg(static_cast<size_t>(nR) * kEnergyGuideEntries);
+  std::vector<double> padded(static_cast<size_t>(nR) * stride, 1.0);
   for (int r = 0; r < nR; ++r) {
     const double* row = ecdf + static_cast<size_t>(r) * nE;
     for (int i = 1; i < nE; ++i)
       if (row[i] < row[i - 1]) return fail(SART_ERR_INVALID_ARGUMENT, "diff_flux_cdfs row not monotone");
     if (row[nE - 1] != 1.0) return fail(SART_ERR_INVALID_ARGUMENT, "every diff_flux_cdfs row must end at 1.0");
-    for (int k = 0; k <= kEnergyGuide; ++k)
-      eg[static_cast<size_t>(r) * (kEnergyGuide + 1) + k] =
-          static_cast<uint16_t>(std::min<size_t>(lower_bound_idx(row, nE, static_cast<double>(k) / kEnergyGuide), nE - 1));
+    uint16_t* g = eg.data() + static_cast<size_t>(r) * kEnergyGuideEntries;
+    const size_t last = static_cast<size_t>(nE) - 1;
+    for (int k = 0; k <= kEnergyGuideUniform; ++k)
+      g[k] = static_cast<uint16_t>(std::min(lower_bound_idx(row, nE, static_cast<double>(k) / 2048.0), last));
+    for (int j = 1; j <= kEnergyGuideLogMax; ++j) {
+      const double edge = 1.0 - decode(kEnergyGuideCode0 - static_cast<uint32_t>(j) + 1u);   // exact: v <= 1/32
+      const size_t ub = static_cast<size_t>(std::upper_bound(row, row + nE, edge) - row);
+      g[kEnergyGuideUniform + j] = static_cast<uint16_t>(std::min(ub, last));
+    }
+    g[kEnergyGuideBuckets] = static_cast<uint16_t>(last);
+    std::memcpy(padded.data() + static_cast<size_t>(r) * stride, row, static_cast<size_t>(nE) * sizeof(double));
   }
   if (int rc = c->d_rcdf.upload(rcdf, nR)) return rc;
-  if (int rc = c->d_ecdf.upload(ecdf, static_cast<size_t>(nR) * nE)) return rc;
+  if (int rc = c->d_ecdf.upload(padded.data(), padded.size())) return rc;
   if (int rc = c->d_rguide.upload(rg.data(), rg.size())) return rc;
   if (int rc = c->d_eguide.upload(eg.data(), eg.size())) return rc;
   c->energies.assign(energies, energies + nE);
@@ -817,7 +851,7 @@ int sart_trace_records_device(sart_context* c, const sart_trace_params_t* p, sar
   if (c->blocks_per_cu_rec == 0) c->blocks_per_cu_rec = 4;
   {
     TimedLaunch tl(c);
-    launch_trace_records(c->hot, c->d_blob.p, a, out_dev,
+    launch_trace_records(c->hot, c->hotb, c->d_blob.p, a, out_dev,
                          grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_rec, records_block()), c->stream);
   }
   SART_HIP(hipGetLastError());
@@ -906,7 +940,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   a.partials = c->d_partials.p;
   {
     TimedLaunch tl(c);
-    launch_trace_histogram(c->hot, c->d_blob.p, a, acc_dev, n_blocks, c->stream, variant);
+    launch_trace_histogram(c->hot, c->hotb, c->d_blob.p, a, acc_dev, n_blocks, c->stream, variant);
   }
   SART_HIP(hipGetLastError());
   return 0;

@@ -18,7 +18,17 @@ namespace sart {
 constexpr int kMaxShells = 64;
 constexpr int kMaxStrips = 16;       // half the number of window strips that are looped over
 constexpr int kRadiusGuide = 2048;   // buckets of the guide table in front of fluxRadiusCDF
-constexpr int kEnergyGuide = 2048;    // buckets per radius row in front of diffFluxCDFs
+// Guide table in front of every row of diffFluxCDFs (lowerBound of the energy draw, raytracer.nim:464-468).  Buckets in the
+// uniform u of the draw: width 1/2048 below u = 31/32; above, where a solar spectrum's CDF creeps towards 1 over hundreds
+// of energies, buckets of constant RELATIVE width in v = 1 - u (64 per octave of v, read off the bits of the double v) down
+// to v = 2^-30.  A bucket then holds 0-2 table entries almost everywhere, and the draw resolves with ONE gather of four
+// consecutive CDF values instead of a data-dependent binary search (a chain of dependent HBM / Infinity-Cache round trips).
+constexpr int kEnergyGuideUniform = 1984;                 // buckets [k / 2048, (k + 1) / 2048), k < 1984 = 2048 * 31/32
+constexpr int kEnergyGuideLogMax = 25 * 64;               // log buckets j = 1 .. 1600 (j = 0: the single point u = 31/32)
+constexpr int kEnergyGuideBuckets = kEnergyGuideUniform + kEnergyGuideLogMax + 1;
+constexpr int kEnergyGuideEntries = kEnergyGuideBuckets + 1;   // u16 per row: bucket k is bracketed by entries k, k + 1
+constexpr uint32_t kEnergyGuideCode0 = (1023u - 5u) << 6;  // (high word of the double 1/32) >> 14
+constexpr int kEnergyCdfPad = 4;                          // 1.0-valued pad behind every CDF row (four-wide candidate gather)
 constexpr int kShellLutMax = 1024;   // cells of the radial look-up table of the shell selection
 constexpr int kMaxRadii = 2048;      // fluxRadiusCDF entries that fit the LDS stage
 constexpr int kSinCosEntries = 129;  // (cos, sin)(pi k / 64), k = 0 .. 128: table behind the sampling angles
@@ -49,7 +59,7 @@ struct ShellDev {
   double nickel_num;
   // reflectivity grid of this shell: layers.lowerBound(j) (raytracer.nim:1573)
   int32_t coating;
-  int32_t _pad;
+  int32_t refl_row0;   // coating * (n_energies + 1): first row of this shell's grid in refl[][n_angles]
 };
 static_assert(sizeof(ShellDev) % 8 == 0, "ShellDev is staged into LDS as 8-byte words");
 
@@ -140,6 +150,19 @@ struct HotA {
 };
 constexpr int kMaxZones = 4;
 
+// What phase B needs as *scalars* at its gathers: the bases of the HBM-resident tables and the sizes their offsets are
+// built from.  Passed by value as a kernel argument and re-read with scalar loads at the start of a phase-B pass, so
+// that every gather is `global_load ... v_offset32, s[base]` instead of 64-bit vector address arithmetic on pointers
+// fetched from LDS.  All tables are < 4 GB (checked on the host), offsets are 32-bit.
+struct HotB {
+  const double* diff_flux_cdfs;       // [n_radii][cdf_stride]: every row followed by kEnergyCdfPad entries of 1.0
+  const uint16_t* energy_guide;       // [n_radii][kEnergyGuideEntries]
+  const EnergyDev* energy_tab;        // [n_energies + 1]
+  const double* refl;                 // [n_coatings][n_energies + 1][n_angles]
+  int32_t n_energies, refl_n_angles;
+  int32_t cdf_stride, _pad;           // n_energies + kEnergyCdfPad
+};
+
 // Device pointers of one context.
 struct DevTables {
   const double* sincos_tab;           // [kSinCosEntries][2]: (cos, sin)(pi k / 64), correctly rounded
@@ -147,8 +170,8 @@ struct DevTables {
   const uint8_t* shell_lut;           // [lut_n]: first shell with R1 > k * lut_step
   const double* flux_radius_cdf;      // [n_radii]
   const uint16_t* radius_guide;       // [kRadiusGuide + 1]
-  const double* diff_flux_cdfs;       // [n_radii][n_energies]
-  const uint16_t* energy_guide;       // [n_radii][kEnergyGuide + 1]
+  const double* diff_flux_cdfs;       // [n_radii][n_energies + kEnergyCdfPad] (rows padded with 1.0)
+  const uint16_t* energy_guide;       // [n_radii][kEnergyGuideEntries]
   const EnergyDev* energy_tab;        // [n_energies + 1]
   // reflectivity re-tabulated per energy index: refl[coating][e_idx][angle] (see hoist_reflectivity)
   const double* refl;                 // [n_coatings][n_energies + 1][n_angles]

@@ -329,19 +329,75 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// Energy index drawn with u5 from the CDF row of the sampled radius (getRandomEnergyFromSolarModel, :444-471).
-__device__ __forceinline__ int sample_energy_index(const DevParams& P, const DevTables& T, int r_idx, double u5) {
-  const auto row = as_global(T.diff_flux_cdfs) + (size_t)r_idx * (size_t)P.n_energies;
-  const auto g = as_global(T.energy_guide) + (size_t)r_idx * (size_t)(kEnergyGuide + 1);
-  const int k = (int)(u5 * (double)kEnergyGuide);
-  const int idx = lower_bound_bracket(row, (int)g[k], (int)g[k + 1], u5);
-  return min(idx, P.n_energies - 1);
+// Gather from an HBM-resident table: wave-uniform base (scalar registers) + 32-bit byte offset per lane.
+typedef double d2 __attribute__((ext_vector_type(2)));   // native vector: loads as one 16-byte access
+template <typename T>
+__device__ __forceinline__ T gload(const void* base, uint32_t byte_off) {
+  typedef const __attribute__((address_space(1))) char* gbytes;
+  return *reinterpret_cast<const __attribute__((address_space(1))) T*>((gbytes)base + byte_off);
+}
+
+// Energy index drawn with u5 from the CDF row of the sampled radius (getRandomEnergyFromSolarModel, :444-471) =
+// lowerBound(row, u5), in three steps that phase B spreads over its mirror arithmetic so that the three gathers of the
+// draw (guide word -> four CDF candidates -> [energy row, reflectivities]) are in flight while the wave computes:
+//   begin       bucket of u5 (sart_device.h: kEnergyGuide*), gather of the guide word (entries k, k + 1 of the row)
+//   candidates  bracket [lo, hi] from the guide word, gather of row[lo .. lo + 3] (rows are padded with 1.0)
+//   finish      lo + #{candidates < u5}: the row is sorted and row[hi] >= u5, so candidates at or beyond hi never count;
+//               only a lane whose four candidates are all < u5 with hi > lo + 4 goes on with a binary search
+struct EnergyDraw {
+  double u;
+  uint32_t row;        // element offset of the CDF row
+  uint32_t gword;      // guide entries k (low half) and k + 1 (high half)
+  uint32_t lo, hi;
+  d2 c01, c23;         // row[lo .. lo + 3]
+};
+__device__ __forceinline__ void energy_draw_begin(const HotB& HB, int r_idx, double u5, EnergyDraw& d) {
+  d.u = u5;
+  const double v = 1.0 - u5;
+  const uint32_t ku = (uint32_t)(int)(u5 * 2048.0);
+  const uint32_t code = (uint32_t)__double2hiint(v) >> 14;                       // exponent and six mantissa bits of v
+  const uint32_t kl = (uint32_t)kEnergyGuideUniform + min(kEnergyGuideCode0 - code, (uint32_t)kEnergyGuideLogMax);
+  const uint32_t k = (v > 0.03125) ? ku : kl;                                    // u5 < 31/32: uniform buckets
+  d.row = __umul24((uint32_t)r_idx, (uint32_t)HB.cdf_stride);                    // both < 2^24
+  // two adjacent u16 as one (possibly unaligned) 32-bit load
+  d.gword = gload<uint32_t>(HB.energy_guide, (__umul24((uint32_t)r_idx, (uint32_t)kEnergyGuideEntries) + k) * 2u);
+}
+__device__ __forceinline__ void energy_draw_candidates(const HotB& HB, EnergyDraw& d) {
+  d.lo = d.gword & 0xFFFFu;
+  d.hi = d.gword >> 16;
+  const uint32_t off = (d.row + d.lo) * 8u;
+  d.c01 = gload<d2>(HB.diff_flux_cdfs, off);
+  d.c23 = gload<d2>(HB.diff_flux_cdfs, off + 16u);
+}
+__device__ __forceinline__ int energy_draw_finish(const HotB& HB, const EnergyDraw& d) {
+  const double u = d.u;
+  uint32_t lo = d.lo + (uint32_t)(d.c01.x < u) + (uint32_t)(d.c01.y < u) + (uint32_t)(d.c23.x < u) + (uint32_t)(d.c23.y < u);
+  if ((d.c23.y < u) & (d.hi > d.lo + 4u)) {   // rare: a wide bucket whose first four entries are all below u
+    asm volatile("; rare: energy bucket wider than four entries");
+    uint32_t hi = d.hi;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (gload<double>(HB.diff_flux_cdfs, (d.row + mid) * 8u) < u) lo = mid + 1; else hi = mid;
+    }
+  }
+  return (int)min(lo, (uint32_t)(HB.n_energies - 1));
+}
+// the three steps back to back (record mode)
+__device__ __forceinline__ int sample_energy_index(const HotB& HB, int r_idx, double u5) {
+  EnergyDraw d;
+  energy_draw_begin(HB, r_idx, u5, d);
+  energy_draw_candidates(HB, d);
+  return energy_draw_finish(HB, d);
 }
 
 static_assert(sizeof(EnergyDev) == 8 * sizeof(double), "EnergyDev is loaded as eight f64");
-__device__ __forceinline__ EnergyDev load_energy_row(const DevTables& T, int e_idx) {
-  const auto p = as_global(reinterpret_cast<const double*>(T.energy_tab)) + (size_t)e_idx * 8;
-  return EnergyDev{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]};
+__device__ __forceinline__ EnergyDev load_energy_row(const HotB& HB, int e_idx) {
+  // field by field: the compiler merges neighbours and drops what a variant does not use (a wider load with a dead half
+  // would have that half's registers reused while the gather is still in flight, which forces an early wait)
+  const uint32_t off = (uint32_t)e_idx * 64u;
+  return EnergyDev{gload<double>(HB.energy_tab, off), gload<double>(HB.energy_tab, off + 8u), gload<double>(HB.energy_tab, off + 16u),
+                   gload<double>(HB.energy_tab, off + 24u), gload<double>(HB.energy_tab, off + 32u), gload<double>(HB.energy_tab, off + 40u),
+                   gload<double>(HB.energy_tab, off + 48u), gload<double>(HB.energy_tab, off + 56u)};
 }
 
 // cos(n phi) from c = cos(phi): Chebyshev T16 (four doublings) or T6 = T2(T3).
@@ -579,7 +635,13 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
 
 // Results of phase B for one ray (record mode needs all of them; histogram mode a few).
 struct RayOut {
-  bool hit_nickel = false, till_window = false, finished = false, outside = false;
+  // lane masks (ballots taken where the predicates are computed: a bool carried across basic blocks is materialised as a
+  // per-lane 0 / 1 and compared again)
+  uint64_t m_nickel = 0, m_till = 0, m_passed = 0;
+  bool passed = false;      // finished && weight != 0
+#ifdef SART_STAGE_TIMING
+  uint64_t tb[6] = {0, 0, 0, 0, 0, 0};
+#endif
   double px = 0.0, py = 0.0, rdet = 0.0, weight = 0.0, reflect = 0.0;
   int e_idx = 0;
 };
@@ -590,8 +652,18 @@ struct RayOut {
 // every table access stays in range); only record fields and the final outputs look at `live`.
 // ------------------------------------------------------------------------------------------------
 template <bool RECORDS, bool FAST>
-__device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, const DevTables& T, const TraceArgs& A,
+__device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, const HotB& HB, const TraceArgs& A,
                                         const RayState& st, int e_idx_in, bool live, RayOut& out, sart_axion_t* rec) {
+#ifdef SART_STAGE_TIMING
+#define SART_B_STAMP(k, dep) do { asm volatile("" :: "v"(dep)); out.tb[k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SART_B_STAMP(k, dep)
+#endif
+  SART_B_STAMP(0, st.X0);
+  // the energy draw runs beside the mirror arithmetic (its gathers are issued early, consumed late)
+  const bool draw_energy = __builtin_amdgcn_readfirstlane(e_idx_in) < 0;   // wave-uniform: false for the X-ray test source
+  EnergyDraw ed = {};
+  if (draw_energy) energy_draw_begin(HB, st.r_idx, st.u5, ed);
   const ShellDev& sh = L.shells[st.shell];
   // P / A may live in LDS: branch conditions are made wave-uniform (scalar branches) explicitly.
   // FAST: vacuum stage, solar source (known at compile time).
@@ -615,6 +687,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   double n1z = wolter ? sh.n1_r3t : sh.n1_tan * fma(-sh.n1_tan, z1, sh.r1);
   if (live & !hit1)                           // divergent, skipped when no lane needs it: the normal at the (off-surface) input point
     n1z = normal_z_general(P, sh, 1, m1x, m1y, z1);
+  if (draw_energy) energy_draw_candidates(HB, ed);   // the guide word has had the first mirror's arithmetic to arrive
   double wx = tsx, wy = tsy, wz = 1.0;
   const double N1 = fma(m1x, m1x, fma(m1y, m1y, n1z * n1z));
   const double sin2_a1 = reflect(wx, wy, wz, L0, m1x, m1y, n1z, N1);
@@ -627,11 +700,13 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     if (ballot64(!(lz > 0.0))) {               // wave-uniform; only for a missed mirror with z1 >= l (never in practice)
       if (!(lz > 0.0)) nick = fsqrt(sin2_a1 / (1.0 - sin2_a1)) > num / lz;
     }
-    out.hit_nickel = live && (st.shell > 0) && nick;
+    const bool hit_nickel = live & (st.shell > 0) & nick;
+    out.m_nickel = ballot64(hit_nickel);
+    if (RECORDS && hit_nickel) rec->hitNickel = 1;
+    live = live & !hit_nickel & hit1;         // nickel (:2045), almostEqual(z1, z0) (:2055)
   }
-  if (RECORDS && out.hit_nickel) rec->hitNickel = 1;
-  live = live && !out.hit_nickel && hit1;     // nickel (:2045), almostEqual(z1, z0) (:2055)
 
+  SART_B_STAMP(1, wz);
   // ---- mirror 2 (:1994-2001 / :2021-2028): ray through (m1x, m1y, z1) along w ----
   const double inv_wz = frcp(wz);
   const double s2x = wx * inv_wz, s2y = wy * inv_wz;
@@ -648,6 +723,35 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
                             : sh.n2_tan * fma(-sh.n2_tan, z2 - sh.m2_zlo, sh.m2_rc);
   const double N2 = fma(m2x, m2x, fma(m2y, m2y, n2z * n2z));
   const double sin2_a2 = reflect(wx, wy, wz, L0, m2x, m2y, n2z, N2);
+
+  SART_B_STAMP(2, wz);
+  // ---- energy index, energy row and reflectivities: gathers issued here, consumed behind the detector-plane arithmetic ----
+  const int e_idx = draw_energy ? energy_draw_finish(HB, ed) : e_idx_in;
+  SART_B_STAMP(3, e_idx);
+  const EnergyDev en = load_energy_row(HB, e_idx);
+  // the two reflectivity gathers are issued here and interpolated behind the detector-plane arithmetic
+  d2 g1 = {1.0, 1.0}, g2 = {1.0, 1.0};
+  double xu1 = 0.0, xu2 = 0.0;
+  if (!(flags & SART_CF_IGNORE_REFLECTION)) {
+    // computeReflectivity (:1533-1580): bilinear in (angle, energy); the energy interpolation is folded
+    // into the per-energy-index table, leaving a linear interpolation in the angle.
+    // row (coating, e_idx) of refl[][n_angles]: 32-bit element offset (the table is < 4 GB, checked on the host)
+    const uint32_t row = __umul24((uint32_t)(sh.refl_row0 + e_idx), (uint32_t)HB.refl_n_angles);
+    const int na2 = HB.refl_n_angles - 2;
+    const double amin = P.refl_angle_min, inv_da = P.refl_inv_dangle, da = P.refl_dangle;
+    auto refl_at = [&](double sin2a, double& xu_out) {
+      // getMirrorAngle (:782-795), degrees; sin^2 is kept away from an exact zero (n.v == 0: measure zero) so that the
+      // seed-based square root cannot produce a NaN weight
+      const double alpha = asin_small(fsqrt_pos(sin2a + 1e-300)) * 57.29577951308232;   // + 1e-300: exact no-op unless sin2a == 0
+      const double t = (alpha - amin) * inv_da;
+      int i = (int)t;                 // = floor(t) for t >= 0; negative or NaN t ends in cell 0 through the clamp
+      i = max(min(i, na2), 0);
+      xu_out = (alpha - fma((double)i, da, amin)) * inv_da;
+      return gload<d2>(HB.refl, (row + (uint32_t)i) * 8u);   // g[i], g[i + 1] (8-byte aligned pair)
+    };
+    g1 = refl_at(sin2_a1, xu1);
+    g2 = refl_at(sin2_a2, xu2);
+  }
 
   // ---- detector plane: getPointDetectorWindow (:797-814, :2070-2083) ----
   const double pmx = fma(m2x, P.pipe_c, z2 * P.pipe_s) - P.d_cb_xray;
@@ -674,8 +778,6 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   }
 
   // ---- weights (:2116-2128) ----
-  const int e_idx = (e_idx_in >= 0) ? e_idx_in : sample_energy_index(P, T, st.r_idx, st.u5);
-  const EnergyDev en = load_energy_row(T, e_idx);
   const double path_cb = st.path_cb;
   double trans_magnet;
   {
@@ -701,27 +803,10 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     }
     trans_magnet = cos_ya * prob * absorb;          // cos of a degree value taken as radians — sic (:1598)
   }
-  double reflectv = 1.0, weight = trans_magnet;
-  if (!(flags & SART_CF_IGNORE_REFLECTION)) {
-    // computeReflectivity (:1533-1580): bilinear in (angle, energy); the energy interpolation is folded
-    // into the per-energy-index table, leaving a linear interpolation in the angle.
-    const auto tab = as_global(T.refl) + ((size_t)sh.coating * (size_t)(P.n_energies + 1) + (size_t)e_idx) * (size_t)P.refl_n_angles;
-    const int na2 = P.refl_n_angles - 2;
-    const double amin = P.refl_angle_min, inv_da = P.refl_inv_dangle, da = P.refl_dangle;
-    auto refl_at = [&](double sin2a) {
-      // getMirrorAngle (:782-795), degrees; sin^2 is clamped away from an exact zero (n.v == 0: measure zero) so that the
-      // seed-based square root cannot produce a NaN weight
-      const double alpha = asin_small(fsqrt_pos(fmax(sin2a, 1e-300))) * 57.29577951308232;
-      const double t = (alpha - amin) * inv_da;
-      int i = (int)t;                 // = floor(t) for t >= 0; negative or NaN t ends in cell 0 through the clamp
-      i = max(min(i, na2), 0);
-      const double xu = (alpha - fma((double)i, da, amin)) * inv_da;
-      const double g0 = tab[i], g1 = tab[i + 1];
-      return fma(xu, g1 - g0, g0);
-    };
-    reflectv = refl_at(sin2_a1) * refl_at(sin2_a2);
-    weight = reflectv * trans_magnet;
-  }
+  // R(alpha, E_idx) = g[i] + xUnit (g[i + 1] - g[i]) for both mirrors (with ignoreReflection: g = (1, 1))
+  const double reflectv = fma(xu1, g1.y - g1.x, g1.x) * fma(xu2, g2.y - g2.x, g2.x);
+  double weight = reflectv * trans_magnet;
+  SART_B_STAMP(4, weight);
   if (RECORDS && live) {
     rec->transmissionMagnet = trans_magnet;
     rec->yawAngles = ya;
@@ -736,8 +821,9 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   }
   pdx -= P.lateral_shift;
   pdy -= P.transversal_shift;
-  out.till_window = live && (weight != 0.0);
-  if (RECORDS && out.till_window) rec->passedTillWindow = 1;
+  const bool till_window = live & (weight != 0.0);
+  out.m_till = ballot64(till_window);
+  if (RECORDS && till_window) rec->passedTillWindow = 1;
 
   // ---- detector window / chip (:2138-2147) ----
   const double rdet2 = fma(pdx, pdx, pdy * pdy);
@@ -750,14 +836,18 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   for (int i = 0; i < n_half_strips; ++i) in_strip = in_strip || (yt > P.strip_lo[i] && yt < P.strip_hi[i]);
   const double trans_window = (n_half_strips > 0) ? (in_strip ? en.t_strongback : en.t_window) : 0.0;
   const uint8_t kind_w = in_strip ? SART_MK_SI : SART_MK_SI3N4;
-  if (!(flags & SART_CF_IGNORE_DET_WINDOW)) weight *= trans_window;
-  if (!(flags & SART_CF_IGNORE_GAS_ABS)) weight *= en.a_gas;         // :2190-2192
-  if (!(flags & SART_CF_XRAY_TEST)) weight *= P.exposure;             // :2207-2212
+  // wave-uniform switches as scalar branches around one multiplication each (the empty asm keeps LLVM from turning them
+  // into a multiplication plus a two-instruction select that every launch pays)
+  if (!(flags & SART_CF_IGNORE_DET_WINDOW)) { asm volatile(""); weight *= trans_window; }
+  if (!(flags & SART_CF_IGNORE_GAS_ABS)) { asm volatile(""); weight *= en.a_gas; }        // :2190-2192
+  if (!(flags & SART_CF_XRAY_TEST)) { asm volatile(""); weight *= P.exposure; }           // :2207-2212
 
-  out.finished = live;
+  SART_B_STAMP(5, weight);
+  out.passed = live & (weight != 0.0);
+  out.m_passed = ballot64(out.passed);
   out.reflect = reflectv;
   out.e_idx = e_idx;
-  out.rdet = fsqrt_pos(fmax(rdet2, 1e-300));
+  out.rdet = fsqrt_pos(rdet2 + 1e-300);       // + 1e-300: exact no-op unless the ray hits the chip centre to the last bit
   out.px = -pdx + P.chip_cx;                                          // :2203-2204
   out.py = pdy + P.chip_cy;
   out.weight = weight;
@@ -865,9 +955,30 @@ __device__ __forceinline__ void reload_zones(ZoneTable& dst) {
   for (int k = 0; k < (int)(sizeof(ZoneTable) / 4); ++k) d[k] = p[k];
 }
 
+// The argument block of trace_histogram_kernel as the code object lays it out (arguments in order, each at its natural
+// alignment; tools/check_kernarg_layout.py compares these offsets with the code object's metadata after every build).
+struct HistKernArgs {
+  HotA H;
+  const DevBlob* blob;
+  TraceArgs A;
+  double* acc;
+  HotB HB;
+};
+// Re-reads one argument (or a leading part of it) from the kernel-argument segment with scalar loads at the place of use.
+template <typename T>
+__device__ __forceinline__ void reload_kernarg(T& dst, size_t byte_offset) {
+  static_assert(sizeof(T) % 4 == 0, "dword granularity");
+  typedef const __attribute__((address_space(4))) uint32_t* kernarg_ptr;
+  kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + byte_offset / 4;
+  asm volatile("" : "+s"(p));
+  uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(T) / 4); ++k) d[k] = p[k];
+}
+
 template <int BLOCK, bool FAST, bool ROT>
 __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
-                                                                double* __restrict__ acc) {
+                                                                double* __restrict__ acc, HotB HBarg) {
   __shared__ TablesLds S;
   __shared__ QueueLds<BLOCK / 64> Q;
   // Only the ~20 scalars phase A needs for every ray travel in the kernel arguments (SGPRs); everything
@@ -903,12 +1014,13 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   const uint32_t rel_begin = (uint32_t)(A.ray_id_offset & 255u);
   const uint32_t rel_end = rel_begin + (uint32_t)A.n_rays;          // one past the last ray (n_rays < 2^31)
   const uint32_t n_chunks = (rel_end + 255u) >> 8;
-  // this wave's replica of the image
-  double* const img = A.replicas + (size_t)((uint32_t)wave_global & A.replica_mask) * (size_t)A.replica_stride;
 
   // wave-uniform counters (ballot + popcount) and per-lane sums
   uint32_t n_reached = 0, n_shell = 0, n_nickel = 0, n_till = 0, n_passed = 0, n_outside = 0;
   double sum_w = 0.0, sum_w2 = 0.0, sum_x = 0.0, sum_y = 0.0, sum_r = 0.0;
+#ifdef SART_STAGE_TIMING   // diagnostic build (make STAGE_TIMING=1): shader-clock cycles per stage, summed over waves, in scalars 12..15
+  uint64_t cyc_a0 = 0, cyc_a1 = 0, cyc_b = 0, cyc_bs[6] = {0, 0, 0, 0, 0, 0};
+#endif
   uint32_t h0 = 0, t0 = 0;   // ring 0 (A0 -> A1) positions, monotone; slot = pos % kQueue
   uint32_t h1 = 0, t1 = 0;   // ring 1 (A1 -> B)
 
@@ -970,54 +1082,76 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       st.r_idx = packed & 0xFFFF;
       st.shell = packed >> 16;
       const DevBlob& Bo = lds_opaque(B);
-      phase_b<false, FAST>(Bo.P, L, Bo.T, lds_opaque(Ab), st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
+      HotB HB;
+      reload_kernarg(HB, offsetof(HistKernArgs, HB));
+      phase_b<false, FAST>(Bo.P, L, HB, lds_opaque(Ab), st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
     }
     h1 += n_valid;
-    n_nickel += (uint32_t)__popcll(ballot64(out.hit_nickel));
-    n_till += (uint32_t)__popcll(ballot64(out.till_window));
-    const bool passed = out.finished && out.weight != 0.0;
-    n_passed += (uint32_t)__popcll(ballot64(passed));
-    if (passed) {
+#ifdef SART_STAGE_TIMING
+    for (int k = 0; k < 5; ++k) cyc_bs[k] += out.tb[k + 1] - out.tb[k];
+    cyc_bs[5] += out.tb[0];     // entry stamps, to place the sub-stages inside the B span
+#endif
+    n_nickel += (uint32_t)__popcll(out.m_nickel);
+    n_till += (uint32_t)__popcll(out.m_till);
+    n_passed += (uint32_t)__popcll(out.m_passed);
+    if (out.passed) {
       sum_w += out.weight;
       sum_w2 = fma(out.weight, out.weight, sum_w2);
       sum_x += out.px;
       sum_y += out.py;
       sum_r += out.rdet;
+      // the launch's image parameters, re-read from the kernel arguments (scalar registers, short-lived)
+      TraceArgs Al;
+      reload_kernarg(Al, offsetof(HistKernArgs, A));
       // prepareHeatmap (:838-842): img[floor(y / step_y), floor(x / step_x)] += w
       // floor(t) in [0, n) <=> 0 <= t < n, and the conversion to int truncates = floor for t >= 0
-      const double fx = (out.px - Ab.image_x_min) * Ab.image_inv_step_x;
-      const double fy = (out.py - Ab.image_y_min) * Ab.image_inv_step_y;
-      const int nx = A.image_nx, ny = A.image_ny;
-      const bool inside = fx >= 0.0 && fx < (double)nx && fy >= 0.0 && fy < (double)ny;
+      const double fx = (out.px - Al.image_x_min) * Al.image_inv_step_x;
+      const double fy = (out.py - Al.image_y_min) * Al.image_inv_step_y;
+      const int nx = Al.image_nx, ny = Al.image_ny;
+      const bool inside = (fx >= 0.0) & (fx < (double)nx) & (fy >= 0.0) & (fy < (double)ny);
+      n_outside += (uint32_t)__popcll(ballot64(!inside));
+      // this wave's replica of the image; the pixel's byte offset is 32-bit (image < 2^29 pixels, checked on the host)
+      double* const img = Al.replicas + (size_t)((uint32_t)wave_global & Al.replica_mask) * (size_t)Al.replica_stride;
 #ifdef SART_DEBUG_KNOBS
-      if (inside && !(A.flags & 0x40000000u))   // SART_DEBUG_NO_IMAGE_ATOMICS (experiment builds only)
+      if (inside && !(Al.flags & 0x40000000u))   // SART_DEBUG_NO_IMAGE_ATOMICS (experiment builds only)
 #else
       if (inside)
 #endif
-        unsafeAtomicAdd(&img[(size_t)((int)fy) * (size_t)nx + (size_t)((int)fx)], out.weight);
-      out.outside = !inside;
-      if (A.spectra) {   // wave-uniform: radial and per-energy histograms behind the scalars
+      {
+        const uint32_t pix = (uint32_t)(int)fy * (uint32_t)nx + (uint32_t)(int)fx;
+        typedef __attribute__((address_space(1))) char* gbytes;
+        unsafeAtomicAdd((double*)((gbytes)img + pix * 8u), out.weight);
+      }
+      if (Al.spectra) {   // wave-uniform: radial and per-energy histograms behind the scalars
         double* rad = acc + (size_t)nx * (size_t)ny + SART_ACC_COUNT;
-        double* en = rad + 2 * (size_t)A.n_radial_bins;
+        double* en = rad + 2 * (size_t)Al.n_radial_bins;
         const size_t ne1 = (size_t)Pb.n_energies + 1;
-        const int rb = min((int)(out.rdet * Ab.radial_inv_bin), A.n_radial_bins - 1);
+        const int rb = min((int)(out.rdet * Al.radial_inv_bin), Al.n_radial_bins - 1);
         unsafeAtomicAdd(&rad[rb], 1.0);
-        unsafeAtomicAdd(&rad[(size_t)A.n_radial_bins + rb], out.weight);
+        unsafeAtomicAdd(&rad[(size_t)Al.n_radial_bins + rb], out.weight);
         unsafeAtomicAdd(&en[out.e_idx], 1.0);
         unsafeAtomicAdd(&en[ne1 + out.e_idx], out.weight);
         unsafeAtomicAdd(&en[2 * ne1 + out.e_idx], out.reflect);
       }
     }
-    n_outside += (uint32_t)__popcll(ballot64(out.outside));
   };
 
   uint32_t chunk = (uint32_t)wave_global;                            // relative to first_chunk (wave-uniform)
   const uint32_t lane4 = 4u * (uint32_t)lane;
   uint32_t pass = 0;                                                 // 0..3: which of its four ids a lane handles now
   U4 stream = U4{0u, 0u, 0u, 0u};                                    // this lane's block of the shared word stream
+#ifdef SART_STAGE_TIMING
+  const uint64_t cyc_start = __builtin_readcyclecounter();
+#define SART_STAMP(var) const uint64_t var = __builtin_readcyclecounter()
+#define SART_SPAN(acc, t_begin) acc += __builtin_readcyclecounter() - (t_begin)
+#else
+#define SART_STAMP(var)
+#define SART_SPAN(acc, t_begin)
+#endif
   for (;;) {
     const bool have_new = chunk < n_chunks;   // wave-uniform
     if (have_new) {
+      SART_STAMP(ts_a0);
       if (pass == 0u) stream = stream_block(((first_chunk + (uint64_t)chunk) << 6) + (uint64_t)lane, A.seed_lo, A.seed_hi);
       const uint32_t w = word_of(stream, pass);                      // high word of u3 (:418) of this pass' ray
       const uint32_t rel = ((chunk << 8) + pass) + lane4;
@@ -1049,6 +1183,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       pass = (pass + 1u) & 3u;
       if (pass == 0u) chunk += (uint32_t)waves_total;
       ring_sync();
+      SART_SPAN(cyc_a0, ts_a0);
     }
     if (early_reject) {
       // ---- stage A1 on a full wave of A0 survivors (or on the remainder once the input is exhausted) ----
@@ -1061,16 +1196,20 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const uint32_t rel = Q.w[wave].ray[slot];
         const uint32_t w = Q.w[wave].u3hi[slot];
         h0 += m;
+        SART_STAMP(ts_a1);
         run_phase_a(rel, v, w);
         ring_sync();
+        SART_SPAN(cyc_a1, ts_a1);
       }
     }
     // ---- stage B on a full wave of A1 survivors (or on the remainder at the very end) ----
     const uint32_t n1 = t1 - h1;
     const bool draining = !have_new & (t0 == h0);
     if ((n1 >= 64u) | (draining & (n1 > 0u))) {
+      SART_STAMP(ts_b);
       run_phase_b(min(n1, 64u));
       ring_sync();
+      SART_SPAN(cyc_b, ts_b);
     }
     if (draining & (t1 == h1)) break;
   }
@@ -1093,6 +1232,13 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     r[SART_ACC_N_REACHED_TELESCOPE] = (double)n_reached;
     r[SART_ACC_N_SHELL_SELECTED] = (double)n_shell;
     r[SART_ACC_N_OUTSIDE_IMAGE] = (double)n_outside;
+#ifdef SART_STAGE_TIMING
+    r[12] = (double)cyc_a0; r[13] = (double)cyc_a1; r[14] = (double)cyc_b;
+    r[15] = (double)(__builtin_readcyclecounter() - cyc_start);
+    // sub-stages of B, packed two per slot (each < 2^40, slot = hi * 2^40 + lo would lose bits in f64): use the sums of x/y/r slots
+    r[SART_ACC_SUM_X] = (double)cyc_bs[0]; r[SART_ACC_SUM_Y] = (double)cyc_bs[1]; r[SART_ACC_SUM_R] = (double)cyc_bs[2];
+    r[SART_ACC_SUM_WEIGHTS_SQ] = (double)cyc_bs[3]; r[SART_ACC_N_OUTSIDE_IMAGE] = (double)cyc_bs[4];
+#endif
   }
   __syncthreads();
   if (threadIdx.x < SART_ACC_COUNT) {
@@ -1135,7 +1281,7 @@ __global__ __launch_bounds__(256) void fold_replicas_kernel(double* __restrict__
 // Literal drop-in for traceAxionWrapper: one Axion record per ray, in ray order (no compaction).
 constexpr int kRecBlock = 256;
 __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
-                                                                   sart_axion_t* __restrict__ out) {
+                                                                   sart_axion_t* __restrict__ out, HotB HB) {
   __shared__ TablesLds S;
   __shared__ DevBlob B;
   {
@@ -1145,8 +1291,7 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
     __syncthreads();
   }
   const DevParams& P = B.P;
-  const DevTables& T = B.T;
-  stage_tables<kRecBlock>(S, P, T);
+  stage_tables<kRecBlock>(S, P, B.T);
   const LdsTables L{S.sincos, S.rcdf, S.rguide, S.shells, S.lut};
 
   const uint64_t stride = (uint64_t)gridDim.x * kRecBlock;
@@ -1159,17 +1304,30 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
     const bool alive = phase_a<false, -1>(H, P, L, A.seed_lo, A.seed_hi, ray_id, u3_hi, st, sampled, reached);
     int e_idx = -1;
     if (sampled) {
-      e_idx = H.test_active ? P.n_energies : sample_energy_index(P, T, st.r_idx, st.u5);
+      e_idx = H.test_active ? P.n_energies : sample_energy_index(HB, st.r_idx, st.u5);
       rec.emratesPre = 1.0;                          // :1818
-      rec.energiesPre = load_energy_row(T, e_idx).energy;  // :1819
+      rec.energiesPre = load_energy_row(HB, e_idx).energy;  // :1819
     }
     if (ballot64(alive)) {
       RayOut ro;
       if (!sampled) { st.u5 = 0.0; st.r_idx = 0; }
-      phase_b<true, false>(P, L, T, A, st, e_idx >= 0 ? e_idx : 0, alive, ro, &rec);
+      phase_b<true, false>(P, L, HB, A, st, e_idx >= 0 ? e_idx : 0, alive, ro, &rec);
     }
     out[i] = rec;
   }
+}
+
+// The offsets the kernels assume for their own arguments when they re-read them from the kernel-argument segment
+// (reload_hot / reload_zones / reload_kernarg).  Not part of the C-ABI: tests/test_host_and_abi.py compares them with the
+// argument offsets in the code object's metadata, so that a compiler that lays arguments out differently fails a CPU test
+// instead of faulting on the GPU.
+extern "C" __attribute__((visibility("default"))) void sart_internal_kernarg_layout(int32_t out[6]) {
+  out[0] = (int32_t)offsetof(HistKernArgs, H);
+  out[1] = (int32_t)offsetof(HistKernArgs, blob);
+  out[2] = (int32_t)offsetof(HistKernArgs, A);
+  out[3] = (int32_t)offsetof(HistKernArgs, acc);
+  out[4] = (int32_t)offsetof(HistKernArgs, HB);
+  out[5] = (int32_t)sizeof(HistKernArgs);
 }
 
 // ---- launch wrappers (called from sart_api.hip) ----
@@ -1187,23 +1345,23 @@ int histogram_blocks_per_cu(int variant) {
   return (e == hipSuccess && n > 0) ? n : 1;
 }
 
-void launch_trace_histogram(const HotA& H, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
+void launch_trace_histogram(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
                             hipStream_t stream, int variant) {
   if (variant == 2)
-    hipLaunchKernelGGL((trace_histogram_kernel<1024, false, true>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc);
+    hipLaunchKernelGGL((trace_histogram_kernel<1024, false, true>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB);
   else if (variant == 1)
-    hipLaunchKernelGGL((trace_histogram_kernel<1024, false, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc);
+    hipLaunchKernelGGL((trace_histogram_kernel<1024, false, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB);
   else
-    hipLaunchKernelGGL((trace_histogram_kernel<1024, true, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc);
+    hipLaunchKernelGGL((trace_histogram_kernel<1024, true, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB);
   const int n_img = A.image_nx * A.image_ny;
   hipLaunchKernelGGL(fold_scalars_kernel, dim3(1), dim3(256), 0, stream, acc + n_img, A.partials, n_blocks, (double)A.n_rays);
   if (A.replica_mask != 0u)
     hipLaunchKernelGGL(fold_replicas_kernel, dim3((n_img + 255) / 256), dim3(256), 0, stream, acc, A.replicas, n_img,
                        (int)A.replica_mask + 1, A.replica_stride);
 }
-void launch_trace_records(const HotA& H, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
+void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream) {
-  hipLaunchKernelGGL(trace_records_kernel, dim3(n_blocks), dim3(kRecBlock), 0, stream, H, blob, A, out);
+  hipLaunchKernelGGL(trace_records_kernel, dim3(n_blocks), dim3(kRecBlock), 0, stream, H, blob, A, out, HB);
 }
 
 }  // namespace sart

@@ -36,6 +36,37 @@ def test_libsart_host_exports_every_declared_symbol():
     assert sorted(L.SART_HOST_SYMBOLS) == names
 
 
+def test_kernel_argument_layout_matches_the_code_object(tmp_path):
+    """The ray kernels re-read their own arguments from the kernel-argument segment at hard-wired offsets
+    (sart_kernels.hip: HistKernArgs).  Those offsets must be the ones the compiler recorded in the code object."""
+    import shutil
+    import subprocess
+    lib = L.load_sart()
+    want = (C.c_int32 * 6)()
+    lib.sart_internal_kernarg_layout(want)
+    obj = tmp_path / "sart_kernels.o"
+    shutil.copy(os.path.join(ROOT, "solaraxionraytracing_amd", "csrc", "build", "sart_kernels.o"), obj)
+    llvm = "/opt/rocm/lib/llvm/bin"
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(obj)], check=True, capture_output=True, cwd=tmp_path)
+    dev = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert len(dev) == 1, dev
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / dev[0])], capture_output=True, text=True,
+                           check=True).stdout
+    # one "- .args:" list per kernel, followed (later) by its ".name:"
+    kernels = re.split(r"\n  - \.a", notes)
+    seen = 0
+    for k in kernels:
+        m = re.search(r"\.name:\s+(\S+)", k)
+        if not m or "trace_histogram_kernel" not in m.group(1):
+            continue
+        args = re.findall(r"\.offset:\s+(\d+)\s+\.size:\s+(\d+)\s+\.value_kind:\s+(\w+)", k)
+        explicit = [(int(o), int(sz)) for o, sz, kind in args if not kind.startswith("hidden")]
+        assert [o for o, _ in explicit] == list(want[:5]), (m.group(1), explicit, list(want))
+        assert explicit[-1][0] + explicit[-1][1] <= want[5]
+        seen += 1
+    assert seen == 3   # FAST, generic, generic rotated
+
+
 def test_struct_sizes_match_c_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text('#include "sart_emission.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sart_setup_t),'
