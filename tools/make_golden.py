@@ -20,8 +20,10 @@ FIELDS = ["passed", "passedTillWindow", "hitNickel", "pointdataX", "pointdataY",
 
 out_dir = os.path.join(ROOT, "tests", "golden")
 os.makedirs(out_dir, exist_ok=True)
-for name in SETUP_NAMES:
-    full = make_setup(name)
+import solaraxionraytracing_amd as sa
+# "<name>_full": the same setup on the default (BASELINE-size) tables: 1968 x 1500 emission CDFs, 1000 x 1000 reflectivity
+for name in SETUP_NAMES + ["babyiaxo_xmm_full"]:
+    full = sa.initFullSetup() if name == "babyiaxo_xmm_full" else make_setup(name)
     o = Oracle(full)
     rec = o.trace_records(N_REC, seed=SEED)
     img, summ, _ = o.trace_histogram(N_HIST, seed=SEED)
