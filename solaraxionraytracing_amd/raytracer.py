@@ -56,6 +56,9 @@ def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_IN
     if solar_model_csv is not None:
         radii, energies, em = tables.read_solar_model_csv(solar_model_csv)
         meta_em = "csv:" + solar_model_csv
+    elif isinstance(emission, str) and emission == "legacy":   # E2: the reference's own emission_rates_Hz.txt / energies.txt (397 x 233)
+        radii, energies, em = tables.legacy_emission_table()
+        meta_em = "E2-legacy-emission_rates_Hz"
     else:
         radii, energies = tables.solar_grid(n_radii, n_energies)
         if isinstance(emission, np.ndarray):

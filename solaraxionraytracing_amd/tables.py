@@ -73,6 +73,24 @@ def primakoff_emission_table(n_radii: int = N_RADII, n_energies: int = N_ENERGIE
     return np.ascontiguousarray(rate)
 
 
+def legacy_emission_table():
+    """E2: the one non-synthetic solar input shipped with the reference — `emission_rates_Hz.txt` [397 radii][233 energies]
+    and `energies.txt` (written by ReadSolarModel/ReadSolarModelEmRate.cc:470-590).  Returns
+    (radii, energies_keV, emission rates): radii are the first 397 rows of the AGSS09 table (0.0015 .. 0.1995 R_sun), the
+    energy grid is the legacy code's non-uniform one (0.36 .. 11.4 keV)."""
+    d = np.load(os.path.join(DATA_DIR, "legacy_emission.npz"))
+    em = np.ascontiguousarray(d["emission_rates_hz"], dtype=np.float64)
+    radii = 0.0015 + 0.0005 * np.arange(em.shape[0], dtype=np.float64)
+    return radii, np.ascontiguousarray(d["energies_kev"], dtype=np.float64), em
+
+
+def llnl_effective_area():
+    """(energy keV, effective area cm^2) of the CAST / LLNL telescope for parallel light
+    (resources/llnl_xray_telescope_cast_effective_area_parallel_light_DTU_thesis.csv)."""
+    d = np.load(os.path.join(DATA_DIR, "reference_curves.npz"))
+    return d["llnl_energy_kev"], d["llnl_effective_area_cm2"]
+
+
 def flat_emission_table(n_radii: int = N_RADII, n_energies: int = N_ENERGIES) -> np.ndarray:
     """E3 (stress): emRate = 1 everywhere."""
     return np.ones((n_radii, n_energies))

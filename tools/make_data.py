@@ -13,7 +13,13 @@ Outputs (all numpy .npz, float64):
                         temperature, electron density, Debye scale - what an OPCD-free Primakoff
                         emission table needs (formulas of readOpacityFile.nim:394-413, 681-690, 788-792).
   reference_curves.npz  McXtrace / XMM angular effective-area curves the reference overlays
-                        (raytracer.nim:2805-2813).
+                        (raytracer.nim:2805-2813) and the CAST / LLNL telescope's effective area for parallel light
+                        (resources/llnl_xray_telescope_cast_effective_area_parallel_light_DTU_thesis.csv, the
+                        `llnlEfficiency` table of config_default.toml:16).
+  legacy_emission.npz   input E2 of SURVEY 8(d), the one non-synthetic solar input the reference ships:
+                        emission_rates_Hz.txt reshaped [397 radii][233 energies] + energies.txt (keV), written by
+                        the legacy ReadSolarModel/ code (axion-electron Compton emission rate in 1/s, g_ae = 1e-13;
+                        radii = the first 397 rows of the AGSS09 table, 0.0015 .. 0.1995 R_sun).
 Run from the repo root:  python tools/make_data.py
 """
 import io
@@ -95,8 +101,21 @@ def solar_profile():
 def reference_curves():
     mc = np.loadtxt(os.path.join(RES, "McXtrace_angular_xmm.csv"), delimiter=",", skiprows=1)
     xmm = np.loadtxt(os.path.join(RES, "xmm_newton_angular_effective_area.csv"), delimiter=",", comments="#")
+    llnl = np.loadtxt(os.path.join(RES, "llnl_xray_telescope_cast_effective_area_parallel_light_DTU_thesis.csv"), delimiter=",",
+                      skiprows=1)
     np.savez_compressed(os.path.join(OUT, "reference_curves.npz"), mcxtrace_angle_deg=mc[:, 0], mcxtrace_rel_flux=mc[:, 2],
-                        xmm_angle_arcmin=xmm[:, 0], xmm_effective_area=xmm[:, 1])
+                        xmm_angle_arcmin=xmm[:, 0], xmm_effective_area=xmm[:, 1], llnl_energy_kev=llnl[:, 0],
+                        llnl_effective_area_cm2=llnl[:, 1])
+
+
+def legacy_emission():
+    energies = np.loadtxt(os.path.join(REF, "energies.txt"))
+    flat = np.loadtxt(os.path.join(REF, "emission_rates_Hz.txt"))
+    n_e = energies.size
+    n_r = (flat.size - 1) // n_e
+    assert (n_r, n_e) == (397, 233) and flat.size == n_r * n_e + 1 and flat[-1] == 0.0   # trailing "0" line
+    np.savez_compressed(os.path.join(OUT, "legacy_emission.npz"), energies_kev=energies,
+                        emission_rates_hz=flat[:-1].reshape(n_r, n_e))
 
 
 if __name__ == "__main__":
@@ -105,5 +124,6 @@ if __name__ == "__main__":
     gold_henke()
     solar_profile()
     reference_curves()
+    legacy_emission()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
