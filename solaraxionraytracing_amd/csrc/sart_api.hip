@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1018,12 +1020,22 @@ int sart_reduce_across_devices(sart_context* const* ctxs, double* const* accs, i
   if (n == 1) return 0;
   Rccl& r = Rccl::get();
   if (!r.ok) return fail(SART_ERR_UNSUPPORTED, "librccl could not be loaded");
-  std::vector<void*> comms(n, nullptr);
   std::vector<int> devs(n);
   for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
-  int rc = r.CommInitAll(comms.data(), n, devs.data());
-  if (rc != 0) return fail(SART_ERR_INTERNAL, std::string("ncclCommInitAll: ") + r.GetErrorString(rc));
-  rc = r.GroupStart();
+  // One communicator set per ordered device list, created on first use and kept for the life of the process: a scan
+  // reduces once per point, and ncclCommInitAll costs orders of magnitude more than the 512 KB reduce itself.
+  static std::mutex comm_mutex;
+  static std::map<std::vector<int>, std::vector<void*>> comm_cache;
+  std::lock_guard<std::mutex> lock(comm_mutex);
+  auto it = comm_cache.find(devs);
+  if (it == comm_cache.end()) {
+    std::vector<void*> fresh(n, nullptr);
+    const int rc_init = r.CommInitAll(fresh.data(), n, devs.data());
+    if (rc_init != 0) return fail(SART_ERR_INTERNAL, std::string("ncclCommInitAll: ") + r.GetErrorString(rc_init));
+    it = comm_cache.emplace(devs, std::move(fresh)).first;
+  }
+  const std::vector<void*>& comms = it->second;
+  int rc = r.GroupStart();
   for (int i = 0; i < n && rc == 0; ++i) {
     if (hipSetDevice(ctxs[i]->device) != hipSuccess) { rc = -1; break; }
     rc = r.Reduce(accs[i], accs[i], n_doubles, 8 /* ncclDouble (ncclFloat64) */, 0 /* ncclSum */, root, comms[i], ctxs[i]->stream);
@@ -1033,7 +1045,10 @@ int sart_reduce_across_devices(sart_context* const* ctxs, double* const* accs, i
   for (int i = 0; i < n; ++i) {
     (void)hipSetDevice(ctxs[i]->device);
     (void)hipStreamSynchronize(ctxs[i]->stream);
-    r.CommDestroy(comms[i]);
+  }
+  if (rc != 0) {   // a failed collective leaves the communicators in an unknown state: drop them
+    for (void* cm : comms) r.CommDestroy(cm);
+    comm_cache.erase(it);
   }
   if (rc != 0) return fail(SART_ERR_INTERNAL, std::string("ncclReduce: ") + (rc > 0 ? r.GetErrorString(rc) : "hipSetDevice failed"));
   return 0;

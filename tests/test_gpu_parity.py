@@ -696,3 +696,70 @@ def test_scan_driver_sharded_by_rays_equals_sharded_by_bins(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     ca, cb = np.loadtxt(a, delimiter=",", skiprows=1), np.loadtxt(b, delimiter=",", skiprows=1)
     np.testing.assert_allclose(cb[:, 1], ca[:, 1], rtol=1e-9)
+
+
+def test_setup_change_between_async_launches_needs_no_explicit_sync():
+    """trace_histogram_device is asynchronous; changing the setup / axion mass / telescope angles right after it
+    re-uploads tables the running launch still reads.  The library orders the two itself (refresh_derived / sync_blob wait
+    for the context's stream), so each launch sees exactly the setup that was current when it was queued."""
+    import torch
+    full = make_setup("babyiaxo_xmm_gas")
+    n = 20_000_000
+    dev = torch.device("cuda", 0)
+    with sa.RayTracer(full) as rt:
+        # reference values, fully synchronised
+        _, s_a = rt.trace_histogram(n, seed=5)
+        rt.set_axion_mass(0.5 * full.setup.m_axion)
+        _, s_b = rt.trace_histogram(n, seed=5)
+        rt.set_axion_mass(full.setup.m_axion)
+        s2 = full.setup.copy()
+        s2.magnet_B = 1.5 * full.setup.magnet_B
+        # now back to back without any synchronisation in between
+        acc = [torch.zeros(sa.accumulator_len(256), dtype=torch.float64, device=dev) for _ in range(3)]
+        p = rt.trace_params(n, seed=5)
+        rt.trace_histogram_device(p, acc[0].data_ptr())
+        rt.set_axion_mass(0.5 * full.setup.m_axion)               # parameter blob
+        rt.trace_histogram_device(p, acc[1].data_ptr())
+        L.check(rt.lib.sart_set_setup(rt.handle, C.byref(s2)))    # shell / energy / reflectivity tables re-hoisted
+        rt.trace_histogram_device(p, acc[2].data_ptr())
+        rt.synchronize()
+        k = 256 * 256 + L.ACC["SUM_WEIGHTS"]
+        got = [float(a[k].item()) for a in acc]
+    assert got[0] == pytest.approx(s_a["SUM_WEIGHTS"], rel=1e-12)
+    assert got[1] == pytest.approx(s_b["SUM_WEIGHTS"], rel=1e-12)
+    assert got[0] != pytest.approx(got[1], rel=1e-3)
+    assert got[2] != pytest.approx(got[0], rel=1e-3) and got[2] > 0
+
+
+def test_scan_drivers_leave_the_context_as_they_found_it():
+    """ADVICE r01: performAngularScan / the mass scan work on a copy of fullSetup in the reference (raytracer.nim:2794-2797);
+    here the context is restored, so the same tracer gives the same answer before and after a scan."""
+    full = make_setup("babyiaxo_xmm_gas")
+    with sa.RayTracer(full) as rt:
+        _, before = rt.trace_histogram(300_000, seed=8)
+        sa.performAngularScan(rt, 0.0, 0.2, 3, n_rays_per_angle=50_000, seed=1)
+        sa.performAxionMassScan(rt, [0.001, 0.02], 50_000, seed=1)
+        got = L.Setup()
+        L.check(rt.lib.sart_get_setup(rt.handle, C.byref(got)))
+        assert got.telescope_turned_y_deg == full.setup.telescope_turned_y_deg and got.m_axion == full.setup.m_axion
+        _, after = rt.trace_histogram(300_000, seed=8)
+    assert after["SUM_WEIGHTS"] == pytest.approx(before["SUM_WEIGHTS"], rel=1e-13) and after["N_PASSED"] == before["N_PASSED"]
+
+
+def test_oversized_grid_and_image_limits(monkeypatch):
+    """more workgroups per CU than the partial-sum buffer used to hold (SART_HIST_BLOCKS_PER_CU) gives the same
+    counts; an image with 2^29 pixels or more is rejected (32-bit pixel offsets on the device)."""
+    full = make_setup("babyiaxo_xmm")
+    with sa.RayTracer(full) as rt:
+        _, ref = rt.trace_histogram(3_000_000, seed=2)
+        p = rt.trace_params(1000)
+        p.image_nx, p.image_ny = 1 << 15, 1 << 14
+        img = np.empty(1)
+        rc = rt.lib.sart_trace_histogram(rt.handle, C.byref(p), None, None)
+        assert rc == L.SART_ERR_INVALID_ARGUMENT and b"2^29" in rt.lib.sart_last_error()
+    monkeypatch.setenv("SART_HIST_BLOCKS_PER_CU", "20")
+    with sa.RayTracer(full) as rt:
+        _, s = rt.trace_histogram(3_000_000, seed=2)
+    for k in ("N_RAYS", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_PASSED", "N_HIT_NICKEL"):
+        assert s[k] == ref[k], k
+    assert s["SUM_WEIGHTS"] == pytest.approx(ref["SUM_WEIGHTS"], rel=1e-12)

@@ -5,8 +5,9 @@
             effective-area style scan of telescope_turned_y, angle bins sharded over the ranks (BASELINE config 4).
             Writes a CSV (the reference only makes a PDF) and compares with the two curves the reference overlays
             (xmm_newton_angular_effective_area.csv, McXtrace_angular_xmm.csv; :2805-2813).
-  mass      gas-stage axion-mass scan (BASELINE config 5): masses sharded over the ranks, or (--shard rays) the rays of
-            every mass point sharded over the ranks with one reduce of the fused accumulator per point.
+  mass      gas-stage axion-mass scan on the full AGSS09 emission table (BASELINE configs[4]): masses sharded over the ranks,
+            or (--shard rays) the rays of every mass point sharded over the ranks with one reduce of the fused accumulator per
+            point ("1e10 rays across 8 MI355X with RCCL histogram reduce": --points 10 --rays 1e9 --shard rays on 8 ranks).
 
 Examples
   python tools/scan.py angular --angularScanMin 0 --angularScanMax 0.3 --numAngularScanPoints 16 --rays 1e7
@@ -34,6 +35,9 @@ def main():
     ap.add_argument("--shard", default="bins", choices=["bins", "rays"],
                     help="bins: every scan point is a full run on one rank (BASELINE config 4); rays: every rank traces its "
                          "share of the ray ids of every point and the accumulators are reduced once per point (config 5)")
+    ap.add_argument("--emission", default=None, choices=["agss09", "primakoff", "legacy", "flat"],
+                    help="solar emission table; default: agss09 (all terms of readOpacityFile.nim on the AGSS09 model, made by the "
+                         "emission kernel) for the mass scan = BASELINE configs[4], primakoff (E1) for the angular scan")
     ap.add_argument("--out", default="gpurun_out/scan.csv")
     args = ap.parse_args()
 
@@ -45,13 +49,14 @@ def main():
     if "SART_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["SART_BENCH_DEVICE"])
     n_rays = int(args.rays)
+    emission = args.emission or ("agss09" if args.mode == "mass" else "primakoff")
     if args.mode == "angular":
-        full = sa.initFullSetup()
+        full = sa.initFullSetup(emission=emission)
         full.setup.chip_x_max = full.setup.chip_y_max = args.chip       # ChipXMax = 100 mm alternative (raytracer.nim:262-264)
         flags = L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS | L.CF_IGNORE_CONV_PROB   # cf. comment :2315
         xs = np.linspace(args.angularScanMin, args.angularScanMax, args.numAngularScanPoints)
     else:
-        full = sa.initFullSetup(stage=L.SK_GAS)
+        full = sa.initFullSetup(stage=L.SK_GAS, emission=emission)   # BASELINE configs[4]: full AGSS09 emission + m_a scan
         flags = 0
         xs = np.linspace(args.massMin, args.massMax, args.points)
     if args.shard == "rays":
