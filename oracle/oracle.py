@@ -75,6 +75,14 @@ def load(variant: str = "f64") -> C.CDLL:
         lib.sart_oracle_trace_records.restype = C.c_int
         lib.sart_oracle_trace_histogram.argtypes = [C.POINTER(Setup), C.POINTER(OracleTables), C.POINTER(TraceParams), _dp, C.c_int]
         lib.sart_oracle_trace_histogram.restype = C.c_int
+        lib.sart_oracle_trace_records_nim_stream.argtypes = [C.POINTER(Setup), C.POINTER(OracleTables), C.POINTER(TraceParams), vp, C.c_int]
+        lib.sart_oracle_trace_records_nim_stream.restype = C.c_int
+        lib.sart_oracle_nim_rand_init.argtypes = [C.POINTER(C.c_uint64 * 2), C.c_int64, C.c_int]
+        lib.sart_oracle_nim_rand_init.restype = None
+        lib.sart_oracle_nim_rand_next.argtypes = [C.POINTER(C.c_uint64 * 2)]
+        lib.sart_oracle_nim_rand_next.restype = C.c_uint64
+        lib.sart_oracle_nim_rand_float.argtypes = [C.POINTER(C.c_uint64 * 2)]
+        lib.sart_oracle_nim_rand_float.restype = _d
         lib.sart_oracle_conversion_prob.argtypes = [_d, _d, _d]
         lib.sart_oracle_conversion_prob.restype = _d
         lib.sart_oracle_eff_photon_mass2.argtypes = [_d] * 4
@@ -145,6 +153,16 @@ class Oracle:
         p = self.params(n_rays, seed, ray_id_offset, flags)
         s = setup if setup is not None else self.full.setup
         self.lib.sart_oracle_trace_records(C.byref(s), C.byref(self.tables), C.byref(p), buf.ctypes.data_as(C.c_void_p), n_threads)
+        return buf
+
+    def trace_records_nim_stream(self, n_rays, seed=299792458, ray_id_offset=0, flags=None, init_variant=1, setup=None) -> np.ndarray:
+        """Records with the reference's own random stream (xoroshiro128+ seeded by randomize(seed), one thread, rays in order):
+        what a single-threaded Nim run of the reference computes.  init_variant: 0 = Nim < 1.4, 1 = Nim >= 1.4."""
+        buf = np.zeros(n_rays, dtype=AXION_DTYPE)
+        p = self.params(n_rays, seed, ray_id_offset, flags)
+        s = setup if setup is not None else self.full.setup
+        self.lib.sart_oracle_trace_records_nim_stream(C.byref(s), C.byref(self.tables), C.byref(p), buf.ctypes.data_as(C.c_void_p),
+                                                      init_variant)
         return buf
 
     def trace_spectra(self, n_rays, seed=299792458, ray_id_offset=0, flags=None, image_n=256, n_radial_bins=10_000,

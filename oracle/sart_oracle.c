@@ -1042,6 +1042,59 @@ int sart_oracle_trace_records(const sart_setup_t* setup, const sart_oracle_table
   return nt;
 }
 
+/* ---- Nim std/random (lib/pure/random.nim): xoroshiro128+ ------------------------------------------------------- */
+static inline uint64_t nim_rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+uint64_t sart_oracle_nim_rand_next(sart_oracle_nim_rand_t* r) {
+  const uint64_t s0 = r->a0;
+  uint64_t s1 = r->a1;
+  const uint64_t result = s0 + s1;
+  s1 ^= s0;
+  r->a0 = nim_rotl(s0, 55) ^ s1 ^ (s1 << 14);
+  r->a1 = nim_rotl(s1, 36);
+  return result;
+}
+static void nim_skip_random_numbers(sart_oracle_nim_rand_t* s) { /* the generator's 2^64 jump */
+  static const uint64_t helper[2] = {0xbeac0467eba5facbull, 0xd86b048b86aa9922ull};
+  uint64_t s0 = 0, s1 = 0;
+  for (int i = 0; i < 2; ++i)
+    for (int b = 0; b < 64; ++b) {
+      if (helper[i] & (1ull << b)) { s0 ^= s->a0; s1 ^= s->a1; }
+      (void)sart_oracle_nim_rand_next(s);
+    }
+  s->a0 = s0;
+  s->a1 = s1;
+}
+void sart_oracle_nim_rand_init(sart_oracle_nim_rand_t* r, int64_t seed, int init_variant) {
+  r->a0 = (uint64_t)(seed >> 16);
+  r->a1 = (uint64_t)(seed & 0xffff);
+  if (init_variant == 1) nim_skip_random_numbers(r);
+  (void)sart_oracle_nim_rand_next(r);
+}
+double sart_oracle_nim_rand_float(sart_oracle_nim_rand_t* r) {
+  const uint64_t x = sart_oracle_nim_rand_next(r);
+  const uint64_t u = (0x3FFull << 52) | (x >> 12);
+  double d;
+  memcpy(&d, &u, sizeof d);
+  return d - 1.0;
+}
+
+int sart_oracle_trace_records_nim_stream(const sart_setup_t* setup, const sart_oracle_tables_t* tables,
+                                         const sart_trace_params_t* params, sart_axion_t* ax_buf, int init_variant) {
+  sart_oracle_nim_rand_t rng;
+  sart_oracle_nim_rand_init(&rng, (int64_t)params->seed, init_variant);
+  const int draws = setup->test_active ? 4 : 6; /* SURVEY App. B */
+  for (uint64_t k = 0; k < params->ray_id_offset * (uint64_t)draws; ++k) (void)sart_oracle_nim_rand_next(&rng);
+  for (uint64_t i = 0; i < params->n_rays; ++i) {
+    double u[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < draws; ++k) u[k] = sart_oracle_nim_rand_float(&rng);
+    sart_axion_t res;
+    memset(&res, 0, sizeof res);
+    sart_oracle_trace_axion(&res, setup, tables, params->flags, u);
+    ax_buf[i] = res;
+  }
+  return 1;
+}
+
 /* One record into the fused accumulator (layout of include/sart.h SART_ACC_*). */
 static void accumulate_record(const sart_axion_t* r, int stage, const sart_trace_params_t* p, double* acc,
                               int n_energies, int e_idx) {

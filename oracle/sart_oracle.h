@@ -51,6 +51,24 @@ int sart_oracle_trace_records(const sart_setup_t* setup, const sart_oracle_table
                               const sart_trace_params_t* params, sart_axion_t* ax_buf,
                               int n_threads);
 
+/* ---- the reference's own random stream (for fixtures produced by a Nim build of the reference) ----------------------
+ * Nim std/random = xoroshiro128+ (rotations 55 / 14 / 36), ONE global stream seeded by `randomize(299792458)`
+ * (raytracer.nim:276); rand(1.0) = 52 mantissa bits of next() under the exponent of 1.0, minus 1.0.
+ * init_variant 0: initRand of Nim < 1.4 (a0 = seed shr 16, a1 = seed and 0xffff, one discarded draw);
+ * init_variant 1: Nim >= 1.4 (the same, with skipRandomNumbers — the 2^64 jump — before the discarded draw). */
+typedef struct sart_oracle_nim_rand_t { uint64_t a0, a1; } sart_oracle_nim_rand_t;
+void sart_oracle_nim_rand_init(sart_oracle_nim_rand_t* r, int64_t seed, int init_variant);
+uint64_t sart_oracle_nim_rand_next(sart_oracle_nim_rand_t* r);
+double sart_oracle_nim_rand_float(sart_oracle_nim_rand_t* r); /* rand(1.0) */
+
+/* traceAxionWrapper with the reference's stream instead of the per-ray Philox blocks: ONE thread, rays in index order,
+ * every ray takes its draws from the running stream in the reference's order (six per ray from the Sun —
+ * theta1, theta2, radius CDF, disk radius, disk angle, energy CDF —, four per ray of the X-ray test source).  This is what
+ * a single-threaded run of the reference (WEAVE_NUM_THREADS=1) computes; with more threads the reference's shared stream
+ * is racy and no run is reproducible.  params->seed is the randomize() seed; ray_id_offset rays are skipped first. */
+int sart_oracle_trace_records_nim_stream(const sart_setup_t* setup, const sart_oracle_tables_t* tables,
+                                         const sart_trace_params_t* params, sart_axion_t* ax_buf, int init_variant);
+
 /* trace + prepareHeatmap(norm=1) + flux sum + counters into `accumulator`
  * (sart_accumulator_len doubles, layout of include/sart.h). Returns threads used. */
 int sart_oracle_trace_histogram(const sart_setup_t* setup, const sart_oracle_tables_t* tables,
