@@ -67,6 +67,43 @@ def test_kernel_argument_layout_matches_the_code_object(tmp_path):
     assert seen == 3   # FAST, generic, generic rotated
 
 
+def test_nim_binding_declares_every_header_field():
+    """integration/sart_ffi.nim (the binding a maintainer of the reference adds) names every field of the three structs and
+    every entry point of include/sart.h, and assigns every sart_setup_t field in toSartSetup.  (No Nim compiler in the image:
+    this is a text check; the file's own `static: doAssert sizeof` lines pin the layouts when it is compiled.)"""
+    nim = open(os.path.join(ROOT, "integration", "sart_ffi.nim")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "sart.h")).read(), flags=re.S)
+
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(",")[0:1] + decl.split(",")[1:]:
+                m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(\[[^\]]*\])?\s*$", part.strip())
+                if m:
+                    names.append(m.group(1))
+        return names
+
+    setup_fields = fields("sart_setup_t")
+    assert len(setup_fields) >= 60
+    for f in setup_fields:
+        if f.startswith("_pad"):
+            continue
+        assert re.search(r"\b%s\*" % f, nim), "SartSetup lacks field " + f
+        assert "result.%s" % f in nim, "toSartSetup does not assign " + f
+    for f in fields("sart_trace_params_t"):
+        assert re.search(r"\b%s\*" % f, nim), "SartTraceParams lacks field " + f
+        assert "result.%s" % f in nim, "sartParams does not set " + f
+    for sym in _declared("sart.h"):
+        assert re.search(r"proc %s\*\(" % sym, nim), "no importc proc for " + sym
+    assert C.sizeof(L.Setup) == 2504 and "sizeof(SartSetup) == 2504" in nim
+    assert C.sizeof(L.TraceParams) == 88 and "sizeof(SartTraceParams) == 88" in nim
+    assert "..." not in nim                      # no elisions
+
+
 def test_struct_sizes_match_c_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text('#include "sart_emission.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sart_setup_t),'
