@@ -256,6 +256,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(full, int(args.cpu_sample), seed)
             if args.workload == "babyiaxo_xmm":
                 out["other_workloads"] = [other_workload_rate(w) for w in ("cast_llnl_gold", "babyiaxo_xmm_gas", "babyiaxo_xmm_rot")]
+                out["other_workloads"].append(emission_table_rate())
                 out["effective_area_rms"] = effective_area_rms()
         print(json.dumps(out))
     rt.close()
@@ -285,6 +286,35 @@ def other_workload_rate(workload: str, n: int = 100_000_000, launches: int = 3):
     avg_s = ms / 1e3 / n_launch
     return {"workload": WORKLOADS[workload], "rays_per_s": n / avg_s, "ms_per_launch": ms / n_launch,
             "passed_fraction": s["N_PASSED"] / s["N_RAYS"], "roofline": roofline_block(workload, float(n), avg_s, n_launch, s, total)}
+
+
+def emission_table_rate(reps: int = 5):
+    """The second kernel of the library: the solar emission table of readOpacityFile.nim's cell loop,
+    1968 radii x 1500 energies, all eight terms.  Unit = one (radius, energy) cell; roofline from its own PMC profile
+    (profiles/pmc_current.json["emission_table"]: f64 flop per cell) x cells / live HIP-event kernel time."""
+    import numpy as np
+    import solaraxionraytracing_amd.emission as em
+    from solaraxionraytracing_amd import tables
+    zones = em.solar_zones()
+    _, energies = tables.solar_grid()
+    cells = len(zones) * energies.size
+    em.emission_table(zones, energies)
+    ms = []
+    for _ in range(reps):
+        table = em.emission_table(zones, energies)
+        ms.append(em.last_kernel_ms())
+    assert np.all(np.isfinite(table)) and table.max() > 0
+    kernel_s = float(np.median(ms)) * 1e-3
+    blk = {"bound": "f64-valu-issue", "achieved": None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+           "kernel": "emission_table_kernel", "avg_kernel_ms": kernel_s * 1e3, "cells_per_launch": cells}
+    pmc = load_pmc("emission_table")
+    if pmc is not None:
+        tf = pmc["f64_flop_per_ray"] * cells / kernel_s / 1e12          # "ray" = unit of the profiled launch = one cell
+        blk.update({"achieved": tf, "frac": tf / F64_VALU_PEAK_TFLOPS, "f64_flop_per_cell": pmc["f64_flop_per_ray"],
+                    "valu_issue_utilisation": pmc.get("valu_issue_utilisation"), "pmc_source": pmc.get("source")})
+        assert blk["frac"] <= 1.0, blk
+    return {"workload": "solar emission table, AGSS09 model, 1968 radii x 1500 energies, eight terms (readOpacityFile.nim:745-860)",
+            "cells_per_s": cells / kernel_s, "ms_per_launch": kernel_s * 1e3, "roofline": blk}
 
 
 def effective_area_rms(points: int = 8, rays_per_angle: int = 1_000_000):

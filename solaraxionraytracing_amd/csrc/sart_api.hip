@@ -110,6 +110,14 @@ std::vector<double> sincos_table() {
   return t;
 }
 
+}  // namespace
+// the table as the library uploads it (tests/test_gpu_math.py feeds it to the device math under test)
+extern "C" __attribute__((visibility("default"))) void sart_internal_sincos_table(double* out) {
+  const std::vector<double> t = sincos_table();
+  std::memcpy(out, t.data(), t.size() * sizeof(double));
+}
+namespace {
+
 size_t lower_bound_idx(const double* a, size_t n, double key) {
   return static_cast<size_t>(std::lower_bound(a, a + n, key) - a);
 }

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/sart_emission.h"
+#include "sart_math.h"
 
 namespace sart {
 int context_device(sart_context* c);
@@ -65,18 +66,20 @@ __device__ __forceinline__ void fnew_pair(double w, double y, double& f_y, doubl
   double sa = 0.0, sb = 0.0;
 #pragma unroll 4
   for (int k = 0; k < kNodes; ++k) {
+    // square root and reciprocals from the hardware seeds + one third-order step (sart_math.h, <= 1 ulp) instead of the
+    // IEEE-exact expansions; the two reciprocals of every (hi, lo) pair come from ONE reciprocal of their product
     const double x = c_node_x[k];
-    const double s = sqrt(x * x + w);
+    const double s = sart::fsqrt_pos(fma(x, x, w));
     const double to = s + x;
-    const double frm = w / to;
+    const double frm = w * sart::frcp(to);
     const double to2 = to * to, fr2 = frm * frm;
     const double a_hi = to2 + ya, a_lo = fr2 + ya;
     const double b_hi = to2 + yb, b_lo = fr2 + yb;
-    const double ra_hi = 1.0 / a_hi, ra_lo = 1.0 / a_lo, rb_hi = 1.0 / b_hi, rb_lo = 1.0 / b_lo;
-    const double ga = ya * (ra_hi - ra_lo) + log(a_hi * ra_lo);
-    const double gb = yb * (rb_hi - rb_lo) + log(b_hi * rb_lo);
-    sa += c_node_w[k] * ga;
-    sb += c_node_w[k] * gb;
+    const double ra = sart::frcp(a_hi * a_lo), rb = sart::frcp(b_hi * b_lo);   // 1 / a_hi = ra a_lo, 1 / a_lo = ra a_hi
+    const double ga = fma(ya * ra, a_lo - a_hi, log(a_hi * a_hi * ra));
+    const double gb = fma(yb * rb, b_lo - b_hi, log(b_hi * b_hi * rb));
+    sa = fma(c_node_w[k], ga, sa);
+    sb = fma(c_node_w[k], gb, sb);
   }
   f_y = 0.5 * sa;
   f_y_sqrt2 = 0.5 * sb;

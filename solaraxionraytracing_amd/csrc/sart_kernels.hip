@@ -29,6 +29,7 @@
 
 #include "../../include/sart.h"
 #include "sart_device.h"
+#include "sart_math.h"
 
 namespace sart {
 
@@ -92,34 +93,6 @@ __device__ __forceinline__ double u52(uint32_t hi, uint32_t lo) {
 // ------------------------------------------------------------------------------------------------
 // small math helpers
 // ------------------------------------------------------------------------------------------------
-// 1/x, 1/sqrt(x) and sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64, relative error e0 <= ~2^-23) plus ONE
-// third-order step (error ~e0^3 < 2^-68, i.e. the result is the seed-independent f64 rounding, <= 1 ulp) instead of
-// the scaling / fix-up sequence of the IEEE-exact expansions: the path never meets denormals or infinities here, and
-// every consumer is tolerance-compared, never bit-compared.  tests/test_gpu_math.py measures the errors on the device.
-__device__ __forceinline__ double frcp(double x) {
-  const double r = __builtin_amdgcn_rcp(x);
-  const double e = fma(-x, r, 1.0);           // 1/x = r / (1 - e) = r (1 + e + e^2 + ...)
-  return fma(r, fma(e, e, e), r);
-}
-__device__ __forceinline__ double frsq(double x) {   // 1/sqrt(x), x > 0
-  const double y = __builtin_amdgcn_rsq(x);
-  const double e = fma(-(x * y), y, 1.0);     // 1/sqrt(x) = y / sqrt(1 - e) = y (1 + e/2 + 3 e^2 / 8 + ...)
-  return fma(y, e * fma(0.375, e, 0.5), y);
-}
-// sqrt(x) for x > 0: Goldschmidt step from the seed + one Newton correction of the residual.  x < 0 gives NaN (every
-// comparison downstream is then false: a miss); x == 0 also gives NaN (0 * inf) - use fsqrt() where an exact zero can occur.
-__device__ __forceinline__ double fsqrt_pos(double x) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y;
-  const double h = 0.5 * y;
-  g = fma(g, fma(-h, g, 0.5), g);             // error ~ 3/8 e0^2
-  return fma(fma(-g, g, x), h, g);            // g + (x - g^2) / (2 sqrt x); h's own error only enters at e0^3
-}
-__device__ __forceinline__ double fsqrt(double x) {
-  const double g = fsqrt_pos(x);
-  return (x > 0.0) ? g : ((x == 0.0) ? 0.0 : __builtin_nan(""));   // rsq(0) = inf would give NaN; negative -> NaN
-}
-
 // sin and cos of pi a, a = TURNS * u for u in [0, 1) (TURNS = 2: a full turn, 1: half a turn), to <= ~1.5 ulp:
 // k = rint(64 a), r = a - k / 64 exactly (|r| <= 1/128), (C, S) = (cos, sin)(pi k / 64) from the 129-entry table in LDS
 // (correctly rounded on the host, exact zeros and ones at the multiples of pi/2), short Taylor polynomials in r
@@ -1328,6 +1301,48 @@ extern "C" __attribute__((visibility("default"))) void sart_internal_kernarg_lay
   out[3] = (int32_t)offsetof(HistKernArgs, acc);
   out[4] = (int32_t)offsetof(HistKernArgs, HB);
   out[5] = (int32_t)sizeof(HistKernArgs);
+}
+
+// ---- device math under test (tests/test_gpu_math.py): evaluates one helper on an array, not part of the C-ABI ----
+__global__ void math_eval_kernel(int fn, const double* __restrict__ in, double* __restrict__ out, int n,
+                                 const double* __restrict__ sincos_tab) {
+  __shared__ double tab[2 * kSinCosEntries];
+  for (int i = threadIdx.x; i < 2 * kSinCosEntries; i += blockDim.x) tab[i] = sincos_tab[i];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double x = in[i];
+  double r = 0.0, sn, cs;
+  const SinCosCoef K = sincos_coef();
+  switch (fn) {
+    case 0: r = frcp(x); break;
+    case 1: r = frsq(x); break;
+    case 2: r = fsqrt_pos(x); break;
+    case 3: sincos_turns<2>(x, tab, K, &sn, &cs); r = sn; break;
+    case 4: sincos_turns<2>(x, tab, K, &sn, &cs); r = cs; break;
+    case 5: sincos_turns<1>(x, tab, K, &sn, &cs); r = sn; break;
+    case 6: sincos_turns<1>(x, tab, K, &sn, &cs); r = cs; break;
+    case 7: r = asin_small(x); break;
+    case 8: r = cos_yaw_of_slope(x); break;
+    case 9: r = atan_small(x); break;
+    case 10: r = cos_small(x); break;
+    case 11: r = fsqrt(x); break;
+    default: break;
+  }
+  out[i] = r;
+}
+extern "C" __attribute__((visibility("default"))) int sart_internal_math_eval(int fn, const double* in_host, double* out_host, int n,
+                                                                               const double* sincos_table_host) {
+  double *d_in = nullptr, *d_out = nullptr, *d_tab = nullptr;
+  if (n < 1 || hipMalloc(&d_in, (size_t)n * 8) != hipSuccess || hipMalloc(&d_out, (size_t)n * 8) != hipSuccess ||
+      hipMalloc(&d_tab, 2 * kSinCosEntries * 8) != hipSuccess)
+    return -1;
+  (void)hipMemcpy(d_in, in_host, (size_t)n * 8, hipMemcpyHostToDevice);
+  (void)hipMemcpy(d_tab, sincos_table_host, 2 * kSinCosEntries * 8, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(math_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, fn, d_in, d_out, n, d_tab);
+  const hipError_t e = hipMemcpy(out_host, d_out, (size_t)n * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_tab);
+  return e == hipSuccess ? 0 : -2;
 }
 
 // ---- launch wrappers (called from sart_api.hip) ----

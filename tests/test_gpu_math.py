@@ -1,0 +1,97 @@
+"""Accuracy of the hand-rolled f64 device math of the ray kernels (sart_math.h, sart_kernels.hip), measured on the GPU against
+numpy's long double / mpmath: seed + one third-order step reciprocals and square roots, the table-based sin / cos of the
+sampling angles, the short series for the small angles of the path.  Bounds are in ulp of the result."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from solaraxionraytracing_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+N = 200_000
+rng = np.random.default_rng(7)
+
+
+def _eval(fn, x):
+    lib = L.load_sart()
+    tab = np.empty(2 * 129)
+    lib.sart_internal_sincos_table(tab.ctypes.data_as(C.POINTER(C.c_double)))
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    dp = C.POINTER(C.c_double)
+    rc = lib.sart_internal_math_eval(fn, x.ctypes.data_as(dp), out.ctypes.data_as(dp), x.size, tab.ctypes.data_as(dp))
+    assert rc == 0
+    return out, tab
+
+
+def _ulps(got, want):
+    want = np.asarray(want, dtype=np.longdouble)
+    return np.abs((got.astype(np.longdouble) - want) / np.spacing(np.abs(want).astype(np.float64)).astype(np.longdouble))
+
+
+def test_sincos_table_is_correctly_rounded_and_exact_at_quarter_turns():
+    import mpmath as mp
+    mp.mp.dps = 40
+    _, tab = _eval(0, np.ones(4))
+    tab = tab.reshape(129, 2)
+    for k in range(129):
+        for got, want in ((tab[k, 0], mp.cos(mp.pi * k / 64)), (tab[k, 1], mp.sin(mp.pi * k / 64))):
+            if abs(want) < 1e-30:                      # multiples of pi / 2: exact zeros in the table
+                assert got == 0.0 and not np.signbit(got)
+            else:
+                assert abs(mp.mpf(float(got)) - want) <= mp.mpf(float(np.spacing(abs(float(want))))) * 0.5000001, k
+    assert tab[0].tolist() == [1.0, 0.0] and tab[32].tolist() == [0.0, 1.0] and tab[64].tolist() == [-1.0, 0.0]
+    assert tab[96].tolist() == [0.0, -1.0] and tab[128].tolist() == [1.0, 0.0]
+
+
+def test_reciprocal_and_square_roots_are_within_one_ulp():
+    x = np.exp(rng.uniform(np.log(1e-12), np.log(1e16), N))
+    ld = x.astype(np.longdouble)
+    assert _ulps(_eval(0, x)[0], 1 / ld).max() <= 1.0                 # frcp
+    assert _ulps(_eval(0, -x)[0], -1 / ld).max() <= 1.0
+    assert _ulps(_eval(1, x)[0], 1 / np.sqrt(ld)).max() <= 1.0        # frsq
+    assert _ulps(_eval(2, x)[0], np.sqrt(ld)).max() <= 1.0            # fsqrt_pos
+    edge = np.array([0.0, -1.0, 4.0, 1e-300])
+    got = _eval(11, edge)[0]                                          # fsqrt: exact zero, NaN for negatives
+    assert got[0] == 0.0 and np.isnan(got[1]) and got[2] == 2.0 and got[3] == pytest.approx(1e-150, rel=1e-15)
+    assert np.isnan(_eval(2, np.array([-3.0]))[0][0])                 # fsqrt_pos: negative -> NaN (a miss downstream)
+
+
+def test_sampling_sines_and_cosines():
+    """sin / cos of 2 pi u and pi u for the uniforms of the sampling (u in [0, 1)): absolute error <= 1.25 ulp(1) (what a point
+    on a circle needs), <= 4 ulp of the value itself away from its zeros, sin^2 + cos^2 = 1 to 1e-15."""
+    u = np.concatenate([rng.random(N), np.array([0.0, 0.25, 0.5, 0.75, 1 - 2.0 ** -53, 1 / 128, 1 / 256, 0.5 + 2.0 ** -40])])
+    ld = u.astype(np.longdouble)
+    pi = np.longdouble("3.14159265358979323846264338327950288")
+    for turns, fs, fc in ((2, 3, 4), (1, 5, 6)):
+        s_got, c_got = _eval(fs, u)[0], _eval(fc, u)[0]
+        s_want, c_want = np.sin(turns * pi * ld), np.cos(turns * pi * ld)
+        scale = np.spacing(np.float64(1.0)) / 2
+        assert np.abs(s_got - s_want).max() <= 2.5 * scale and np.abs(c_got - c_want).max() <= 2.5 * scale
+        big = np.abs(s_want) > 1e-3
+        assert _ulps(s_got[big], s_want[big]).max() <= 4.0        # (measured 2.9: the absolute bound above is the relevant one)
+        big = np.abs(c_want) > 1e-3
+        assert _ulps(c_got[big], c_want[big]).max() <= 4.0
+        assert np.abs(s_got ** 2 + c_got ** 2 - 1.0).max() < 1e-15
+    assert _eval(3, np.array([0.0, 0.5]))[0].tolist() == [0.0, 0.0]     # sin(0), sin(pi): exact zeros
+    assert _eval(4, np.array([0.25, 0.75]))[0].tolist() == [0.0, 0.0]   # cos(pi/2), cos(3 pi/2)
+
+
+def test_small_angle_series():
+    import mpmath as mp
+    mp.mp.dps = 40
+    x = rng.uniform(-0.06, 0.06, 20_000)
+    assert _ulps(_eval(7, x)[0], np.arcsin(x.astype(np.longdouble))).max() <= 1.5          # asin_small (graze angles)
+    t = rng.uniform(-0.006, 0.006, 4000)
+    want = np.array([float(mp.cos((180 / mp.pi) * mp.atan(mp.mpf(float(v))))) for v in t])
+    got = _eval(8, t)[0]                                                                   # cos(deg(atan t)) as one series
+    assert np.abs(got - want).max() <= 2.3e-16
+    t2 = rng.uniform(0.006, 0.3, 2000) * rng.choice([-1, 1], 2000)                         # two-step path beyond the series
+    want2 = np.array([float(mp.cos((180 / mp.pi) * mp.atan(mp.mpf(float(v))))) for v in t2])
+    assert np.abs(_eval(8, t2)[0] - want2).max() <= 2e-14
+    a = rng.uniform(-0.05, 0.05, 20_000)
+    assert _ulps(_eval(9, a)[0], np.arctan(a.astype(np.longdouble))).max() <= 1.5          # atan_small
+    c = rng.uniform(-1.0, 1.0, 20_000)
+    assert np.abs(_eval(10, c)[0] - np.cos(c.astype(np.longdouble)).astype(np.float64)).max() <= 2.3e-16   # cos_small

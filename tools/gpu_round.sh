@@ -27,6 +27,8 @@ for STEP in "$@"; do
       for W in cast_llnl_gold babyiaxo_xmm_gas babyiaxo_xmm_rot; do
         (cd $ROOT && timeout -k 10 900 bash tools/pmc_profile.sh ${TAG}_$W --workload $W --rays-per-step 1e8)
       done ;;
+    pmc_emission)
+      (cd $ROOT && PMC_PROGRAM=tools/emission_bench.py PMC_PASSES="1 2 3 9" timeout -k 10 600 bash tools/pmc_profile.sh ${TAG}_emission_table --no-cpu) ;;
     quick)   # iteration loop: throughput table + instruction-count PMC passes (1-2) for the headline workload and CAST
       (cd $ROOT && timeout -k 10 300 python tools/throughput_table.py > gpurun_out/tt_$TAG.txt 2>&1) || { tail -20 $ROOT/gpurun_out/tt_$TAG.txt; exit 1; }
       cat $ROOT/gpurun_out/tt_$TAG.txt

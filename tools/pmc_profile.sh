@@ -25,6 +25,10 @@ i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
   if [ -n "$PMC_PASSES" ] && ! echo " $PMC_PASSES " | grep -q " $i "; then continue; fi   # PMC_PASSES="1 2": only those passes
-  rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --profile-run --steps 2 --warmup 1 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+  if [ -n "$PMC_PROGRAM" ]; then   # another program of this repository under the same passes (e.g. tools/emission_bench.py --no-cpu)
+    rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/$PMC_PROGRAM "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+  else
+    rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --profile-run --steps 2 --warmup 1 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+  fi
   echo "pass $i done: $P"
 done
