@@ -134,6 +134,7 @@ struct sart_context {
     bool no_image_atomics = false;   // SART_DEBUG_NO_IMAGE_ATOMICS: timing experiment only (results are wrong)
 #endif
     bool no_early_reject = false;    // SART_NO_EARLY_REJECT: stage A0 off
+    bool no_image_tile = false;      // SART_NO_IMAGE_TILE: small focal spots go to global atomics only (as before the tile)
     bool force_generic = false;      // SART_FORCE_GENERIC: never use the specialised kernel variant
     int image_replicas = 0;          // SART_IMAGE_REPLICAS: 0 = chosen from the plate scale
     int hist_blocks_per_cu = 0;      // SART_HIST_BLOCKS_PER_CU: 0 = occupancy query
@@ -172,6 +173,15 @@ struct sart_context {
   DevBuf<double> d_acc;        // scratch accumulator of the blocking convenience call
   DevBuf<sart_axion_t> d_rec;  // scratch records of the blocking convenience call
   bool derived_dirty = true;
+  // LDS image tile (sart_device.h: TraceArgs::tile_*): centre of the focal spot in image pixels, found by a pilot launch
+  // for the current setup and image binning
+  struct TileCache {
+    bool valid = false, in_pilot = false;
+    int32_t nx = 0, ny = 0;
+    double x_min = 0, x_max = 0, y_min = 0, y_max = 0;
+    int32_t x0 = 0, y0 = 0, n = 0;
+  } tile;
+  DevBuf<double> d_pilot;
 
   // timing
   bool timing = false;
@@ -466,6 +476,7 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   a.image_y_min = p->image_y_min;
   a.image_inv_step_x = 1.0 / ((p->image_x_max - p->image_x_min) / static_cast<double>(p->image_nx));  // :828-830
   a.image_inv_step_y = 1.0 / ((p->image_y_max - p->image_y_min) / static_cast<double>(p->image_ny));
+  a.tile_x0 = a.tile_y0 = a.tile_n = a._pad_tile = 0;
   a.spectra = p->spectra ? 1 : 0;
   a.n_radial_bins = 0;
   a.radial_inv_bin = 0.0;
@@ -577,6 +588,7 @@ int sync_blob(sart_context* c) {
   c->hotb._pad = 0;
   if (!c->knobs.no_early_reject) build_zones(c->setup, c->params, c->n_radii, c->hot);
   c->blob_dirty = false;
+  c->tile.valid = false;   // the focal spot may have moved
   return 0;
 }
 
@@ -669,6 +681,7 @@ int sart_create(int device_ordinal, sart_context** out) {
     c->knobs.no_image_atomics = flag("SART_DEBUG_NO_IMAGE_ATOMICS");
 #endif
     c->knobs.no_early_reject = flag("SART_NO_EARLY_REJECT");
+    c->knobs.no_image_tile = flag("SART_NO_IMAGE_TILE");
     c->knobs.force_generic = flag("SART_FORCE_GENERIC");
     c->knobs.image_replicas = number("SART_IMAGE_REPLICAS");
     c->knobs.hist_blocks_per_cu = number("SART_HIST_BLOCKS_PER_CU");
@@ -926,6 +939,52 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
       }
       a.replicas = c->d_replicas.p;
       a.replica_mask = static_cast<uint32_t>(R - 1);
+      // Small focal spot and no stage A0 (its ring space in LDS is free): accumulate the centre of the spot in a
+      // per-workgroup LDS tile.  The tile is centred on the spot's centroid, measured once per setup and image binning by a
+      // pilot launch of 2e5 rays into a one-pixel image (only SUM_X / SUM_Y / N_PASSED are read).
+      if (c->hot.n_zones == 0 && !c->knobs.no_image_tile && !c->tile.in_pilot) {
+        sart_context::TileCache& t = c->tile;
+        const bool same = t.valid && t.nx == p->image_nx && t.ny == p->image_ny && t.x_min == p->image_x_min &&
+                          t.x_max == p->image_x_max && t.y_min == p->image_y_min && t.y_max == p->image_y_max;
+        if (!same) {
+          t.valid = false;
+          t.n = 0;
+          sart_trace_params_t q = *p;
+          q.n_rays = std::min<uint64_t>(p->n_rays, 200000);
+          q.image_nx = q.image_ny = 1;
+          q.accumulate = 0;
+          q.spectra = 0;
+          if (int rc = c->d_pilot.resize(sart_accumulator_len(1, 1))) return rc;
+          t.in_pilot = true;
+          const bool was_timing = c->timing;
+          c->timing = false;   // the pilot is not one of the caller's launches
+          const int rc = sart_trace_histogram_device(c, &q, c->d_pilot.p);
+          c->timing = was_timing;
+          t.in_pilot = false;
+          if (rc) return rc;
+          double sc[SART_ACC_COUNT];
+          SART_HIP(hipMemcpyAsync(sc, c->d_pilot.p + 1, sizeof sc, hipMemcpyDeviceToHost, c->stream));
+          SART_HIP(hipStreamSynchronize(c->stream));
+          t.nx = p->image_nx; t.ny = p->image_ny;
+          t.x_min = p->image_x_min; t.x_max = p->image_x_max; t.y_min = p->image_y_min; t.y_max = p->image_y_max;
+          if (sc[SART_ACC_N_PASSED] >= 100.0) {
+            const double cx = (sc[SART_ACC_SUM_X] / sc[SART_ACC_N_PASSED] - p->image_x_min) * a.image_inv_step_x;
+            const double cy = (sc[SART_ACC_SUM_Y] / sc[SART_ACC_N_PASSED] - p->image_y_min) * a.image_inv_step_y;
+            const int n = std::min({static_cast<int>(kImageTileMax), p->image_nx, p->image_ny});
+            const int x0 = std::clamp(static_cast<int>(std::floor(cx)) - n / 2, 0, p->image_nx - n);
+            const int y0 = std::clamp(static_cast<int>(std::floor(cy)) - n / 2, 0, p->image_ny - n);
+            t.x0 = x0; t.y0 = y0; t.n = n;
+          }
+          t.valid = true;
+          // the pilot used (and zeroed again) the replica buffer with its own stride: make sure this launch's layout holds
+          if (c->d_replicas.n != need || !c->d_replicas.p) {
+            if (int rc2 = c->d_replicas.resize(need)) return rc2;
+            SART_HIP(hipMemset(c->d_replicas.p, 0, need * sizeof(double)));
+          }
+          a.replicas = c->d_replicas.p;
+        }
+        a.tile_x0 = t.x0; a.tile_y0 = t.y0; a.tile_n = t.n;
+      }
     } else {
       a.replicas = acc_dev;
       a.replica_mask = 0u;

@@ -204,6 +204,11 @@ struct TraceArgs {
   // optional spectra behind the scalars (include/sart.h: sart_accumulator_len_spectra)
   int32_t spectra, n_radial_bins;
   double radial_inv_bin;
+  // Image tile in LDS (small focal spots, stage A0 off: the space of ring 0 is free): pixels [tile_x0, tile_x0 + tile_n) x
+  // [tile_y0, tile_y0 + tile_n) are accumulated per workgroup with ds_add_f64 and flushed once at the end of the kernel;
+  // everything else goes to global atomics as before.  tile_n = 0: off.
+  int32_t tile_x0, tile_y0, tile_n, _pad_tile;
 };
+constexpr int kImageTileMax = 45;   // 45 x 45 <= 16 waves x 128 doubles of ring-0 space
 
 }  // namespace sart

@@ -919,6 +919,9 @@ struct ZoneTable {
   uint32_t lo[kMaxZones], hi[kMaxZones];
 };
 static_assert(sizeof(ZoneTable) == sizeof(HotA) - offsetof(HotA, n_zones), "ZoneTable mirrors the tail of HotA");
+static_assert(offsetof(WaveRings, u3hi) == offsetof(WaveRings, ray) + kQueue * sizeof(uint32_t) && offsetof(WaveRings, ray) % 8 == 0,
+              "the image tile uses ray + u3hi of every wave as 128 contiguous doubles");
+static_assert(kImageTileMax * kImageTileMax <= 16 * kQueue, "image tile fits the ring-0 space of 16 waves");
 __device__ __forceinline__ void reload_zones(ZoneTable& dst) {
   typedef const __attribute__((address_space(4))) uint32_t* kernarg_ptr;
   kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(HotA, n_zones) / 4;
@@ -1091,9 +1094,21 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       if (inside)
 #endif
       {
-        const uint32_t pix = (uint32_t)(int)fy * (uint32_t)nx + (uint32_t)(int)fx;
-        typedef __attribute__((address_space(1))) char* gbytes;
-        unsafeAtomicAdd((double*)((gbytes)img + pix * 8u), out.weight);
+        const uint32_t ix = (uint32_t)(int)fx, iy = (uint32_t)(int)fy;
+        // the workgroup's LDS tile around the focal spot first ("LDS then global atomics"): scattered f64 atomics execute at
+        // the memory side, one 64-byte request per lane, ~2e10 / s for the whole chip
+        const uint32_t tn = (uint32_t)Al.tile_n;
+        const uint32_t tx = ix - (uint32_t)Al.tile_x0, ty = iy - (uint32_t)Al.tile_y0;   // unsigned: below the origin wraps to huge
+        if ((tx < tn) & (ty < tn)) {
+          const uint32_t t = ty * tn + tx;                                   // < 45 * 45 <= 16 x 128
+          // ring 0 of wave (t >> 7): `ray` and `u3hi` are adjacent, 128 doubles per wave
+          double* cell = reinterpret_cast<double*>(&Q.w[t >> 7].ray[0]) + (t & 127u);
+          __hip_atomic_fetch_add(cell, out.weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f64
+        } else {
+          const uint32_t pix = iy * (uint32_t)nx + ix;
+          typedef __attribute__((address_space(1))) char* gbytes;
+          unsafeAtomicAdd((double*)((gbytes)img + pix * 8u), out.weight);
+        }
       }
       if (Al.spectra) {   // wave-uniform: radial and per-energy histograms behind the scalars
         double* rad = acc + (size_t)nx * (size_t)ny + SART_ACC_COUNT;
@@ -1185,6 +1200,20 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       SART_SPAN(cyc_b, ts_b);
     }
     if (draining & (t1 == h1)) break;
+  }
+
+  // flush of the LDS image tile: one global atomic per non-empty tile pixel and workgroup
+  if (A.tile_n > 0) {
+    __syncthreads();   // every wave of the workgroup has left the loop (uniform condition: kernel argument)
+    const uint32_t tn = (uint32_t)A.tile_n, n_tile = tn * tn;
+    double* const img = A.replicas + (size_t)((uint32_t)wave_global & A.replica_mask) * (size_t)A.replica_stride;
+    for (uint32_t t = threadIdx.x; t < n_tile; t += BLOCK) {
+      const double v = reinterpret_cast<const double*>(&Q.w[t >> 7].ray[0])[t & 127u];
+      if (v != 0.0) {
+        const uint32_t ty = t / tn, tx = t - ty * tn;
+        unsafeAtomicAdd(&img[(size_t)((uint32_t)A.tile_y0 + ty) * (size_t)A.image_nx + ((uint32_t)A.tile_x0 + tx)], v);
+      }
+    }
   }
 
   // scalars: wave reduction -> LDS -> one plain store per workgroup and quantity (folded by fold_scalars_kernel)
