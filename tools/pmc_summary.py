@@ -36,10 +36,10 @@ def collect(d, kernel):
             acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         # Dispatches of the same kernel that are not the profiled launches (the 2e5-ray pilot launch that places the LDS image
         # tile, warm-up launches of another size) are recognised by their SQ_WAVES / much smaller counts and dropped: keep the
-        # dispatches whose value is at least half of the largest one.
+        # dispatches whose value is at least 0.8 of the largest one.
         for k, v in acc.items():
             top = max(v)
-            keep = [x for x in v if x >= 0.5 * top] if top > 0 else v
+            keep = [x for x in v if x >= 0.8 * top] if top > 0 else v
             res[k] = sum(keep) / len(keep)
     return res
 
