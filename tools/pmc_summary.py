@@ -11,7 +11,8 @@ Derived figures and their formulas (all per launch of `rays` rays, counters are 
   valu_insts_per_64_rays  = SQ_INSTS_VALU * 64 / rays
   f64_flop_per_ray        = (2 FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) * 64 lanes / rays      (wave instructions x 64 lanes)
   valu_issue_utilisation  = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES * waves_per_simd, waves_per_simd = SQ_WAVES / (4 n_cu)
-                            (both counters are quad-cycles summed over waves; every wave lives for the whole launch)
+                            (both counters are quad-cycles summed over waves; every wave lives for the whole launch);
+                            cross-check / short-lived waves: 4 SQ_ACTIVE_INST_VALU / (4 n_cu x GRBM_GUI_ACTIVE / 8)
   fabric_read_bytes       = 32 RDREQ_32B + 64 RDREQ_64B + 128 RDREQ_128B   (TCC_EA0_RDREQ by size; cross-check: 2 x FETCH_SIZE
                             x 1024, the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md)
   fabric_write_bytes      = WRITE_SIZE x 1024
@@ -73,6 +74,13 @@ def derive(w, rays, n_cu):
         if "WRITE_SIZE" in w:
             out["fabric_write_bytes_per_ray"] = g("WRITE_SIZE") * 1024.0 / rays
             out["fabric_bytes_per_ray"] = out["fabric_read_bytes_per_ray"] + out["fabric_write_bytes_per_ray"]
+    if "GRBM_GUI_ACTIVE" in w and "SQ_ACTIVE_INST_VALU" in w:
+        # same quantity from the clock counter: VALU-active cycles summed over waves / (SIMDs x kernel cycles), kernel cycles =
+        # GRBM_GUI_ACTIVE / 8 (rocprofv3 reports the sum over the 8 XCDs).  Valid for kernels whose waves do not live for the
+        # whole launch too (the emission kernel), where the per-wave form above over-counts.
+        out["valu_issue_utilisation_from_clock"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / (4.0 * n_cu * g("GRBM_GUI_ACTIVE") / 8.0)
+        if out.get("waves_per_simd", 0.0) > 8.0:
+            out["valu_issue_utilisation"] = out["valu_issue_utilisation_from_clock"]
     if "TCC_HIT_sum" in w:
         out["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
     return out
