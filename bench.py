@@ -173,13 +173,7 @@ def main():
 
     full, flags = make_setup(args.workload)
     wl_name = WORKLOADS[args.workload]
-    rays_step = int(args.rays_per_step)
-    if args.scaling == "weak":
-        rays_rank, step_total = rays_step, rays_step * world
-        lo_in_step = rank * rays_step
-    else:
-        lo_in_step, hi_in_step = D.shard_range(rays_step, rank, world)
-        rays_rank, step_total = hi_in_step - lo_in_step, rays_step
+    rays_rank, step_total, lo_in_step = D.step_shard(args.scaling, int(args.rays_per_step), rank, world)
     rt = sa.RayTracer(full, device=local_rank)
     # Launches, torch ops on the accumulator and the RCCL reduce are ordered by ONE explicit stream.  (torch's
     # default stream has handle 0, which sart_set_stream reads as "the context's own stream".)

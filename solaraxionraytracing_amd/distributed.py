@@ -22,6 +22,20 @@ def shard_range(n_total: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def step_shard(scaling: str, rays_per_step: int, rank: int, world_size: int):
+    """What one rank traces in one benchmark / production step: returns (rays of this rank, rays of the whole step, offset of
+    this rank's first ray inside the step).  "weak": every rank traces ``rays_per_step`` rays (per-GPU work fixed);
+    "strong": ``rays_per_step`` is the step's total, split by ``shard_range``.  Step k of the job then covers the global ray
+    ids [k * step_total, (k + 1) * step_total) exactly once, whatever the world size."""
+    n = int(rays_per_step)
+    if scaling == "weak":
+        return n, n * world_size, rank * n
+    if scaling == "strong":
+        lo, hi = shard_range(n, rank, world_size)
+        return hi - lo, n, lo
+    raise ValueError("scaling must be 'weak' or 'strong'")
+
+
 def shard_angles(n_angles: int, rank: int, world_size: int):
     """Angle bins of an angular scan owned by ``rank`` (round-robin, performAngularScan :2791-2800 is a
     loop over independent full runs)."""

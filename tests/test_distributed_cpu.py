@@ -26,6 +26,24 @@ def test_shard_range_partitions_exactly():
     assert sorted(sum((D.shard_angles(16, r, 3) for r in range(3)), [])) == list(range(16))
 
 
+def test_step_shard_covers_every_ray_id_exactly_once():
+    """bench.py / production stepping: weak (fixed rays per GPU) and strong (fixed total) splits tile the id space."""
+    for scaling, n in (("weak", 1000), ("strong", 1003), ("strong", 5)):
+        for world in (1, 2, 3, 8):
+            for steps in (1, 3):
+                seen = np.zeros(0, dtype=np.int64)
+                total = None
+                for k in range(steps):
+                    for rank in range(world):
+                        rays, step_total, lo = D.step_shard(scaling, n, rank, world)
+                        total = step_total
+                        seen = np.concatenate([seen, k * step_total + lo + np.arange(rays)])
+                assert total == (n * world if scaling == "weak" else n)
+                assert np.array_equal(np.sort(seen), np.arange(steps * total)), (scaling, n, world)
+    with pytest.raises(ValueError):
+        D.step_shard("other", 10, 0, 1)
+
+
 def _worker(rank, world, port, n_total, seed, out_path):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))

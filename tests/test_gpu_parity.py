@@ -279,9 +279,11 @@ def test_full_size_properties(config):
     assert s["SUM_Y"] / s["N_PASSED"] == pytest.approx(7.0, abs=0.2)
 
 
-def test_bench_two_rank_rehearsal():
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_rank_rehearsal(scaling):
     """bench.py's multi-rank path (ray-id sharding, shared stream, single reduce) with 2 ranks sharing this GPU over
-    gloo — the RCCL run on 2/4/8 GPUs is the driver's; this catches ordering bugs between the launches and the reduce."""
+    gloo — the RCCL run on 2/4/8 GPUs is the driver's; this catches ordering bugs between the launches and the reduce.
+    weak: every rank traces --rays-per-step; strong: the step's total is split over the ranks (BASELINE configs[4])."""
     import json
     import os
     import subprocess
@@ -289,14 +291,16 @@ def test_bench_two_rank_rehearsal():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SART_BENCH_BACKEND="gloo", SART_BENCH_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--rays-per-step", "2e7", "--profile-run"]
+           "--master-port", "29547" if scaling == "weak" else "29549", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--rays-per-step", "2e7", "--profile-run", "--scaling", scaling]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["config"]["total_rays"] == 2 * 3 * 2e7 and d["scaling"] == "weak"
+    total = (2 if scaling == "weak" else 1) * 3 * 2e7
+    assert d["n_gpus"] == 2 and d["config"]["total_rays"] == total and d["scaling"] == scaling
     assert d["results"]["passed_fraction"] == pytest.approx(0.2144, abs=2e-3)
+    assert d["results"]["image_sum"] == pytest.approx(d["results"]["flux"], rel=1e-9)
     assert d["value"] > 1e9
 
 
