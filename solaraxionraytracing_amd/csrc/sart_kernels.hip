@@ -1130,6 +1130,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   U4 stream = U4{0u, 0u, 0u, 0u};                                    // this lane's block of the shared word stream
 #ifdef SART_STAGE_TIMING
   const uint64_t cyc_start = __builtin_readcyclecounter();
+  const uint64_t real_start = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: shader clock = d(memtime) / d(memrealtime) x 100 MHz
 #define SART_STAMP(var) const uint64_t var = __builtin_readcyclecounter()
 #define SART_SPAN(acc, t_begin) acc += __builtin_readcyclecounter() - (t_begin)
 #else
@@ -1237,6 +1238,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
 #ifdef SART_STAGE_TIMING
     r[12] = (double)cyc_a0; r[13] = (double)cyc_a1; r[14] = (double)cyc_b;
     r[15] = (double)(__builtin_readcyclecounter() - cyc_start);
+    r[SART_ACC_N_HIT_NICKEL] = (double)(__builtin_amdgcn_s_memrealtime() - real_start);
     // sub-stages of B, packed two per slot (each < 2^40, slot = hi * 2^40 + lo would lose bits in f64): use the sums of x/y/r slots
     r[SART_ACC_SUM_X] = (double)cyc_bs[0]; r[SART_ACC_SUM_Y] = (double)cyc_bs[1]; r[SART_ACC_SUM_R] = (double)cyc_bs[2];
     r[SART_ACC_SUM_WEIGHTS_SQ] = (double)cyc_bs[3]; r[SART_ACC_N_OUTSIDE_IMAGE] = (double)cyc_bs[4];

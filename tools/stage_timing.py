@@ -23,6 +23,7 @@ for wl in ("babyiaxo_xmm", "cast_llnl_gold"):
     a0, a1, b, tot = v[12], v[13], v[14], v[15]
     passes = n / 64.0
     n_a1 = (v[L.ACC["N_REACHED_TELESCOPE"]] if False else None)
+    print("   in-kernel shader clock (s_memtime / s_memrealtime x 100 MHz, mean over waves): %.3f GHz" % (tot / max(v[L.ACC["N_HIT_NICKEL"]], 1.0) * 0.1))
     print("%s: kernel %.3f ms; wave lifetime %.0f cycles (%.2f GHz); share A0 %.3f A1 %.3f B %.3f other %.3f" % (
         wl, ms / nl, tot / waves, tot / waves / (ms / nl * 1e-3) / 1e9, a0 / tot, a1 / tot, b / tot, 1 - (a0 + a1 + b) / tot))
     print("   cycles per launched pass of 64 rays (per wave): A0 %.0f  A1 %.0f  B %.0f  total %.0f" % (
