@@ -55,8 +55,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (50 x 1e9 rays = 0.9 s of kernel time on one MI355X)")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays-per-step", type=float, default=1e9,
                     help="rays per step: per GPU (--scaling weak) or in total (--scaling strong); 1e9 = one BabyIAXO image of "
                          "BASELINE configs[2]")

@@ -169,6 +169,73 @@ def test_survival_fractions_babyiaxo():
     assert 0.02 < s["N_HIT_NICKEL"] / 2e5 < 0.06
 
 
+def test_baseline_config0_default_toml_1e5_rays_on_the_cpu_path(tmp_path):
+    """BASELINE configs[0]: "config/config_default.toml, 1e5 rays on the Nim CPU path (plumbing, no GPU)".  The keys and values
+    of the reference's config_default.toml:1-50 through the TOML layer (config.py), initFullSetup on the DEFAULT table sizes
+    (1968 x 1500 CDFs, 1000 x 1000 reflectivity) and 1e5 rays through the CPU oracle — BabyIAXO / InGridIAXO / vacuum / XMM, all
+    flags off; survival chain of SURVEY App. C."""
+    from solaraxionraytracing_amd import config
+    from solaraxionraytracing_amd import _lib as L
+    cfgdir = tmp_path / "config"
+    cfgdir.mkdir()
+    (cfgdir / "config.toml").write_text("""
+[Resources]
+resourcePath   = "../resources"
+outputPath     = "../out"
+llnlEfficiency = "llnl_xray_telescope_cast_effective_area_parallel_light_DTU_thesis.csv"
+goldFilePrefix = "henke_download/"
+rawSolarModel  = "AGSS09_solar_model_stripped.dat"
+solarModelFile = "solar_model_dataframe.csv"
+llnlReflFile   = "llnl_layer_reflectivities.h5"
+goldReflFile   = "gold_0.25microns_reflectivities.h5"
+[ReadOpacityFile]
+solarModelFile = "solar_model_dataframe.csv"
+opcdPath       = "OPCD"
+[Setup]
+experimentSetup = "BabyIAXO"
+detectorSetup   = "InGridIAXO"
+stageSetup      = "vacuum"
+telescopeSetup  = "XMM"
+[Magnet]
+useConfig = false
+B = 2.0
+radiusCB = 350.0
+lengthColdbore = 11300.0
+lengthB = 11000.0
+pGasRoom = 1.0
+tGas = 100.0
+[TestXraySource]
+useConfig = false
+active = true
+parallel = false
+energy = 1.0
+distance = 2000.0
+radius = 350.0
+offAxisUp = 0.0
+offAxisLeft = 0.0
+activity = 0.125
+lengthCol = 0.021
+[DetectorInstallation]
+useConfig = false
+distanceDetectorXRT = 1485.0
+distanceWindowFocalPlane = 0.0
+lateralShift = 0.0
+transversalShift = 0.0
+""")
+    full = config.init_full_setup_from_config(str(cfgdir / "config.toml"))
+    s = full.setup
+    assert (s.experiment, s.stage, s.telescope_kind, s.detector_kind) == (L.ES_BABYIAXO, L.SK_VACUUM, L.TK_XMM, L.DK_INGRIDIAXO)
+    assert s.magnet_radiusCB == 500.0 and s.distance_detector_xrt == 7500.0      # useConfig = false: the built-in blocks (:1113-1123, :1401-1407)
+    assert full.diffFluxCDFs.shape == (1968, 1500) and full.reflectivity.data.shape == (1, 1000, 1000) and full.flags == 0
+    n = 100_000
+    img, sm, _ = O.Oracle(full).trace_histogram(n, seed=299792458)
+    assert sm["N_RAYS"] == n
+    assert sm["N_REACHED_TELESCOPE"] / n == pytest.approx(0.547, abs=0.01)       # SURVEY App. C survival chain
+    assert sm["N_SHELL_SELECTED"] / n == pytest.approx(0.329, abs=0.01)
+    assert sm["N_PASSED"] / n == pytest.approx(0.214, abs=0.01)
+    assert img.sum() == pytest.approx(sm["SUM_WEIGHTS"], rel=1e-12) and sm["SUM_WEIGHTS"] > 0
+
+
 def test_ray_uniforms_are_uniform_and_uncorrelated():
     """The six uniforms of a ray (Philox4x32-10 blocks keyed by seed and ray id; the high word of u3 from the word stream
     that four consecutive rays share) behave like independent U[0,1) samples: moments, lag correlations along the ray id
