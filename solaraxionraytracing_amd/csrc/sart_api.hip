@@ -127,7 +127,7 @@ size_t lower_bound_idx(const double* a, size_t n, double key) {
 struct sart_context {
   int device = 0;
   int n_cu = 0;
-  int blocks_per_cu_hist[3] = {0, 0, 0}, blocks_per_cu_rec = 0;
+  int blocks_per_cu_hist[5] = {0, 0, 0, 0, 0}, blocks_per_cu_rec = 0;
   // tuning / experiment knobs, read from the environment once when the context is created
   struct Knobs {
 #ifdef SART_DEBUG_KNOBS              // experiment builds only (make DEBUG_KNOBS=1); compiled out of the shipped library
@@ -993,9 +993,12 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   // kernel variant: 0 = specialised for the common configuration (solar source, telescope not rotated, vacuum, no
   // hole loop); 1 = generic, not rotated; 2 = generic, rotated
   const DevParams& P = c->params;
-  const bool fast = !P.test_active && !P.rotated && !P.stage_gas && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) &&
-                    !c->knobs.force_generic;
-  const int variant = fast ? 0 : (P.rotated ? 2 : 1);
+  // 0 / 3 / 4: compile-time specialisations for the solar source without the hole loop (vacuum; gas stage = the m_a scan;
+  // rotated telescope = the angular scan); 1 / 2: everything else with the switches read at run time
+  const bool fast = !P.test_active && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) && !c->knobs.force_generic;
+  int variant = P.rotated ? 2 : 1;
+  if (fast && !P.rotated) variant = P.stage_gas ? 3 : 0;
+  if (fast && P.rotated && !P.stage_gas) variant = 4;
   if (c->blocks_per_cu_hist[variant] == 0) {
     c->blocks_per_cu_hist[variant] = std::max(1, histogram_blocks_per_cu(variant));
     if (c->knobs.hist_blocks_per_cu > 0) c->blocks_per_cu_hist[variant] = c->knobs.hist_blocks_per_cu;

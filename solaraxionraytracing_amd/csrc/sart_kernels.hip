@@ -399,11 +399,13 @@ __device__ __forceinline__ double cos_n_phi(int n, double c) {
 // FAST = the configuration known at compile time to be: solar source (no X-ray test source), telescope
 // not rotated, no hole loop in the optics.  The generic instantiation reads those switches at run time.
 // ROT: telescope rotation known at compile time (0 / 1) or read at run time (-1).
-template <bool FAST, int ROT>
+// ZEXT: st.path_cb carries the z extent of the path in the magnetic field instead of its length (phase B of the vacuum,
+// unrotated specialisation multiplies pathCB^2 by 1 + slope^2 itself and needs no square root here).
+template <bool FAST, int ROT, bool ZEXT>
 __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const LdsTables& L, uint32_t seed_lo,
                                         uint32_t seed_hi, uint64_t ray_id, uint32_t u3_hi, RayState& st, bool& sampled,
                                         bool& reached) {
-  static_assert(!(FAST && ROT != 0), "FAST implies an unrotated telescope");
+  static_assert(!ZEXT || (FAST && ROT == 0), "the z-extent form needs the magnet-frame slopes in phase B");
   const bool cfg_test = FAST ? false : (H.test_active != 0);
   const bool cfg_rotated = (ROT < 0) ? (H.rotated != 0) : (ROT != 0);
   const bool cfg_holes = FAST ? false : (H.telescope_kind == SART_TK_XMM && H.inner_blocks < 0);
@@ -478,7 +480,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
 
   // ---- bore (:1813-1848) ----
   const double A2 = fma(sx, sx, sy * sy);     // slope^2
-  const double norm = FAST ? 1.0 : fsqrt_pos(1.0 + A2);   // FAST: phase B applies the factor (1 + A2) to pathCB^2 itself
+  const double norm = ZEXT ? 1.0 : fsqrt_pos(1.0 + A2);   // ZEXT: phase B applies the factor (1 + A2) to pathCB^2 itself
   // entrance plane z = 0
   const double x0 = fma(-H.length_b, sx, ex), y0 = fma(-H.length_b, sy, ey);
   const bool hits_entrance = fma(x0, x0, y0 * y0) < H.radius_cb_sq;
@@ -624,7 +626,8 @@ struct RayOut {
 // `live` carries the reference's early returns.  Dead lanes keep computing (indices are clamped so that
 // every table access stays in range); only record fields and the final outputs look at `live`.
 // ------------------------------------------------------------------------------------------------
-template <bool RECORDS, bool FAST>
+// GAS: stage known at compile time (0 vacuum / 1 gas) or read at run time (-1).  ZEXT: see phase_a.
+template <bool RECORDS, bool FAST, int GAS, bool ZEXT>
 __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, const HotB& HB, const TraceArgs& A,
                                         const RayState& st, int e_idx_in, bool live, RayOut& out, sart_axion_t* rec) {
 #ifdef SART_STAGE_TIMING
@@ -641,7 +644,8 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   // P / A may live in LDS: branch conditions are made wave-uniform (scalar branches) explicitly.
   // FAST: vacuum stage, solar source (known at compile time).
   const int wolter = __builtin_amdgcn_readfirstlane(P.telescope_wolter);
-  const int stage_gas = FAST ? 0 : __builtin_amdgcn_readfirstlane(P.stage_gas);
+  static_assert(!ZEXT || GAS == 0, "the z-extent form is the vacuum conversion probability");
+  const int stage_gas = (GAS >= 0) ? GAS : __builtin_amdgcn_readfirstlane(P.stage_gas);
   const int test_active = FAST ? 0 : __builtin_amdgcn_readfirstlane(P.test_active);
   const int n_half_strips = __builtin_amdgcn_readfirstlane(P.n_half_strips);
   const uint32_t flags = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.flags);
@@ -758,7 +762,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     double absorb = 1.0;
     if (!stage_gas) {
       // conversionProb (:363-365) = conv_k pathCB^2; FAST carries the z extent of the path: pathCB^2 = z^2 (1 + slope^2)
-      if (!(flags & SART_CF_IGNORE_CONV_PROB)) prob = FAST ? (P.conv_k * L0) * (path_cb * path_cb) : P.conv_k * path_cb * path_cb;
+      if (!(flags & SART_CF_IGNORE_CONV_PROB)) prob = ZEXT ? (P.conv_k * L0) * (path_cb * path_cb) : P.conv_k * path_cb * path_cb;
     } else {
       // axionConversionProb2 / intensitySuppression2 (axionMassforMagnet.nim:75-113) with pathCB as length
       const double Lnat = path_cb * P.gas_inv_hbarc_m;               // length / 1.97e-7, length in m
@@ -952,7 +956,10 @@ __device__ __forceinline__ void reload_kernarg(T& dst, size_t byte_offset) {
   for (int k = 0; k < (int)(sizeof(T) / 4); ++k) d[k] = p[k];
 }
 
-template <int BLOCK, bool FAST, bool ROT>
+// Instantiations: <FAST, ROT, GAS> = <true, false, 0> the common configuration; <true, false, 1> gas stage (the m_a scan of
+// BASELINE configs[4]); <true, true, 0> rotated telescope (the angular scan of configs[3]); <false, *, -1> everything else
+// (X-ray test source, hole loop, rotated + gas) with the switches read at run time.
+template <int BLOCK, bool FAST, bool ROT, int GAS>
 __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
                                                                 double* __restrict__ acc, HotB HBarg) {
   __shared__ TablesLds S;
@@ -1016,7 +1023,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     bool sampled = false, reached = false;
     HotA Hl;
     reload_hot(Hl);
-    const bool ok = phase_a<FAST, ROT ? 1 : 0>(Hl, Pb, L, A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi, st, sampled, reached);
+    constexpr bool ZEXT = FAST && !ROT && GAS == 0;
+    const bool ok = phase_a<FAST, ROT ? 1 : 0, ZEXT>(Hl, Pb, L, A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi, st, sampled, reached);
     const bool alive = valid && ok;
     n_reached += (uint32_t)__popcll(ballot64(valid && reached));
     const uint64_t mask = ballot64(alive);
@@ -1060,7 +1068,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       const DevBlob& Bo = lds_opaque(B);
       HotB HB;
       reload_kernarg(HB, offsetof(HistKernArgs, HB));
-      phase_b<false, FAST>(Bo.P, L, HB, lds_opaque(Ab), st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
+      phase_b<false, FAST, GAS, FAST && !ROT && GAS == 0>(Bo.P, L, HB, lds_opaque(Ab), st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
     }
     h1 += n_valid;
 #ifdef SART_STAGE_TIMING
@@ -1305,7 +1313,7 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
     bool sampled, reached;
     const uint64_t ray_id = A.ray_id_offset + i;
     const uint32_t u3_hi = word_of(stream_block(ray_id >> 2, A.seed_lo, A.seed_hi), (uint32_t)ray_id & 3u);
-    const bool alive = phase_a<false, -1>(H, P, L, A.seed_lo, A.seed_hi, ray_id, u3_hi, st, sampled, reached);
+    const bool alive = phase_a<false, -1, false>(H, P, L, A.seed_lo, A.seed_hi, ray_id, u3_hi, st, sampled, reached);
     int e_idx = -1;
     if (sampled) {
       e_idx = H.test_active ? P.n_energies : sample_energy_index(HB, st.r_idx, st.u5);
@@ -1315,7 +1323,7 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
     if (ballot64(alive)) {
       RayOut ro;
       if (!sampled) { st.u5 = 0.0; st.r_idx = 0; }
-      phase_b<true, false>(P, L, HB, A, st, e_idx >= 0 ? e_idx : 0, alive, ro, &rec);
+      phase_b<true, false, -1, false>(P, L, HB, A, st, e_idx >= 0 ? e_idx : 0, alive, ro, &rec);
     }
     out[i] = rec;
   }
@@ -1378,27 +1386,34 @@ extern "C" __attribute__((visibility("default"))) int sart_internal_math_eval(in
 
 // ---- launch wrappers (called from sart_api.hip) ----
 int records_block() { return kRecBlock; }
-// Variants: 0 = FAST, 1 = generic with the telescope not rotated, 2 = generic, rotated; all with 1024 threads = 4 waves /
-// SIMD (measured fastest of 256 / 512 / 768 / 1024).
+// Variants: 0 = specialised (solar source, no hole loop) vacuum, not rotated; 1 = generic, not rotated; 2 = generic, rotated;
+// 3 = specialised, gas stage; 4 = specialised, rotated.  All with 1024 threads = 4 waves / SIMD (measured fastest of 256 / 512 /
+// 768 / 1024).
 int histogram_block_of(int) { return 1024; }
+
+#define SART_HIST_VARIANTS(X) \
+  X(0, true, false, 0) X(1, false, false, -1) X(2, false, true, -1) X(3, true, false, 1) X(4, true, true, 0)
 
 int histogram_blocks_per_cu(int variant) {
   int n = 0;
-  hipError_t e;
-  if (variant == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, false, true>, 1024, 0);
-  else if (variant == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, false, false>, 1024, 0);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, true, false>, 1024, 0);
+  hipError_t e = hipErrorInvalidValue;
+  switch (variant) {
+#define X(ID, F, R, G) case ID: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, F, R, G>, 1024, 0); break;
+    SART_HIST_VARIANTS(X)
+#undef X
+    default: break;
+  }
   return (e == hipSuccess && n > 0) ? n : 1;
 }
 
 void launch_trace_histogram(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
                             hipStream_t stream, int variant) {
-  if (variant == 2)
-    hipLaunchKernelGGL((trace_histogram_kernel<1024, false, true>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB);
-  else if (variant == 1)
-    hipLaunchKernelGGL((trace_histogram_kernel<1024, false, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB);
-  else
-    hipLaunchKernelGGL((trace_histogram_kernel<1024, true, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB);
+  switch (variant) {
+#define X(ID, F, R, G) case ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB); break;
+    SART_HIST_VARIANTS(X)
+#undef X
+    default: return;
+  }
   const int n_img = A.image_nx * A.image_ny;
   hipLaunchKernelGGL(fold_scalars_kernel, dim3(1), dim3(256), 0, stream, acc + n_img, A.partials, n_blocks, (double)A.n_rays);
   if (A.replica_mask != 0u)

@@ -465,15 +465,18 @@ def test_command_line_full_run_and_angular_scan(tmp_path):
     assert scan.shape == (3, 3) and scan[0, 2] == 1.0 and scan[2, 2] < 1.0
 
 
-@pytest.mark.parametrize("name", ["babyiaxo_xmm", "cast_llnl"])
+@pytest.mark.parametrize("name", ["babyiaxo_xmm", "cast_llnl", "babyiaxo_xmm_gas", "babyiaxo_xmm_rot"])
 def test_specialised_and_generic_kernel_variants_agree(name):
-    """The compile-time specialised instantiation (solar source, telescope not rotated, vacuum, no hole loop) and the generic
-    one are the same source: same rays, same counters, same image (SART_FORCE_GENERIC is read when a context is created)."""
+    """The compile-time specialised instantiations (solar source, no hole loop: vacuum / gas stage / rotated telescope) and the
+    generic ones are the same source: same rays, same counters, same image (SART_FORCE_GENERIC is read when a context is
+    created).  The vacuum specialisation carries the z extent of the path and multiplies pathCB^2 by 1 + slope^2 in phase B;
+    the others carry the path length itself."""
     import os
     full = make_setup(name)
     n = 5_000_000
     with sa.RayTracer(full) as rt:
         img_a, s_a = rt.trace_histogram(n, seed=23, ray_id_offset=777)
+        assert s_a["N_PASSED"] > 0.1 * n
     os.environ["SART_FORCE_GENERIC"] = "1"
     try:
         with sa.RayTracer(full) as rt:
