@@ -770,3 +770,39 @@ def test_oversized_grid_and_image_limits(monkeypatch):
     for k in ("N_RAYS", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_PASSED", "N_HIT_NICKEL"):
         assert s[k] == ref[k], k
     assert s["SUM_WEIGHTS"] == pytest.approx(ref["SUM_WEIGHTS"], rel=1e-12)
+
+
+@pytest.mark.parametrize("shape", [(256, 256), (40, 30), (1, 14000), (3000, 3000)])
+def test_lds_image_tile_equals_global_atomics(shape, monkeypatch):
+    """Small focal spots (CAST / LLNL; stage A0 off) accumulate the centre of the spot in a per-workgroup LDS tile that is
+    placed by a pilot launch and flushed at the end of the kernel.  Same rays with the tile switched off (SART_NO_IMAGE_TILE):
+    identical counters, images equal up to summation order — for the standard binning, for images smaller than the tile, for a
+    one-column image (y-slice histogram) and for the 3000 x 3000 maps of generateResultPlots."""
+    nx, ny = shape
+    full = make_setup("cast_llnl_gold")
+    n = 3_000_000
+    with sa.RayTracer(full) as rt:
+        img_a, s_a = rt.trace_image(n, nx, ny, seed=12)
+        img_a2, s_a2 = rt.trace_image(n, nx, ny, seed=12)          # second call: tile position comes from the cache
+    monkeypatch.setenv("SART_NO_IMAGE_TILE", "1")
+    with sa.RayTracer(full) as rt:
+        img_b, s_b = rt.trace_image(n, nx, ny, seed=12)
+    for k in ("N_RAYS", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW", "N_PASSED", "N_OUTSIDE_IMAGE"):
+        assert s_a[k] == s_b[k] == s_a2[k], k
+    assert s_a["N_PASSED"] > 0.8 * n
+    scale = img_b.max()
+    np.testing.assert_allclose(img_a, img_b, rtol=1e-10, atol=scale * 1e-13)
+    np.testing.assert_allclose(img_a2, img_b, rtol=1e-10, atol=scale * 1e-13)
+    assert img_a.sum() == pytest.approx(s_a["SUM_WEIGHTS"], rel=1e-11)
+    # the setup moves the spot: the tile is re-placed (cache invalidated with the parameter blob), results stay right
+    with sa.RayTracer(full) as rt:
+        rt.trace_image(200_000, nx, ny, seed=1)
+        rt.set_telescope_angles(turned_y_deg=0.02)
+        img_c, s_c = rt.trace_image(n, nx, ny, seed=12)
+    monkeypatch.delenv("SART_NO_IMAGE_TILE")
+    with sa.RayTracer(full) as rt:
+        rt.trace_image(200_000, nx, ny, seed=1)
+        rt.set_telescope_angles(turned_y_deg=0.02)
+        img_d, s_d = rt.trace_image(n, nx, ny, seed=12)
+    assert s_c["N_PASSED"] == s_d["N_PASSED"]
+    np.testing.assert_allclose(img_d, img_c, rtol=1e-10, atol=max(img_c.max(), 1e-300) * 1e-13)
