@@ -119,9 +119,8 @@ __device__ __forceinline__ void sincos_turns(double u, const double* __restrict_
 // asin for the grazing angles of the path (|x| < ~0.03): odd Taylor series
 // asin x = x + x^3/6 + 3x^5/40 + 5x^7/112 + 35x^9/1152 + 63x^11/2816 + 231x^13/13312 + 143x^15/10240,
 // truncation error < 1e-19 below 0.06; the library function outside.
-__device__ __forceinline__ double asin_small(double x) {
+__device__ __forceinline__ double asin_small(double x, double x2) {   // x2 = x^2 (the caller has it)
   if (fabs(x) < 0.06) {
-    const double x2 = x * x;
     double p = SC(0.01396484375);               // 143/10240
     p = fma(p, x2, SC(0.017352764423076924));   // 231/13312
     p = fma(p, x2, SC(0.022372159090909092));   // 63/2816
@@ -240,11 +239,14 @@ __device__ __forceinline__ bool pick_root(double a, double hb, double c, double 
 // Reflection of the (un-normalised) direction w, |w|^2 = L, at a surface with (un-normalised)
 // normal n, |n|^2 = N2:  the reference's v' = v cos 2a - (v x axis) sin 2a with a = asin|n.v|/|n|
 // (:774-779) equals  v (1 - 2c^2 + 2c|c|) - 2|c| n^  with c = n^.v ; written for w = |w| v.
-// Returns sin^2(a) = c^2.
+// Returns sin^2(a) = c^2 and, in sin_a, sin(a) = |c| (from the reciprocal square root the formula needs anyway: the
+// reflectivity lookup wants the angle itself, and a separate square root of c^2 would cost seven more instructions).
 __device__ __forceinline__ double reflect(double& wx, double& wy, double& wz, double L, double nx, double ny,
-                                          double nz, double N2) {
+                                          double nz, double N2, double& sin_a) {
   const double dnw = fma(nx, wx, fma(ny, wy, nz * wz));
-  const double rnl = frcp(N2 * L);           // one reciprocal for both 1/N2 and 1/(N2 L)
+  const double y = frsq(N2 * L);             // 1 / (|n| |w|)
+  const double rnl = y * y;                  // 1 / (N2 L): serves 1/N2 and 1/(N2 L)
+  sin_a = fabs(dnw) * y;
   const double c2 = dnw * dnw * rnl;
   const double f = dnw * (L * rnl);
   const double ox = wx, oy = wy, oz = wz;
@@ -667,7 +669,8 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   if (draw_energy) energy_draw_candidates(HB, ed);   // the guide word has had the first mirror's arithmetic to arrive
   double wx = tsx, wy = tsy, wz = 1.0;
   const double N1 = fma(m1x, m1x, fma(m1y, m1y, n1z * n1z));
-  const double sin2_a1 = reflect(wx, wy, wz, L0, m1x, m1y, n1z, N1);
+  double sin_a1, sin_a2;
+  const double sin2_a1 = reflect(wx, wy, wz, L0, m1x, m1y, n1z, N1, sin_a1);
 
   // lineHitsNickel (:1706-1734), evaluated before the no-hit test (:2040-2057):
   // tan(a1) > num / (l - z1)  <=>  sin^2(a1) ((l - z1)^2 + num^2) > num^2   (num >= 0, l - z1 > 0)
@@ -699,7 +702,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const double n2z = wolter ? sh.n2_r3t * fma(2.0 * (P.l_mirror - z2), sh.n2_invF, 1.0)
                             : sh.n2_tan * fma(-sh.n2_tan, z2 - sh.m2_zlo, sh.m2_rc);
   const double N2 = fma(m2x, m2x, fma(m2y, m2y, n2z * n2z));
-  const double sin2_a2 = reflect(wx, wy, wz, L0, m2x, m2y, n2z, N2);
+  const double sin2_a2 = reflect(wx, wy, wz, L0, m2x, m2y, n2z, N2, sin_a2);
 
   SART_B_STAMP(2, wz);
   // ---- energy index, energy row and reflectivities: gathers issued here, consumed behind the detector-plane arithmetic ----
@@ -716,18 +719,16 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     const uint32_t row = __umul24((uint32_t)(sh.refl_row0 + e_idx), (uint32_t)HB.refl_n_angles);
     const int na2 = HB.refl_n_angles - 2;
     const double amin = P.refl_angle_min, inv_da = P.refl_inv_dangle, da = P.refl_dangle;
-    auto refl_at = [&](double sin2a, double& xu_out) {
-      // getMirrorAngle (:782-795), degrees; sin^2 is kept away from an exact zero (n.v == 0: measure zero) so that the
-      // seed-based square root cannot produce a NaN weight
-      const double alpha = asin_small(fsqrt_pos(sin2a + 1e-300)) * 57.29577951308232;   // + 1e-300: exact no-op unless sin2a == 0
+    auto refl_at = [&](double sina, double sin2a, double& xu_out) {
+      const double alpha = asin_small(sina, sin2a) * 57.29577951308232;   // getMirrorAngle (:782-795), degrees
       const double t = (alpha - amin) * inv_da;
       int i = (int)t;                 // = floor(t) for t >= 0; negative or NaN t ends in cell 0 through the clamp
       i = max(min(i, na2), 0);
       xu_out = (alpha - fma((double)i, da, amin)) * inv_da;
       return gload<d2>(HB.refl, (row + (uint32_t)i) * 8u);   // g[i], g[i + 1] (8-byte aligned pair)
     };
-    g1 = refl_at(sin2_a1, xu1);
-    g2 = refl_at(sin2_a2, xu2);
+    g1 = refl_at(sin_a1, sin2_a1, xu1);
+    g2 = refl_at(sin_a2, sin2_a2, xu2);
   }
 
   // ---- detector plane: getPointDetectorWindow (:797-814, :2070-2083) ----
@@ -1361,7 +1362,7 @@ __global__ void math_eval_kernel(int fn, const double* __restrict__ in, double* 
     case 4: sincos_turns<2>(x, tab, K, &sn, &cs); r = cs; break;
     case 5: sincos_turns<1>(x, tab, K, &sn, &cs); r = sn; break;
     case 6: sincos_turns<1>(x, tab, K, &sn, &cs); r = cs; break;
-    case 7: r = asin_small(x); break;
+    case 7: r = asin_small(x, x * x); break;
     case 8: r = cos_yaw_of_slope(x); break;
     case 9: r = atan_small(x); break;
     case 10: r = cos_small(x); break;
