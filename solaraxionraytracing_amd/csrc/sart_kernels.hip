@@ -926,7 +926,6 @@ struct ZoneTable {
 static_assert(sizeof(ZoneTable) == sizeof(HotA) - offsetof(HotA, n_zones), "ZoneTable mirrors the tail of HotA");
 static_assert(offsetof(WaveRings, u3hi) == offsetof(WaveRings, ray) + kQueue * sizeof(uint32_t) && offsetof(WaveRings, ray) % 8 == 0,
               "the image tile uses ray + u3hi of every wave as 128 contiguous doubles");
-static_assert(kImageTileMax * kImageTileMax <= 16 * kQueue, "image tile fits the ring-0 space of 16 waves");
 __device__ __forceinline__ void reload_zones(ZoneTable& dst) {
   typedef const __attribute__((address_space(4))) uint32_t* kernarg_ptr;
   kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(HotA, n_zones) / 4;
@@ -965,6 +964,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
                                                                 double* __restrict__ acc, HotB HBarg) {
   __shared__ TablesLds S;
   __shared__ QueueLds<BLOCK / 64> Q;
+  static_assert(kImageTileMax * kImageTileMax <= (BLOCK / 64) * kQueue,
+                "the LDS image tile (host: kImageTileMax) lives in the ring-0 space of this workgroup's waves");
   // Only the ~20 scalars phase A needs for every ray travel in the kernel arguments (SGPRs); everything
   // else is read from an LDS copy of the parameter blob (broadcast ds_read).  All of them together do not
   // fit the 102 SGPRs of a wave and would be spilled through VGPR lanes (v_readlane = VALU slots).
