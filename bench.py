@@ -49,6 +49,7 @@ WORKLOADS = {
     "babyiaxo_xmm_gas": "BabyIAXO magnet + XMM-Newton shells, gas stage (the m_a-scan kernel variant of BASELINE configs[4])",
     "babyiaxo_xmm_rot": "BabyIAXO magnet + XMM-Newton shells, telescope turned 0.1 deg, effective-area flags, chip 100 mm "
                         "(one angle bin of BASELINE configs[3])",
+    "babyiaxo_xmm_small_tables": "diagnostic only: the headline workload on 400 x 300 / 200 x 200 tables that stay in every XCD's L2",
 }
 
 
@@ -75,6 +76,8 @@ def make_setup(workload: str):
     flags = 0
     if workload == "babyiaxo_xmm":
         full = sa.initFullSetup()
+    elif workload == "babyiaxo_xmm_small_tables":
+        full = sa.initFullSetup(n_radii=400, n_energies=300, refl_n_angles=200, refl_n_energies=200)
     elif workload == "cast_llnl_gold":
         full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
     elif workload == "babyiaxo_xmm_gas":

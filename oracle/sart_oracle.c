@@ -89,10 +89,9 @@ static inline real rad_to_deg(real r) { return r / RAD_PER_DEG; }
 
 /* ------------------------------------------------------------------------------------------
  * RNG: Philox4x32-10 (Salmon et al., SC'11), key = (seed lo, seed hi),
- * counter = (ray id lo, ray id hi, block, 0).  Uniform k of a ray is built from words
- * (2k, 2k+1) of blocks 0..2 by mantissa fill, exactly as Nim's rand(1.0) turns its 64 random bits
- * into a float in [0, 1) — except the high word of u3, which comes from a word stream shared by
- * consecutive rays (see sart_oracle_uniforms).
+ * counter = (ray id lo, ray id hi, block, 0).  The six uniforms of a ray are built from blocks 0 and 1
+ * by mantissa fill, as Nim's rand(1.0) turns its 64 random bits into a float in [0, 1) — the high word
+ * of u3 comes from a word stream shared by consecutive rays (see sart_oracle_uniforms).
  * ---------------------------------------------------------------------------------------- */
 static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                  uint32_t k0, uint32_t k1, uint32_t out[4]) {
@@ -110,28 +109,36 @@ static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+static inline double fill52(uint32_t hi, uint32_t lo) {
+  /* 52 random mantissa bits (hi and the upper 20 bits of lo) under the exponent of 1.0, minus 1.0: Nim's std/random
+   * rand(1.0) */
+  uint64_t bits = ((uint64_t)hi << 32) | (uint64_t)lo;
+  union { uint64_t i; double d; } cv;
+  cv.i = 0x3FF0000000000000ull | (bits >> 12);
+  return cv.d - 1.0;
+}
+
 void sart_oracle_uniforms(uint64_t seed, uint64_t ray_id, double u[6]) {
-  uint32_t w[12];
-  for (uint32_t b = 0; b < 3; ++b)
-    philox4x32_10((uint32_t)ray_id, (uint32_t)(ray_id >> 32), b, 0u, (uint32_t)seed,
-                  (uint32_t)(seed >> 32), &w[4 * b]);
+  /* Two counter blocks per ray (256 bits) + one word of the shared stream serve the six uniforms: the two CDF draws
+   * (u2 radius, u5 energy) and the disc angle (u4) are filled with 52 random mantissa bits like Nim's rand(1.0); the two
+   * angles of the solar point (u0, u1) and the disc radius (u3) get 44: a high word of their own and the 12 bits that a
+   * 52-bit fill leaves over in its low word (2^-44 of a turn = 3.6e-13 rad; no bit is used twice). */
+  uint32_t w0[4], w1[4];
+  philox4x32_10((uint32_t)ray_id, (uint32_t)(ray_id >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w0);
+  philox4x32_10((uint32_t)ray_id, (uint32_t)(ray_id >> 32), 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w1);
   /* The high word of u3 (the uniform behind the radius of the point on the bore exit, :418) is word `ray_id` of a
    * word stream with random access: stream[n] = word (n & 3) of the block with counter (n >> 2, 3, 0).  Four
    * consecutive rays share that block, which is what lets the HIP kernel's first stage (rays that this word alone
-   * proves dead) cost a quarter of a Philox block per ray.  The low 20 bits stay the ray's own. */
-  {
-    uint32_t sh[4];
-    const uint64_t g = ray_id >> 2;
-    philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 3u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), sh);
-    w[6] = sh[ray_id & 3u];
-  }
-  for (int k = 0; k < 6; ++k) {
-    /* 52 random mantissa bits under the exponent of 1.0, minus 1.0: Nim's std/random rand(1.0) */
-    uint64_t bits = ((uint64_t)w[2 * k] << 32) | (uint64_t)w[2 * k + 1];
-    union { uint64_t i; double d; } cv;
-    cv.i = 0x3FF0000000000000ull | (bits >> 12);
-    u[k] = cv.d - 1.0;
-  }
+   * proves dead) cost a quarter of a Philox block per ray. */
+  uint32_t sh[4];
+  const uint64_t g = ray_id >> 2;
+  philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 3u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), sh);
+  u[2] = fill52(w0[0], w0[1]);
+  u[5] = fill52(w0[2], w0[3]);
+  u[0] = fill52(w1[0], w0[1] << 20);
+  u[1] = fill52(w1[1], w0[3] << 20);
+  u[4] = fill52(w1[2], w1[3]);
+  u[3] = fill52(sh[ray_id & 3u], w1[3] << 20);
 }
 
 /* ------------------------------------------------------------------------------------------

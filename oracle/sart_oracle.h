@@ -36,8 +36,9 @@ typedef struct sart_oracle_tables_t {
   const double* gas_abs_x; const double* gas_abs_y; int32_t n_gas_abs; int32_t _pad3;
 } sart_oracle_tables_t;
 
-/* The six uniforms of ray `ray_id` (Philox4x32-10, key = seed, counter = (id, block); the high word of u3 is word
- * `ray_id` of a word stream shared by consecutive rays: counter = (id >> 2, 3), word id & 3). */
+/* The six uniforms of ray `ray_id` (Philox4x32-10, key = seed, counter = (id, block), blocks 0 and 1: 52 random mantissa
+ * bits for the CDF draws u2, u5 and the disc angle u4, 44 for u0, u1, u3; the high word of u3 is word `ray_id` of a word
+ * stream shared by consecutive rays: counter = (id >> 2, 3), word id & 3). */
 void sart_oracle_uniforms(uint64_t seed, uint64_t ray_id, double u[6]);
 
 /* traceAxion for one ray given its uniforms; *res must be zero-initialised by the caller

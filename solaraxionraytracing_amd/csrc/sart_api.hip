@@ -132,6 +132,7 @@ struct sart_context {
   struct Knobs {
 #ifdef SART_DEBUG_KNOBS              // experiment builds only (make DEBUG_KNOBS=1); compiled out of the shipped library
     bool no_image_atomics = false;   // SART_DEBUG_NO_IMAGE_ATOMICS: timing experiment only (results are wrong)
+    uint32_t debug_flags = 0;        // SART_DEBUG_FLAGS=<hex>: 0x20000000 stage A0 drops every ray, 0x10000000 stage A1 does
 #endif
     bool no_early_reject = false;    // SART_NO_EARLY_REJECT: stage A0 off
     bool no_image_tile = false;      // SART_NO_IMAGE_TILE: small focal spots go to global atomics only (as before the tile)
@@ -469,6 +470,7 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   a.flags = p->flags;
 #ifdef SART_DEBUG_KNOBS
   if (c->knobs.no_image_atomics) a.flags |= 0x40000000u;
+  a.flags |= c->knobs.debug_flags & 0x38000000u;
 #endif
   a.image_nx = p->image_nx;
   a.image_ny = p->image_ny;
@@ -679,6 +681,7 @@ int sart_create(int device_ordinal, sart_context** out) {
     auto number = [](const char* name) { const char* e = std::getenv(name); return e ? std::max(0, std::atoi(e)) : 0; };
 #ifdef SART_DEBUG_KNOBS
     c->knobs.no_image_atomics = flag("SART_DEBUG_NO_IMAGE_ATOMICS");
+    if (const char* e = std::getenv("SART_DEBUG_FLAGS")) c->knobs.debug_flags = static_cast<uint32_t>(std::strtoul(e, nullptr, 16));
 #endif
     c->knobs.no_early_reject = flag("SART_NO_EARLY_REJECT");
     c->knobs.no_image_tile = flag("SART_NO_IMAGE_TILE");
@@ -915,14 +918,18 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   }
   {
     // Replication factor from the expected size of the solar image in pixels: plate scale (distance XRT -> detector)
-    // times the angular radius of the emitting core (~0.25 R_sun).  Wide images (BabyIAXO / XMM: f = 7.5 m) see no
-    // contention and add straight into the caller's accumulator.
+    // times the angular radius of the emitting core (~0.25 R_sun).  Scattered f64 atomics execute at the memory side
+    // (TCC_EA0_ATOMIC = every atomic) at ~2.4e10 lane-operations / s for the whole chip whatever the type or scope
+    // (tools/microbench/atomic_rates.hip), and the hot pixels of one image serialise there: wide images (BabyIAXO / XMM:
+    // f = 7.5 m) take 8 replicas (measured 1 / 2 / 4 / 8 / 16 / 32 / 128 replicas: 1.87 / 1.78 / 1.77 / 1.74-1.79 / 1.78 /
+    // 1.78 / 1.79 ms per 1e8 rays; 1.67 ms with the atomics switched off), small focal spots 64.
     const sart_setup_t& s = c->setup;
     const double spot_px = s.distance_detector_xrt * (0.25 * s.radius_sun / s.distance_sun_earth) *
                            a.image_inv_step_x;
     // Measured on CAST / LLNL (88 % of all rays land within ~30 pixels): 1 replica 12.4 ms per 1e8 rays, 16: 5.5, 64: 4.4,
     // 128: 4.4, 512: 4.6 (3.99 ms with the atomics switched off).
-    int R = spot_px > 96.0 ? 1 : 64;
+    int R = spot_px > 96.0 ? 8 : 64;
+    if (static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny) > (1u << 20)) R = std::min(R, 1);   // heat maps of millions of pixels: no scratch copies
     if (s.test_active) R = 64;
     if (c->knobs.image_replicas > 0) R = std::min(kMaxImageReplicas, c->knobs.image_replicas);
     while (R & (R - 1)) R &= R - 1;   // power of two

@@ -412,13 +412,16 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   const bool cfg_rotated = (ROT < 0) ? (H.rotated != 0) : (ROT != 0);
   const bool cfg_holes = FAST ? false : (H.telescope_kind == SART_TK_XMM && H.inner_blocks < 0);
   const uint32_t id_lo = (uint32_t)ray_id, id_hi = (uint32_t)(ray_id >> 32);
+  // The six uniforms of a ray from TWO counter blocks (256 bits) + its word of the shared stream (sart_oracle_uniforms):
+  // the two CDF draws (u2, u5) and the disc angle (u4) have 52 random mantissa bits, the two angles of the solar point
+  // (u0, u1) and the disc radius (u3) 44: a high word of their own + the 12 bits the 52-bit fills leave over in a word.
   const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, seed_lo, seed_hi);
   const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, seed_lo, seed_hi);
-  const U4 b2 = philox4x32_10(id_lo, id_hi, 2u, 0u, seed_lo, seed_hi);
-  const double u0 = u52(b0.x, b0.y), u1 = u52(b0.z, b0.w);
-  const double u2 = u52(b1.x, b1.y), u3 = u52(u3_hi, b1.w);   // u3_hi = word ray_id of the shared stream
-  const double u4 = u52(b2.x, b2.y);
-  st.u5 = u52(b2.z, b2.w);
+  const double u2 = u52(b0.x, b0.y);
+  st.u5 = u52(b0.z, b0.w);
+  const double u0 = u52(b1.x, b0.y << 20), u1 = u52(b1.y, b0.w << 20);
+  const double u4 = u52(b1.z, b1.w);
+  const double u3 = u52(u3_hi, b1.w << 20);   // u3_hi = word ray_id of the shared stream
   st.r_idx = 0;
 
   bool ok = true;
@@ -436,7 +439,10 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
       int lo = (int)L.rguide[k];
       const int hi = (int)L.rguide[k + 1];
       if (H.radius_span <= 4) {
-        for (int s = 0; s < H.radius_span; ++s) lo += (lo < hi && L.rcdf[lo] < u2) ? 1 : 0;
+        // four consecutive candidates in ONE round trip to LDS: the table is sorted and rcdf[hi] >= u2, so entries at or
+        // beyond hi never count (the stage pads the table with four entries of 1.0)
+        const double c0 = L.rcdf[lo], c1 = L.rcdf[lo + 1], c2 = L.rcdf[lo + 2], c3 = L.rcdf[lo + 3];
+        lo += (int)(c0 < u2) + (int)(c1 < u2) + (int)(c2 < u2) + (int)(c3 < u2);
       } else {
         lo = lower_bound_bracket(L.rcdf, lo, hi, u2);
       }
@@ -600,12 +606,18 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   // R1 ascending: the nearest shell above is the first j with R1[j] > radial; the look-up cell (narrower
   // than any shell spacing) gives it up to one step
   const int nS = H.n_shells;
-  int j = (int)L.lut[max(min((int)(radial * H.lut_inv_step), H.lut_n - 1), 0)];
-  j += (j < nS && !(L.shells[min(j, nS - 1)].r1 > radial)) ? 1 : 0;
+  const int j0 = (int)L.lut[max(min((int)(radial * H.lut_inv_step), H.lut_n - 1), 0)];
+  // the radii of the cell's shell and of the one below it, read together (one round trip to LDS instead of two dependent ones)
+  const int jc = min(j0, nS - 1), jb = max(jc - 1, 0);
+  const double c_r1 = L.shells[jc].r1, c_ro = L.shells[jc].r1_outer;
+  const double b_r1 = L.shells[jb].r1, b_ro = L.shells[jb].r1_outer;
+  const bool step = (j0 < nS) & !(c_r1 > radial);
+  const int j = j0 + (step ? 1 : 0);
   ok = ok && (j < nS);   // radial == R1[last] exactly (measure zero; the reference then uses a zero shell)
-  // glass front (:1942-1944): only the shell just below can contain radial (thickness < spacing, checked on the host)
-  const int jm = min(max(j - 1, 0), nS - 1);
-  ok = ok && !(j > 0 && radial > L.shells[jm].r1 && radial < L.shells[jm].r1_outer);
+  // glass front (:1942-1944): only the shell just below the selected one can contain radial (thickness < spacing, checked on
+  // the host): the cell's shell after a step, the one below it otherwise
+  const double g_r1 = step ? c_r1 : b_r1, g_ro = step ? c_ro : b_ro;
+  ok = ok && !(j > 0 && radial > g_r1 && radial < g_ro);
   st.shell = min(j, nS - 1);
   return ok;
 }
@@ -705,30 +717,38 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const double sin2_a2 = reflect(wx, wy, wz, L0, m2x, m2y, n2z, N2, sin_a2);
 
   SART_B_STAMP(2, wz);
-  // ---- energy index, energy row and reflectivities: gathers issued here, consumed behind the detector-plane arithmetic ----
-  const int e_idx = draw_energy ? energy_draw_finish(HB, ed) : e_idx_in;
-  SART_B_STAMP(3, e_idx);
-  const EnergyDev en = load_energy_row(HB, e_idx);
-  // the two reflectivity gathers are issued here and interpolated behind the detector-plane arithmetic
-  d2 g1 = {1.0, 1.0}, g2 = {1.0, 1.0};
+  // ---- reflectivity lookups, angle part (computeReflectivity :1533-1580: bilinear in (angle, energy); the energy
+  // interpolation is folded into the per-energy-index table, leaving a linear interpolation in the angle).  The cell and
+  // the fraction inside it do not depend on the energy index: computed while the CDF candidates are in flight ----
+  const bool use_refl = !(flags & SART_CF_IGNORE_REFLECTION);
+  int ia1 = 0, ia2 = 0;
   double xu1 = 0.0, xu2 = 0.0;
-  if (!(flags & SART_CF_IGNORE_REFLECTION)) {
-    // computeReflectivity (:1533-1580): bilinear in (angle, energy); the energy interpolation is folded
-    // into the per-energy-index table, leaving a linear interpolation in the angle.
-    // row (coating, e_idx) of refl[][n_angles]: 32-bit element offset (the table is < 4 GB, checked on the host)
-    const uint32_t row = __umul24((uint32_t)(sh.refl_row0 + e_idx), (uint32_t)HB.refl_n_angles);
+  if (use_refl) {
     const int na2 = HB.refl_n_angles - 2;
     const double amin = P.refl_angle_min, inv_da = P.refl_inv_dangle, da = P.refl_dangle;
-    auto refl_at = [&](double sina, double sin2a, double& xu_out) {
+    auto angle_cell = [&](double sina, double sin2a, double& xu_out) {
       const double alpha = asin_small(sina, sin2a) * 57.29577951308232;   // getMirrorAngle (:782-795), degrees
       const double t = (alpha - amin) * inv_da;
       int i = (int)t;                 // = floor(t) for t >= 0; negative or NaN t ends in cell 0 through the clamp
       i = max(min(i, na2), 0);
       xu_out = (alpha - fma((double)i, da, amin)) * inv_da;
-      return gload<d2>(HB.refl, (row + (uint32_t)i) * 8u);   // g[i], g[i + 1] (8-byte aligned pair)
+      return i;
     };
-    g1 = refl_at(sin_a1, sin2_a1, xu1);
-    g2 = refl_at(sin_a2, sin2_a2, xu2);
+    ia1 = angle_cell(sin_a1, sin2_a1, xu1);
+    ia2 = angle_cell(sin_a2, sin2_a2, xu2);
+  }
+
+  // ---- energy index; the energy row and the two reflectivity pairs are requested the moment it is known and consumed
+  // behind the detector-plane and window geometry ----
+  const int e_idx = draw_energy ? energy_draw_finish(HB, ed) : e_idx_in;
+  SART_B_STAMP(3, e_idx);
+  const EnergyDev en = load_energy_row(HB, e_idx);
+  d2 g1 = {1.0, 1.0}, g2 = {1.0, 1.0};
+  if (use_refl) {
+    // row (coating, e_idx) of refl[][n_angles]: 32-bit element offset (the table is < 4 GB, checked on the host)
+    const uint32_t row = __umul24((uint32_t)(sh.refl_row0 + e_idx), (uint32_t)HB.refl_n_angles);
+    g1 = gload<d2>(HB.refl, (row + (uint32_t)ia1) * 8u);   // g[i], g[i + 1] (8-byte aligned pair)
+    g2 = gload<d2>(HB.refl, (row + (uint32_t)ia2) * 8u);
   }
 
   // ---- detector plane: getPointDetectorWindow (:797-814, :2070-2083) ----
@@ -755,6 +775,25 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     rec->pixvalsY = floor(Y0 / (48.0 / 1400.0)) + 700.0;
   }
 
+  const double distance_pipe_m = (pdz - zcb) * 1e-3;               // :2116 (before the straight-through override of pdz)
+  if (test_active) {   // straight through the hole in the optics (:2130-2132)
+    const bool through = (sh.r1 - fsqrt(Q0)) > 100.0;
+    pdx = through ? fma(sh.dist_det_raw, tsx, X0) : pdx;
+    pdy = through ? fma(sh.dist_det_raw, tsy, Y0) : pdy;
+    pdz = through ? sh.dist_det_raw : pdz;
+  }
+  pdx -= P.lateral_shift;
+  pdy -= P.transversal_shift;
+
+  // ---- geometry of the detector window / chip (:2138-2147) and of the window strips (:2149-2187: rotateAroundZ by theta,
+  // strips along x): none of it needs the gathers, so it runs before they are consumed ----
+  const double rdet2 = fma(pdx, pdx, pdy * pdy);
+  const bool on_chip = !(!(flags & SART_CF_IGNORE_DET_WINDOW) && rdet2 > P.radius_window_sq) &&
+                       !(fabs(pdx) > P.chip_cx || fabs(pdy) > P.chip_cy);
+  const double yt = fabs(fma(pdy, P.theta_c, -pdx * P.theta_s));
+  bool in_strip = false;
+  for (int i = 0; i < n_half_strips; ++i) in_strip = in_strip || (yt > P.strip_lo[i] && yt < P.strip_hi[i]);
+
   // ---- weights (:2116-2128) ----
   const double path_cb = st.path_cb;
   double trans_magnet;
@@ -775,7 +814,6 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
         const double term3 = fma(eh, eh, 1.0) - 2.0 * eh * cos(q * Lnat);
         prob = P.gas_term1 * term2 * term3;
       }
-      const double distance_pipe_m = (pdz - zcb) * 1e-3;             // :2116
       // intensitySuppression2 (axionMassforMagnet.nim:100-113): exp(-mu_pipe d) exp(-mu_magnet L) as one exponential
       absorb = exp(-fma(en.mu_pipe, distance_pipe_m, en.mu_magnet * (path_cb * 1e-3)));
     }
@@ -791,27 +829,11 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     rec->reflect = reflectv;
   }
 
-  if (test_active) {   // straight through the hole in the optics (:2130-2132)
-    const bool through = (sh.r1 - fsqrt(Q0)) > 100.0;
-    pdx = through ? fma(sh.dist_det_raw, tsx, X0) : pdx;
-    pdy = through ? fma(sh.dist_det_raw, tsy, Y0) : pdy;
-    pdz = through ? sh.dist_det_raw : pdz;
-  }
-  pdx -= P.lateral_shift;
-  pdy -= P.transversal_shift;
   const bool till_window = live & (weight != 0.0);
   out.m_till = ballot64(till_window);
   if (RECORDS && till_window) rec->passedTillWindow = 1;
+  live = live && on_chip;
 
-  // ---- detector window / chip (:2138-2147) ----
-  const double rdet2 = fma(pdx, pdx, pdy * pdy);
-  live = live && !(!(flags & SART_CF_IGNORE_DET_WINDOW) && rdet2 > P.radius_window_sq);
-  live = live && !(fabs(pdx) > P.chip_cx || fabs(pdy) > P.chip_cy);
-
-  // window strips (:2149-2187): rotateAroundZ by theta, strips along x
-  const double yt = fabs(fma(pdy, P.theta_c, -pdx * P.theta_s));
-  bool in_strip = false;
-  for (int i = 0; i < n_half_strips; ++i) in_strip = in_strip || (yt > P.strip_lo[i] && yt < P.strip_hi[i]);
   const double trans_window = (n_half_strips > 0) ? (in_strip ? en.t_strongback : en.t_window) : 0.0;
   const uint8_t kind_w = in_strip ? SART_MK_SI : SART_MK_SI3N4;
   // wave-uniform switches as scalar branches around one multiplication each (the empty asm keeps LLVM from turning them
@@ -857,7 +879,7 @@ constexpr int kQueue = 128;   // ring capacity per wave: < 64 left over + <= 64 
 
 struct __align__(16) TablesLds {
   double sincos[2 * kSinCosEntries];
-  double rcdf[kMaxRadii];
+  double rcdf[kMaxRadii + 4];   // + four entries of 1.0 behind the table (four-wide candidate read of the radius draw)
   ShellDev shells[kMaxShells];
   uint16_t rguide[kRadiusGuide + 8];
   uint8_t lut[kShellLutMax];
@@ -881,7 +903,7 @@ struct __align__(16) QueueLds {
 template <int BLOCK>
 __device__ __forceinline__ void stage_tables(TablesLds& S, const DevParams& P, const DevTables& T) {
   for (int i = threadIdx.x; i < 2 * kSinCosEntries; i += BLOCK) S.sincos[i] = as_global(T.sincos_tab)[i];
-  for (int i = threadIdx.x; i < P.n_radii; i += BLOCK) S.rcdf[i] = as_global(T.flux_radius_cdf)[i];
+  for (int i = threadIdx.x; i < P.n_radii + 4; i += BLOCK) S.rcdf[i] = (i < P.n_radii) ? as_global(T.flux_radius_cdf)[i] : 1.0;
   for (int i = threadIdx.x; i <= kRadiusGuide; i += BLOCK) S.rguide[i] = as_global(T.radius_guide)[i];
   {
     const auto src = as_global(reinterpret_cast<const uint64_t*>(T.shells));
@@ -1027,7 +1049,11 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     reload_hot(Hl);
     constexpr bool ZEXT = FAST && !ROT && GAS == 0;
     const bool ok = phase_a<FAST, ROT ? 1 : 0, ZEXT>(Hl, Pb, L, A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi, st, sampled, reached);
+#ifdef SART_DEBUG_KNOBS
+    const bool alive = valid && ok && !(A.flags & 0x10000000u);   // experiment: nothing reaches phase B
+#else
     const bool alive = valid && ok;
+#endif
     n_reached += (uint32_t)__popcll(ballot64(valid && reached));
     const uint64_t mask = ballot64(alive);
     const uint32_t cnt = (uint32_t)__popcll(mask);
@@ -1097,7 +1123,12 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       const bool inside = (fx >= 0.0) & (fx < (double)nx) & (fy >= 0.0) & (fy < (double)ny);
       n_outside += (uint32_t)__popcll(ballot64(!inside));
       // this wave's replica of the image; the pixel's byte offset is 32-bit (image < 2^29 pixels, checked on the host)
+#ifdef SART_DEBUG_KNOBS
+      const uint32_t rep_key = (Al.flags & 0x08000000u) ? blockIdx.x : (uint32_t)wave_global;   // experiment: replica per XCD
+      double* const img = Al.replicas + (size_t)(rep_key & Al.replica_mask) * (size_t)Al.replica_stride;
+#else
       double* const img = Al.replicas + (size_t)((uint32_t)wave_global & Al.replica_mask) * (size_t)Al.replica_stride;
+#endif
 #ifdef SART_DEBUG_KNOBS
       if (inside && !(Al.flags & 0x40000000u))   // SART_DEBUG_NO_IMAGE_ATOMICS (experiment builds only)
 #else
@@ -1169,7 +1200,11 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         }
         const uint64_t valid_m = ballot64(rel >= rel_begin) & ballot64(rel < rel_end);
         n_reached += (uint32_t)__popcll(valid_m & reached_m);
+#ifdef SART_DEBUG_KNOBS
+        const uint64_t mask = (A.flags & 0x20000000u) ? 0ull : (valid_m & ~dead_m);   // experiment: nothing reaches stage A1
+#else
         const uint64_t mask = valid_m & ~dead_m;
+#endif
         if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
           const uint32_t slot = (t0 + prefix_of(mask)) % kQueue;
           Q.w[wave].ray[slot] = rel;

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Experiment build of libsart with the SART_DEBUG_* knobs (never shipped): tools/microbench/libsart_dbg.so; use with
+# SART_LIBSART=$PWD/tools/microbench/libsart_dbg.so.  Extra compiler flags: $1.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+B=/tmp/sart_dbg_build; mkdir -p $B
+cd $ROOT/solaraxionraytracing_amd/csrc
+for f in sart_api sart_kernels sart_emission; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -DSART_DEBUG_KNOBS $1 -mllvm -disable-machine-licm -c -o $B/$f.o $f.hip &
+done
+wait
+/opt/rocm/bin/hipcc -O3 -fPIC --offload-arch=gfx950 -shared -o ${OUT:-$ROOT/tools/microbench/libsart_dbg.so} $B/sart_api.o $B/sart_kernels.o $B/sart_emission.o

@@ -8,8 +8,12 @@ from solaraxionraytracing_amd import _lib as L
 from bench import make_setup
 
 n = 100_000_000
-for wl in ("babyiaxo_xmm", "cast_llnl_gold"):
-    full, flags = make_setup(wl)
+SMALL = dict(n_radii=400, n_energies=300, refl_n_angles=200, refl_n_energies=200)   # tables that stay in every XCD's L2
+for wl in ("babyiaxo_xmm", "cast_llnl_gold", "babyiaxo_xmm/small-tables"):
+    if wl.endswith("small-tables"):
+        full, flags = sa.initFullSetup(**SMALL), 0
+    else:
+        full, flags = make_setup(wl)
     with sa.RayTracer(full) as rt:
         rt.trace_histogram(n // 10, seed=1, flags=flags)
         rt.enable_kernel_timing(True)
