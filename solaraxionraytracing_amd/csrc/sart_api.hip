@@ -127,7 +127,7 @@ size_t lower_bound_idx(const double* a, size_t n, double key) {
 struct sart_context {
   int device = 0;
   int n_cu = 0;
-  int blocks_per_cu_hist[5] = {0, 0, 0, 0, 0}, blocks_per_cu_rec = 0;
+  int blocks_per_cu_hist[6] = {0, 0, 0, 0, 0, 0}, blocks_per_cu_rec = 0;
   // tuning / experiment knobs, read from the environment once when the context is created
   struct Knobs {
 #ifdef SART_DEBUG_KNOBS              // experiment builds only (make DEBUG_KNOBS=1); compiled out of the shipped library
@@ -136,6 +136,7 @@ struct sart_context {
 #endif
     bool no_early_reject = false;    // SART_NO_EARLY_REJECT: stage A0 off
     bool no_image_tile = false;      // SART_NO_IMAGE_TILE: small focal spots go to global atomics only (as before the tile)
+    bool no_path_const = false;      // SART_NO_PATH_CONST: never use the constant-path kernel variant (5)
     bool force_generic = false;      // SART_FORCE_GENERIC: never use the specialised kernel variant
     int image_replicas = 0;          // SART_IMAGE_REPLICAS: 0 = chosen from the plate scale
     int hist_blocks_per_cu = 0;      // SART_HIST_BLOCKS_PER_CU: 0 = occupancy query
@@ -163,6 +164,7 @@ struct sart_context {
   std::vector<ShellDev> shells;
   std::vector<uint8_t> shell_lut;
   int radius_span = 0;
+  bool path_const = false;     // no survivor of phase A entered through the bore wall (path_is_constant)
   DevBuf<ShellDev> d_shells;
   DevBuf<double> d_sincos;     // (cos, sin)(pi k / 64), k = 0 .. 128 (sampling angles, sart_kernels.hip: sincos_turns)
   DevBuf<uint8_t> d_lut;
@@ -567,6 +569,23 @@ void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h
   }
 }
 
+// True if every ray from the Sun that survives the three cuts behind the magnetic field (cold-bore exit, two pipe cuts;
+// raytracer.nim:1846-1868) crossed the entrance plane z = 0 inside the bore, i.e. none of them entered through the bore
+// wall (lineIntersectsCylinderOnce, :1825-1843): with |slope| <= s_max a ray that is within R_k of the axis at the plane
+// dz_k behind the field exit was within R_k + (lengthB + dz_k) s_max of it at z = 0.  The path in the magnetic field is
+// then lengthB (times the slope factor) for every ray that reaches the mirrors, and the kernel variant 5 does not carry it.
+bool path_is_constant(const DevParams& P, const HotA& h, int n_radii) {
+  if (P.test_active || n_radii < 1) return false;
+  const double R = P.radius_cb;
+  const double r_sun_max = (0.0015 + (n_radii - 1) * 0.0005) * P.sun_radius;
+  const double s_max = (r_sun_max + R) / (P.sun_distance + P.length_b - r_sun_max) * (1.0 + 1e-6);
+  const double dz[3] = {h.dz1, h.dz2, h.dz3};
+  const double Rk[3] = {R, std::sqrt(P.pipe1_radius_sq), std::sqrt(P.pipe1_radius_sq)};
+  double reach = 1e300;   // largest distance from the axis at z = 0 of a ray that passes all three cuts
+  for (int k = 0; k < 3; ++k) reach = std::min(reach, Rk[k] + (P.length_b + dz[k]) * s_max);
+  return reach + 1e-6 < R;
+}
+
 DevTables tables_of(sart_context* c);
 
 // (Re)uploads the parameter blob if the host mirror changed.  Ordered after all work already queued on
@@ -589,6 +608,7 @@ int sync_blob(sart_context* c) {
   c->hotb.cdf_stride = c->n_energies + kEnergyCdfPad;
   c->hotb._pad = 0;
   if (!c->knobs.no_early_reject) build_zones(c->setup, c->params, c->n_radii, c->hot);
+  c->path_const = path_is_constant(c->params, c->hot, c->n_radii);
   c->blob_dirty = false;
   c->tile.valid = false;   // the focal spot may have moved
   return 0;
@@ -685,6 +705,7 @@ int sart_create(int device_ordinal, sart_context** out) {
 #endif
     c->knobs.no_early_reject = flag("SART_NO_EARLY_REJECT");
     c->knobs.no_image_tile = flag("SART_NO_IMAGE_TILE");
+    c->knobs.no_path_const = flag("SART_NO_PATH_CONST");
     c->knobs.force_generic = flag("SART_FORCE_GENERIC");
     c->knobs.image_replicas = number("SART_IMAGE_REPLICAS");
     c->knobs.hist_blocks_per_cu = number("SART_HIST_BLOCKS_PER_CU");
@@ -916,6 +937,17 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
     }
     return 0;
   }
+  // kernel variant: 0 = specialised for the common configuration (solar source, telescope not rotated, vacuum, no
+  // hole loop); 1 = generic, not rotated; 2 = generic, rotated
+  const DevParams& P = c->params;
+  // 0 / 3 / 4: compile-time specialisations for the solar source without the hole loop (vacuum; gas stage = the m_a scan;
+  // rotated telescope = the angular scan); 1 / 2: everything else with the switches read at run time; 5: variant 0 when no
+  // surviving ray entered through the bore wall (constant path in the magnetic field, LDS image tile beside stage A0)
+  const bool fast = !P.test_active && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) && !c->knobs.force_generic;
+  int variant = P.rotated ? 2 : 1;
+  if (fast && !P.rotated) variant = P.stage_gas ? 3 : 0;
+  if (fast && P.rotated && !P.stage_gas) variant = 4;
+  if (variant == 0 && c->path_const && !c->knobs.no_path_const) variant = 5;
   {
     // Replication factor from the expected size of the solar image in pixels: plate scale (distance XRT -> detector)
     // times the angular radius of the emitting core (~0.25 R_sun).  Scattered f64 atomics execute at the memory side
@@ -946,10 +978,11 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
       }
       a.replicas = c->d_replicas.p;
       a.replica_mask = static_cast<uint32_t>(R - 1);
-      // Small focal spot and no stage A0 (its ring space in LDS is free): accumulate the centre of the spot in a
-      // per-workgroup LDS tile.  The tile is centred on the spot's centroid, measured once per setup and image binning by a
-      // pilot launch of 2e5 rays into a one-pixel image (only SUM_X / SUM_Y / N_PASSED are read).
-      if (c->hot.n_zones == 0 && !c->knobs.no_image_tile && !c->tile.in_pilot) {
+      // No stage A0 (its ring space in LDS is free) or the constant-path variant (the path column of ring 1 is free):
+      // accumulate the centre of the spot in a per-workgroup LDS tile (CAST / LLNL: 65 % of the hits, BabyIAXO / XMM: 29 %).
+      // The tile is centred on the spot's centroid, measured once per setup and image binning by a pilot launch of 2e5 rays
+      // into a one-pixel image (only SUM_X / SUM_Y / N_PASSED are read).
+      if ((c->hot.n_zones == 0 || variant == 5) && !c->knobs.no_image_tile && !c->tile.in_pilot) {
         sart_context::TileCache& t = c->tile;
         const bool same = t.valid && t.nx == p->image_nx && t.ny == p->image_ny && t.x_min == p->image_x_min &&
                           t.x_max == p->image_x_max && t.y_min == p->image_y_min && t.y_max == p->image_y_max;
@@ -997,15 +1030,6 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
       a.replica_mask = 0u;
     }
   }
-  // kernel variant: 0 = specialised for the common configuration (solar source, telescope not rotated, vacuum, no
-  // hole loop); 1 = generic, not rotated; 2 = generic, rotated
-  const DevParams& P = c->params;
-  // 0 / 3 / 4: compile-time specialisations for the solar source without the hole loop (vacuum; gas stage = the m_a scan;
-  // rotated telescope = the angular scan); 1 / 2: everything else with the switches read at run time
-  const bool fast = !P.test_active && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) && !c->knobs.force_generic;
-  int variant = P.rotated ? 2 : 1;
-  if (fast && !P.rotated) variant = P.stage_gas ? 3 : 0;
-  if (fast && P.rotated && !P.stage_gas) variant = 4;
   if (c->blocks_per_cu_hist[variant] == 0) {
     c->blocks_per_cu_hist[variant] = std::max(1, histogram_blocks_per_cu(variant));
     if (c->knobs.hist_blocks_per_cu > 0) c->blocks_per_cu_hist[variant] = c->knobs.hist_blocks_per_cu;

@@ -981,13 +981,21 @@ __device__ __forceinline__ void reload_kernarg(T& dst, size_t byte_offset) {
 // Instantiations: <FAST, ROT, GAS> = <true, false, 0> the common configuration; <true, false, 1> gas stage (the m_a scan of
 // BASELINE configs[4]); <true, true, 0> rotated telescope (the angular scan of configs[3]); <false, *, -1> everything else
 // (X-ray test source, hole loop, rotated + gas) with the switches read at run time.
-template <int BLOCK, bool FAST, bool ROT, int GAS>
+// PATHC (common configuration only): the host has proved that no ray that survives phase A entered through the bore wall
+// (sart_api.hip: build_zones), so the path in the magnetic field is the constant lengthB for every ray of phase B: ring 1
+// does not carry it, and its 128 doubles per wave hold the LDS image tile instead (with stage A0 running beside it).
+template <int BLOCK, bool FAST, bool ROT, int GAS, bool PATHC>
 __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
                                                                 double* __restrict__ acc, HotB HBarg) {
   __shared__ TablesLds S;
   __shared__ QueueLds<BLOCK / 64> Q;
+  static_assert(!PATHC || (FAST && !ROT && GAS == 0), "the constant-path form belongs to the vacuum, unrotated specialisation");
   static_assert(kImageTileMax * kImageTileMax <= (BLOCK / 64) * kQueue,
-                "the LDS image tile (host: kImageTileMax) lives in the ring-0 space of this workgroup's waves");
+                "the LDS image tile (host: kImageTileMax) lives in 128 doubles per wave of this workgroup's rings");
+  // cell t of the LDS image tile: 128 doubles per wave, in the space of ring 0 (stage A0 off) or of ring 1's path column (PATHC)
+  auto tile_cell = [&](uint32_t t) -> double* {
+    return PATHC ? &Q.w[t >> 7].path[t & 127u] : reinterpret_cast<double*>(&Q.w[t >> 7].ray[0]) + (t & 127u);
+  };
   // Only the ~20 scalars phase A needs for every ray travel in the kernel arguments (SGPRs); everything
   // else is read from an LDS copy of the parameter blob (broadcast ds_read).  All of them together do not
   // fit the 102 SGPRs of a wave and would be spilled through VGPR lanes (v_readlane = VALU slots).
@@ -1062,7 +1070,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       const uint32_t slot = (t1 + prefix_of(mask)) % kQueue;
       Q.w[wave].X0[slot] = st.X0; Q.w[wave].Y0[slot] = st.Y0;
       Q.w[wave].tsx[slot] = st.tsx; Q.w[wave].tsy[slot] = st.tsy;
-      Q.w[wave].path[slot] = st.path_cb; Q.w[wave].u5[slot] = st.u5;
+      if (!PATHC) Q.w[wave].path[slot] = st.path_cb;
+      Q.w[wave].u5[slot] = st.u5;
       Q.w[wave].idx[slot] = st.r_idx | (st.shell << 16);
     }
     t1 += cnt;
@@ -1078,7 +1087,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       // predicated off; every index they lead to is one a real ray produced
       st.X0 = Q.w[wave].X0[slot]; st.Y0 = Q.w[wave].Y0[slot];
       st.tsx = Q.w[wave].tsx[slot]; st.tsy = Q.w[wave].tsy[slot];
-      st.path_cb = Q.w[wave].path[slot]; st.u5 = Q.w[wave].u5[slot];
+      st.path_cb = PATHC ? H.length_b : Q.w[wave].path[slot];   // PATHC: z extent of the path = lengthB for every ray
+      st.u5 = Q.w[wave].u5[slot];
       if (!ROT) {
         st.zcb = -(H.dz3 - H.dz1);
       } else {
@@ -1142,9 +1152,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const uint32_t tx = ix - (uint32_t)Al.tile_x0, ty = iy - (uint32_t)Al.tile_y0;   // unsigned: below the origin wraps to huge
         if ((tx < tn) & (ty < tn)) {
           const uint32_t t = ty * tn + tx;                                   // < 45 * 45 <= 16 x 128
-          // ring 0 of wave (t >> 7): `ray` and `u3hi` are adjacent, 128 doubles per wave
-          double* cell = reinterpret_cast<double*>(&Q.w[t >> 7].ray[0]) + (t & 127u);
-          __hip_atomic_fetch_add(cell, out.weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f64
+          __hip_atomic_fetch_add(tile_cell(t), out.weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f64
         } else {
           const uint32_t pix = iy * (uint32_t)nx + ix;
           typedef __attribute__((address_space(1))) char* gbytes;
@@ -1254,7 +1262,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     const uint32_t tn = (uint32_t)A.tile_n, n_tile = tn * tn;
     double* const img = A.replicas + (size_t)((uint32_t)wave_global & A.replica_mask) * (size_t)A.replica_stride;
     for (uint32_t t = threadIdx.x; t < n_tile; t += BLOCK) {
-      const double v = reinterpret_cast<const double*>(&Q.w[t >> 7].ray[0])[t & 127u];
+      const double v = *tile_cell(t);
       if (v != 0.0) {
         const uint32_t ty = t / tn, tx = t - ty * tn;
         unsafeAtomicAdd(&img[(size_t)((uint32_t)A.tile_y0 + ty) * (size_t)A.image_nx + ((uint32_t)A.tile_x0 + tx)], v);
@@ -1424,18 +1432,19 @@ extern "C" __attribute__((visibility("default"))) int sart_internal_math_eval(in
 // ---- launch wrappers (called from sart_api.hip) ----
 int records_block() { return kRecBlock; }
 // Variants: 0 = specialised (solar source, no hole loop) vacuum, not rotated; 1 = generic, not rotated; 2 = generic, rotated;
-// 3 = specialised, gas stage; 4 = specialised, rotated.  All with 1024 threads = 4 waves / SIMD (measured fastest of 256 / 512 /
+// 3 = specialised, gas stage; 4 = specialised, rotated; 5 = variant 0 with the constant path in the magnetic field (PATHC).  All with 1024 threads = 4 waves / SIMD (measured fastest of 256 / 512 /
 // 768 / 1024).
 int histogram_block_of(int) { return 1024; }
 
 #define SART_HIST_VARIANTS(X) \
-  X(0, true, false, 0) X(1, false, false, -1) X(2, false, true, -1) X(3, true, false, 1) X(4, true, true, 0)
+  X(0, true, false, 0, false) X(1, false, false, -1, false) X(2, false, true, -1, false) X(3, true, false, 1, false) \
+  X(4, true, true, 0, false) X(5, true, false, 0, true)
 
 int histogram_blocks_per_cu(int variant) {
   int n = 0;
   hipError_t e = hipErrorInvalidValue;
   switch (variant) {
-#define X(ID, F, R, G) case ID: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, F, R, G>, 1024, 0); break;
+#define X(ID, F, R, G, PC) case ID: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, F, R, G, PC>, 1024, 0); break;
     SART_HIST_VARIANTS(X)
 #undef X
     default: break;
@@ -1446,7 +1455,7 @@ int histogram_blocks_per_cu(int variant) {
 void launch_trace_histogram(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
                             hipStream_t stream, int variant) {
   switch (variant) {
-#define X(ID, F, R, G) case ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB); break;
+#define X(ID, F, R, G, PC) case ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G, PC>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB); break;
     SART_HIST_VARIANTS(X)
 #undef X
     default: return;

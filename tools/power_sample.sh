@@ -1,13 +1,14 @@
 #!/bin/bash
-# Samples socket power and shader clock (rocm-smi) while the headline workload runs: bash tools/power_sample.sh [bench args]
+# Samples socket power, shader clock and junction temperature (rocm-smi) while the ray kernel runs:
+#   bash tools/power_sample.sh [power_run.py args]      (environment: SART_LIBSART / SART_DEBUG_FLAGS for ablated builds)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-python3 $ROOT/bench.py --profile-run --steps 500 --warmup 5 "$@" > /tmp/power_bench.json 2>/tmp/power_bench.err &
+python3 $ROOT/tools/power_run.py --seconds ${POWER_SECONDS:-14} "$@" > /tmp/power_run.txt 2>/tmp/power_run.err &
 PID=$!
-sleep 12
-for i in 1 2 3 4 5 6; do
-  rocm-smi --showpower --showclocks --showtemp 2>/dev/null | grep -E "Power|sclk|mclk|fclk|Temperature \(Sensor (junction|edge)" | tr -s ' ' | tr '\n' ';'
+sleep ${POWER_DELAY:-9}
+for i in $(seq 1 ${POWER_SAMPLES:-6}); do
+  rocm-smi --showpower --showclocks --showtemp 2>/dev/null | grep -E "Package Power|sclk|junction" | sed 's/.*: //' | tr '\n' ' '
   echo
-  sleep 0.7
+  sleep 1
 done
 wait $PID
-python3 -c "import json; d=json.load(open('/tmp/power_bench.json')); print('rays/s %.4g  ms_per_step %.3f' % (d['value'], d['ms_per_step']))"
+cat /tmp/power_run.txt; tail -2 /tmp/power_run.err
