@@ -250,6 +250,7 @@ def main():
                         "shell_selected_fraction": summ["N_SHELL_SELECTED"] / total_rays},
         }
         if world == 1 and not args.profile_run:
+            out["roofline"]["energy"] = energy_block(step, stream, float(rays_rank))
             out["cpu_baseline"] = cpu_baseline(full, int(args.cpu_sample), seed)
             if args.workload == "babyiaxo_xmm":
                 out["other_workloads"] = [other_workload_rate(w) for w in ("cast_llnl_gold", "babyiaxo_xmm_gas", "babyiaxo_xmm_rot")]
@@ -260,6 +261,53 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def energy_block(step, stream, rays_per_step: float, seconds: float = 5.0):
+    """The limiter the counters do not show: the kernel runs against the socket power cap, so its rate is
+    set by the energy a ray costs.  Outside the timed region the same steps run for `seconds` while rocm-smi is read a few
+    times from a side thread: socket power, shader clock, and the energy per ray they imply at the rate of that window.
+    Best effort: null fields if rocm-smi is not there or may not be read."""
+    import re
+    import subprocess
+    import threading
+    import torch
+    samples = []
+
+    def sampler():
+        time.sleep(1.5)
+        for _ in range(4):
+            try:
+                txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+                pw = re.search(r"Package Power \(W\): ([0-9.]+)", txt)
+                ck = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+                if pw and ck:
+                    samples.append((float(pw.group(1)), float(ck.group(1))))
+            except Exception:
+                pass
+            time.sleep(0.5)
+
+    th = threading.Thread(target=sampler)
+    th.start()
+    stream.synchronize()
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(8):
+            step(20_000 + k)
+            k += 1
+        stream.synchronize()
+    dt = time.perf_counter() - t0
+    th.join()
+    rate = k * rays_per_step / dt
+    blk = {"socket_power_w": None, "sclk_mhz": None, "nj_per_ray": None, "rays_per_s_sustained": rate, "seconds": dt,
+           "note": "rocm-smi beside %d untimed steps; idle socket power with the waves asleep is 336 W, the cap ~1190 W "
+                   "(tools/microbench/energy_rates.hip, profiles/)" % k}
+    if samples:
+        pw = sum(s[0] for s in samples) / len(samples)
+        blk.update({"socket_power_w": pw, "sclk_mhz": sum(s[1] for s in samples) / len(samples), "nj_per_ray": pw / rate * 1e9,
+                    "samples": len(samples)})
+    return blk
 
 
 def other_workload_rate(workload: str, n: int = 100_000_000, launches: int = 3):

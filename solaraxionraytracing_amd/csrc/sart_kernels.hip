@@ -80,6 +80,16 @@ __device__ __forceinline__ double scalar_const() {
 }
 #define SC(x) (scalar_const<__builtin_bit_cast(uint64_t, (double)(x))>())
 
+// One Horner step p x + C with the coefficient C as a scalar operand: v_fma_f64 v, v, v, s.  Left to itself LLVM selects the
+// two-address v_fmac_f64 for a single-use addend and copies the constant into the destination first (two v_mov_b32 per
+// step, also when the constant already sits in scalar registers).
+__device__ __forceinline__ double fma_vvs(double p, double x, double c_scalar) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "s"(c_scalar));
+  return r;
+}
+#define HORNER(p, x, c) fma_vvs((p), (x), SC(c))
+
 // Uniform in [0, 1) from two words (hi word first): 52 random mantissa bits under the exponent of 1.0,
 // minus 1.0 — the construction of Nim's std/random rand(1.0) (and of the oracle).
 __device__ __forceinline__ double u52(uint32_t hi, uint32_t lo) {
@@ -121,13 +131,13 @@ __device__ __forceinline__ void sincos_turns(double u, const double* __restrict_
 // truncation error < 1e-19 below 0.06; the library function outside.
 __device__ __forceinline__ double asin_small(double x, double x2) {   // x2 = x^2 (the caller has it)
   if (fabs(x) < 0.06) {
-    double p = SC(0.01396484375);               // 143/10240
-    p = fma(p, x2, SC(0.017352764423076924));   // 231/13312
-    p = fma(p, x2, SC(0.022372159090909092));   // 63/2816
-    p = fma(p, x2, SC(0.030381944444444444));   // 35/1152
-    p = fma(p, x2, SC(0.044642857142857144));   // 5/112
-    p = fma(p, x2, SC(0.075));                  // 3/40
-    p = fma(p, x2, SC(0.16666666666666666));    // 1/6
+    double p = 0.01396484375;                      // 143/10240
+    p = HORNER(p, x2, 0.017352764423076924);       // 231/13312
+    p = HORNER(p, x2, 0.022372159090909092);       // 63/2816
+    p = HORNER(p, x2, 0.030381944444444444);       // 35/1152
+    p = HORNER(p, x2, 0.044642857142857144);       // 5/112
+    p = HORNER(p, x2, 0.075);                      // 3/40
+    p = HORNER(p, x2, 0.16666666666666666);        // 1/6
     return fma(x * x2, p, x);
   }
   return asin(x);
@@ -174,12 +184,12 @@ __device__ __forceinline__ double cos_small(double x) {
 __device__ __forceinline__ double cos_yaw_of_slope(double t) {
   if (fabs(t) < 0.006) {
     const double x = t * t;
-    double p = SC(2976939695167.2104);           // t^12
-    p = fma(p, x, SC(-112889008417.68803));      // t^10
-    p = fma(p, x, SC(2979383355.295581));        // t^8
-    p = fma(p, x, SC(-49735946.89381117));       // t^6
-    p = fma(p, x, SC(450128.3326032301));        // t^4
-    p = fma(p, x, SC(-1641.403175005872));       // t^2 : -(180 / pi)^2 / 2
+    double p = 2976939695167.2104;                // t^12
+    p = HORNER(p, x, -112889008417.68803);        // t^10
+    p = HORNER(p, x, 2979383355.295581);          // t^8
+    p = HORNER(p, x, -49735946.89381117);         // t^6
+    p = HORNER(p, x, 450128.3326032301);          // t^4
+    p = HORNER(p, x, -1641.403175005872);         // t^2 : -(180 / pi)^2 / 2
     return fma(p, x, 1.0);
   }
   return cos_small(-atan_small(t) * 57.29577951308232);

@@ -806,3 +806,40 @@ def test_lds_image_tile_equals_global_atomics(shape, monkeypatch):
         img_d, s_d = rt.trace_image(n, nx, ny, seed=12)
     assert s_c["N_PASSED"] == s_d["N_PASSED"]
     np.testing.assert_allclose(img_d, img_c, rtol=1e-10, atol=max(img_c.max(), 1e-300) * 1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tables", ["small", "default"])
+def test_constant_path_variant_equals_the_carried_path(tables, monkeypatch):
+    """BabyIAXO-type setups (bore much wider than the pipes): no ray that survives the cuts behind the magnet entered
+    through the bore wall (sart_api.hip: path_is_constant), so kernel variant 5 drops the path column of ring 1 and keeps an
+    LDS image tile in its place while stage A0 runs.  Same rays through variant 0 (SART_NO_PATH_CONST) and through variant 5
+    with the tile off: identical counters, fluxes to 1e-12, images equal up to summation order; and the record path (which
+    carries the path of every ray) says the same about the rays: pathCB is not a record field, but transmissionMagnet =
+    cos(ya) conv_k pathCB^2 is, and it equals the constant-path value for every surviving ray."""
+    full = make_setup("babyiaxo_xmm") if tables == "small" else sa.initFullSetup()
+    n = 4_000_000
+    with sa.RayTracer(full) as rt:
+        img_a, s_a = rt.trace_histogram(n, seed=77)
+    monkeypatch.setenv("SART_NO_IMAGE_TILE", "1")
+    with sa.RayTracer(full) as rt:
+        img_t, s_t = rt.trace_histogram(n, seed=77)
+    monkeypatch.delenv("SART_NO_IMAGE_TILE")
+    monkeypatch.setenv("SART_NO_PATH_CONST", "1")
+    with sa.RayTracer(full) as rt:
+        img_b, s_b = rt.trace_histogram(n, seed=77)
+        rec = rt.traceAxionWrapper(200_000, seed=77)
+    for k in ("N_RAYS", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW", "N_PASSED", "N_OUTSIDE_IMAGE"):
+        assert s_a[k] == s_b[k] == s_t[k], k
+    assert s_a["N_PASSED"] > 0.2 * n
+    for k in ("SUM_WEIGHTS", "SUM_WEIGHTS_SQ", "SUM_X", "SUM_Y", "SUM_R"):
+        assert s_a[k] == pytest.approx(s_b[k], rel=1e-12) and s_t[k] == pytest.approx(s_b[k], rel=1e-12), k
+    scale = img_b.max()
+    np.testing.assert_allclose(img_a, img_b, rtol=1e-10, atol=scale * 1e-13)
+    np.testing.assert_allclose(img_t, img_b, rtol=1e-10, atol=scale * 1e-13)
+    assert img_a.sum() == pytest.approx(s_a["SUM_WEIGHTS"], rel=1e-11)
+    # records: transmissionMagnet / cos(yaw) = conv_k pathCB^2 with pathCB = lengthB sqrt(1 + slope^2) for every survivor
+    ok = rec["passedTillWindow"] != 0
+    assert ok.sum() > 10_000
+    tm = rec["transmissionMagnet"][ok] / np.cos(rec["yawAngles"][ok])
+    assert tm.max() / tm.min() < 1.0 + 1e-4          # (1 + slope^2) varies by < 3e-5; a wall entry would shorten the path by per cents
