@@ -509,7 +509,9 @@ HotA hot_of(const DevParams& P) {
   h.pipe1_radius_sq = P.pipe1_radius_sq;
   h.entrance_x = P.entrance_x; h.entrance_y = P.entrance_y;
   h.r1_last = P.r1_last; h.lut_inv_step = P.lut_inv_step;
-  h.spider_z = P.spider_z; h.spoke_cos_thr = P.spoke_cos_thr; h.inner_radius = P.inner_radius;
+  h.spider_z = P.spider_z; h.inner_radius = P.inner_radius;
+  // 16 spokes: the kernel compares the scaled Chebyshev value z = T16 / 32768 (sart_kernels.hip: spoke_measure)
+  h.spoke_cos_thr = (P.spoke_n == 16) ? P.spoke_cos_thr * (1.0 / 32768.0) : P.spoke_cos_thr;
   h.ring_lo = P.ring_lo; h.ring_hi = P.ring_hi;
   h.test_active = P.test_active; h.rotated = P.rotated; h.telescope_kind = P.telescope_kind; h.spoke_n = P.spoke_n;
   h.n_shells = P.n_shells; h.lut_n = P.lut_n; h.radius_span = P.radius_span; h.inner_blocks = P.inner_blocks;

@@ -130,7 +130,15 @@ __device__ __forceinline__ void sincos_turns(double u, const double* __restrict_
 // asin x = x + x^3/6 + 3x^5/40 + 5x^7/112 + 35x^9/1152 + 63x^11/2816 + 231x^13/13312 + 143x^15/10240,
 // truncation error < 1e-19 below 0.06; the library function outside.
 __device__ __forceinline__ double asin_small(double x, double x2) {   // x2 = x^2 (the caller has it)
+  if (fabs(x) < 0.02) {   // every grazing angle of the shipped optics (<= 1.0 deg): five terms, truncation 63/2816 x^10 < 3e-19
+    double p = 0.030381944444444444;               // 35/1152
+    p = HORNER(p, x2, 0.044642857142857144);       // 5/112
+    p = HORNER(p, x2, 0.075);                      // 3/40
+    p = HORNER(p, x2, 0.16666666666666666);        // 1/6
+    return fma(x * x2, p, x);
+  }
   if (fabs(x) < 0.06) {
+    asm volatile("; rare: grazing angle beyond 1.1 deg");
     double p = 0.01396484375;                      // 143/10240
     p = HORNER(p, x2, 0.017352764423076924);       // 231/13312
     p = HORNER(p, x2, 0.022372159090909092);       // 63/2816
@@ -385,13 +393,16 @@ __device__ __forceinline__ EnergyDev load_energy_row(const HotB& HB, int e_idx) 
                    gload<double>(HB.energy_tab, off + 48u), gload<double>(HB.energy_tab, off + 56u)};
 }
 
-// cos(n phi) from c = cos(phi): Chebyshev T16 (four doublings) or T6 = T2(T3).
-__device__ __forceinline__ double cos_n_phi(int n, double c) {
+// cos(n phi) from c = cos(phi) for the spoke test cos(n phi) >= cos(n w): Chebyshev T6 = T2(T3), or T16 by four doublings in
+// scaled form, one FMA each: with u = c^2 - 1/2, v = u^2 - 1/8, w = v^2 - 1/128, z = w^2 - 1/32768 the doublings give
+// T2 = 2u, T4 = 8v, T8 = 128w, T16 = 32768 z (powers of two: exact), so the function returns z and the host stores the
+// threshold divided by 32768 (sart_api.hip: hot_of).
+__device__ __forceinline__ double spoke_measure(int n, double c) {
   if (n == 16) {
-    double t = fma(2.0 * c, c, -1.0);
-    t = fma(2.0 * t, t, -1.0);
-    t = fma(2.0 * t, t, -1.0);
-    return fma(2.0 * t, t, -1.0);
+    const double u = fma(c, c, -0.5);
+    const double v = fma(u, u, -0.125);
+    const double w = fma(v, v, -0.0078125);
+    return fma(w, w, -1.0 / 32768.0);
   }
   const double t3 = c * fma(4.0 * c, c, -3.0);
   return fma(2.0 * t3, t3, -1.0);
@@ -575,7 +586,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
     const double c_ent = X0 * inv_radial;
     const double xs = fma(H.spider_z, tsx, X0), ys = fma(H.spider_z, tsy, Y0);
     const double c_sp = xs * frsq(fma(xs, xs, ys * ys));
-    const bool spoke = (cos_n_phi(H.spoke_n, c_ent) >= H.spoke_cos_thr) || (cos_n_phi(H.spoke_n, c_sp) >= H.spoke_cos_thr);
+    const bool spoke = (spoke_measure(H.spoke_n, c_ent) >= H.spoke_cos_thr) || (spoke_measure(H.spoke_n, c_sp) >= H.spoke_cos_thr);
     bool blocked = inner || ring || spoke;
     if (cfg_holes) {
       // hole loop (:1675-1688) with lineIntersectsObject (:494-527) on the entrance plane; replaces the
@@ -1216,7 +1227,10 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
           dead_m |= in;
           reached_m |= ((Z.zone_reached >> z) & 1u) ? in : 0ull;      // wave-uniform select
         }
-        const uint64_t valid_m = ballot64(rel >= rel_begin) & ballot64(rel < rel_end);
+        // all four ids of every lane lie inside the launch for every chunk but the first and the last (wave-uniform test)
+        const uint32_t chunk_lo = chunk << 8;
+        uint64_t valid_m = ~0ull;
+        if ((chunk_lo < rel_begin) | (chunk_lo + 256u > rel_end)) valid_m = ballot64(rel >= rel_begin) & ballot64(rel < rel_end);
         n_reached += (uint32_t)__popcll(valid_m & reached_m);
 #ifdef SART_DEBUG_KNOBS
         const uint64_t mask = (A.flags & 0x20000000u) ? 0ull : (valid_m & ~dead_m);   // experiment: nothing reaches stage A1
