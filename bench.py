@@ -264,10 +264,10 @@ def main():
 
 
 def energy_block(step, stream, rays_per_step: float, seconds: float = 5.0):
-    """The limiter the counters do not show: the kernel runs against the socket power cap, so its rate is
-    set by the energy a ray costs.  Outside the timed region the same steps run for `seconds` while rocm-smi is read a few
-    times from a side thread: socket power, shader clock, and the energy per ray they imply at the rate of that window.
-    Best effort: null fields if rocm-smi is not there or may not be read."""
+    """What the counters do not show: the clock the power manager grants this kernel (2.06 of 2.4 GHz at ~1185 W, DESIGN.md
+    3.3).  Outside the timed region the same steps run for `seconds` while rocm-smi is read a few times from a side
+    thread: socket power, shader clock, and the energy per ray they imply at the rate of that window.  Best effort: null
+    fields if rocm-smi is not there or may not be read."""
     import re
     import subprocess
     import threading
@@ -301,8 +301,8 @@ def energy_block(step, stream, rays_per_step: float, seconds: float = 5.0):
     th.join()
     rate = k * rays_per_step / dt
     blk = {"socket_power_w": None, "sclk_mhz": None, "nj_per_ray": None, "rays_per_s_sustained": rate, "seconds": dt,
-           "note": "rocm-smi beside %d untimed steps; idle socket power with the waves asleep is 336 W, the cap ~1190 W "
-                   "(tools/microbench/energy_rates.hip, profiles/)" % k}
+           "note": "rocm-smi beside %d untimed steps; for scale: the socket draws 336 W with all waves asleep and 970 W with "
+                   "v_fma_f64 alone on every SIMD at 2.4 GHz (tools/microbench/energy_rates.hip, DESIGN.md 3.3)" % k}
     if samples:
         pw = sum(s[0] for s in samples) / len(samples)
         blk.update({"socket_power_w": pw, "sclk_mhz": sum(s[1] for s in samples) / len(samples), "nj_per_ray": pw / rate * 1e9,

@@ -130,15 +130,7 @@ __device__ __forceinline__ void sincos_turns(double u, const double* __restrict_
 // asin x = x + x^3/6 + 3x^5/40 + 5x^7/112 + 35x^9/1152 + 63x^11/2816 + 231x^13/13312 + 143x^15/10240,
 // truncation error < 1e-19 below 0.06; the library function outside.
 __device__ __forceinline__ double asin_small(double x, double x2) {   // x2 = x^2 (the caller has it)
-  if (fabs(x) < 0.02) {   // every grazing angle of the shipped optics (<= 1.0 deg): five terms, truncation 63/2816 x^10 < 3e-19
-    double p = 0.030381944444444444;               // 35/1152
-    p = HORNER(p, x2, 0.044642857142857144);       // 5/112
-    p = HORNER(p, x2, 0.075);                      // 3/40
-    p = HORNER(p, x2, 0.16666666666666666);        // 1/6
-    return fma(x * x2, p, x);
-  }
   if (fabs(x) < 0.06) {
-    asm volatile("; rare: grazing angle beyond 1.1 deg");
     double p = 0.01396484375;                      // 143/10240
     p = HORNER(p, x2, 0.017352764423076924);       // 231/13312
     p = HORNER(p, x2, 0.022372159090909092);       // 63/2816
