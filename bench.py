@@ -310,15 +310,17 @@ def energy_block(step, stream, rays_per_step: float, seconds: float = 5.0):
     return blk
 
 
-def other_workload_rate(workload: str, n: int = 100_000_000, launches: int = 3):
-    """The other kernel variants / BASELINE configs beside the headline workload: `launches` 1e8-ray launches each,
-    HIP-event kernel time, own roofline block from that workload's committed PMC profile.  Informational; `value` is the
-    BabyIAXO workload."""
+def other_workload_rate(workload: str, n: int = 100_000_000, launches: int = 20):
+    """The other kernel variants / BASELINE configs beside the headline workload: `launches` 1e8-ray launches each (BASELINE
+    configs[1] is quoted at 1e8 rays) behind five untimed ones - the first launches after an idle gap run while the clock
+    is still ramping up -, HIP-event kernel time, own roofline block from that workload's committed PMC profile.
+    Informational; `value` is the BabyIAXO workload."""
     import solaraxionraytracing_amd as sa
     from solaraxionraytracing_amd import _lib as L
     full, flags = make_setup(workload)
     with sa.RayTracer(full) as rt:
-        rt.trace_histogram(n // 10, seed=1, flags=flags)
+        for k in range(5):
+            rt.trace_histogram(n, seed=2, ray_id_offset=k * n, flags=flags)
         rt.enable_kernel_timing(True)
         for k in range(launches):
             img, s = rt.trace_histogram(n, seed=1, ray_id_offset=k * n, accumulate=(k > 0), flags=flags)

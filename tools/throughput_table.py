@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
-"""Throughput of the histogram path for a set of configurations (GPU box).  Prints a markdown table."""
+"""Throughput of the histogram path for a set of configurations (GPU box): 20 launches of 1e8 rays behind 5 untimed ones.
+Prints a markdown table."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import solaraxionraytracing_amd as sa
 from solaraxionraytracing_amd import _lib as L
 
-def run(name, full, n=100_000_000, flags=None, reps=5):
+def run(name, full, n=100_000_000, flags=None, reps=20):
     with sa.RayTracer(full) as rt:
-        rt.trace_histogram(n // 10, seed=1, flags=flags)
+        for k in range(5):   # the first launches after an idle gap run while the clock is still ramping up
+            rt.trace_histogram(n, seed=2, ray_id_offset=k * n, flags=flags)
         rt.enable_kernel_timing(True)
         for k in range(reps):
             img, s = rt.trace_histogram(n, seed=1, ray_id_offset=k * n, flags=flags, accumulate=(k > 0))
