@@ -157,18 +157,28 @@ def check_image(host, n_img: int, summ: dict):
 
 def main():
     args = parse()
+    from solaraxionraytracing_amd import distributed as D
+
+    # `--gpus N` means N ranks whoever starts this script: under torchrun (WORLD_SIZE set) this process is one of them and
+    # WORLD_SIZE must equal N; stand-alone with N > 1 this process only starts N copies of itself (one rank each) and
+    # waits for them.  Either way a mismatch, or fewer devices than ranks, ends with exit code 2 BEFORE anything touches a
+    # GPU - a line whose n_gpus is not what was asked for is never printed.
+    # SART_BENCH_BACKEND=gloo + SART_BENCH_DEVICE=0: rehearsal of the multi-rank path on a one-GPU box.
+    rc = D.launch_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    if rc is not None:
+        raise SystemExit(rc)
+
     import torch
     import torch.distributed as dist
 
     import solaraxionraytracing_amd as sa
-    from solaraxionraytracing_amd import _lib as L, distributed as D
+    from solaraxionraytracing_amd import _lib as L
 
-    # SART_BENCH_BACKEND=gloo + SART_BENCH_DEVICE=0: rehearsal of the multi-rank path on a one-GPU box
     rank, world, local_rank = D.init_process_group_from_env(os.environ.get("SART_BENCH_BACKEND"))
+    assert world == args.gpus, (world, args.gpus)
+    backend = dist.get_backend() if world > 1 else "none"
     if "SART_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["SART_BENCH_DEVICE"])
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -209,13 +219,22 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+    stream.synchronize()                 # this rank's launches are done (the reduce would wait for them anyway)
+    t_red = time.perf_counter()
     D.reduce_accumulator(acc, dst=0)     # the single RCCL reduce of the output histograms
     barrier()
     t1 = time.perf_counter()
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    # MAX over ranks of the whole timed region; of the reduce (its wait for the slowest rank included) rank 0's figure
+    times = torch.tensor([t1 - t0, t_red - t0], dtype=torch.float64, device=dev)
+    rays_all = torch.zeros(world, dtype=torch.float64, device=dev)
+    rays_all[rank] = float(rays_rank)
     if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed_s = float(elapsed.item())
+        if backend != "nccl":
+            times, rays_all = times.cpu(), rays_all.cpu()
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
+    elapsed_s = float(times[0].item())
+    reduce_ms = (t1 - t_red) * 1e3
     kernel_ms, n_launch = rt.kernel_timing()
     rt.enable_kernel_timing(False)
 
@@ -233,6 +252,8 @@ def main():
             "value": value,
             "unit": "rays/s",
             "n_gpus": world,
+            "world_size": world,
+            "backend": backend,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed_s / args.steps * 1e3,
@@ -241,7 +262,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": wl_name, "rays_per_step_per_gpu": rays_rank, "total_rays": total_rays,
+            "reduce_ms": reduce_ms,
+            "slowest_rank_compute_ms_per_step": float(times[1].item()) / args.steps * 1e3,
+            "config": {"workload": wl_name, "rays_per_step_per_gpu": rays_rank,
+                       "rays_per_step_per_rank": [int(x) for x in rays_all.tolist()], "total_rays": total_rays,
                        "tables": full.meta, "sharding": "global ray id, 1 RCCL reduce of image+scalars",
                        "device": rt.device_info(), "knobs": active_knobs()},
             "roofline": roofline_block(args.workload, float(rays_rank), avg_kernel_s, n_launch, summ, total_rays),

@@ -10,6 +10,7 @@ any world size; results agree up to f64 summation order.
 from __future__ import annotations
 
 import os
+import sys
 from typing import Callable, Tuple
 
 import numpy as np
@@ -40,6 +41,104 @@ def shard_angles(n_angles: int, rank: int, world_size: int):
     """Angle bins of an angular scan owned by ``rank`` (round-robin, performAngularScan :2791-2800 is a
     loop over independent full runs)."""
     return list(range(rank, n_angles, world_size))
+
+
+MAX_RANKS_ON_ONE_DEVICE = 6   # rehearsal mode (all ranks on one card): the GPU boxes allow six processes per card
+
+
+class LaunchRefused(SystemExit):
+    """Raised (exit code 2) when the requested number of ranks cannot be honoured: nothing has touched a GPU yet."""
+
+    def __init__(self, msg: str):
+        print("refused: " + msg, file=sys.stderr)
+        super().__init__(2)
+
+
+def visible_devices() -> int:
+    """Number of HIP devices this process could use, WITHOUT initialising one (torch.cuda.device_count() only asks the
+    driver; torch.cuda.is_available() / any tensor on a device would create a context, after which spawning or re-executing
+    is no longer safe on the GPU boxes)."""
+    import torch
+    try:
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def check_world(n_ranks: int, backend: str | None, shared_device: int | None, n_devices: int | None = None) -> None:
+    """The rules a launch of ``n_ranks`` ranks must meet, checked before anything touches a GPU: one device per rank — or,
+    rehearsal mode, all ranks on ``shared_device`` with a backend that allows it (gloo; RCCL refuses two ranks on one
+    card) and at most MAX_RANKS_ON_ONE_DEVICE of them."""
+    n_dev = visible_devices() if n_devices is None else n_devices
+    if n_ranks < 1:
+        raise LaunchRefused("--gpus must be >= 1")
+    if shared_device is not None:
+        if shared_device < 0 or shared_device >= n_dev:
+            raise LaunchRefused("SART_BENCH_DEVICE=%d but %d device(s) are visible" % (shared_device, n_dev))
+        if n_ranks > 1 and backend != "gloo":
+            raise LaunchRefused("%d ranks on one device need SART_BENCH_BACKEND=gloo (RCCL wants one device per rank)" % n_ranks)
+        if n_ranks > MAX_RANKS_ON_ONE_DEVICE:
+            raise LaunchRefused("%d ranks on one device: at most %d processes may share a card" % (n_ranks, MAX_RANKS_ON_ONE_DEVICE))
+    elif n_ranks > n_dev:
+        raise LaunchRefused("--gpus %d but only %d device(s) are visible" % (n_ranks, n_dev))
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])
+
+
+def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
+    """Makes ``<script> --gpus N`` mean N ranks whoever starts it.
+
+    * Under a launcher (WORLD_SIZE set: torchrun, the driver's command line): this process is one rank; returns None after
+      checking that WORLD_SIZE == ``n_ranks`` and that enough devices exist (LaunchRefused = exit code 2 otherwise: a
+      benchmark line whose ``n_gpus`` is not what was asked for must not be printed).
+    * Stand-alone with ``n_ranks`` == 1: returns None (single process, no process group).
+    * Stand-alone with ``n_ranks`` > 1: starts ``n_ranks`` fresh copies of ``script`` (children of this process, one rank
+      each, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment) BEFORE any HIP call
+      here, waits for them and returns the exit code to leave with (rank 0's stdout is this process's stdout).  A rank that
+      fails ends the others (exact PIDs).
+
+    Environment: SART_BENCH_BACKEND (nccl = RCCL by default, gloo for rehearsals), SART_BENCH_DEVICE (all ranks share that
+    device: rehearsal of the multi-rank path on a one-GPU box)."""
+    import subprocess
+    import time
+
+    backend = os.environ.get("SART_BENCH_BACKEND") or "nccl"
+    shared = int(os.environ["SART_BENCH_DEVICE"]) if "SART_BENCH_DEVICE" in os.environ else None
+    if "WORLD_SIZE" in os.environ:
+        world = int(os.environ["WORLD_SIZE"])
+        if world != n_ranks:
+            raise LaunchRefused("--gpus %d but WORLD_SIZE=%d" % (n_ranks, world))
+        check_world(world, backend, shared)
+        return None
+    check_world(n_ranks, backend, shared)
+    if n_ranks == 1:
+        return None
+    port = free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SART_BENCH_BACKEND=backend)
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                for q in alive:          # a dead rank leaves the others waiting in a collective: end them
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def init_process_group_from_env(backend: str | None = None):

@@ -89,3 +89,81 @@ def test_two_rank_sharded_trace_equals_single_process(tmp_path):
     assert acc[n_img + _lib.ACC["SUM_WEIGHTS"]] == pytest.approx(summ["SUM_WEIGHTS"], rel=1e-12)
     np.testing.assert_allclose(acc[:n_img].reshape(img.shape), img, rtol=1e-12, atol=1e-30)
     np.testing.assert_array_equal(np.load(out + ".curve.npy"), 10.0 + np.arange(7))
+
+
+# ---- `--gpus N` launches N ranks by itself and refuses to lie (bench.py, tools/scan.py) -------------------------------
+
+_RANK_SCRIPT = '''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from solaraxionraytracing_amd import distributed as D
+r, w, lr = D.init_process_group_from_env("gloo")
+t = torch.tensor([float(r + 1)], dtype=torch.float64)
+dist.all_reduce(t)
+open(os.path.join(sys.argv[1], "rank%%d" %% r), "w").write("%%d %%d %%g" %% (r, w, t.item()))
+if r == 0:
+    print("hello from rank 0 of", w)
+dist.barrier()
+dist.destroy_process_group()
+if len(sys.argv) > 2 and int(sys.argv[2]) == r:
+    sys.exit(7)
+'''
+
+
+def test_launch_ranks_starts_n_fresh_processes(tmp_path, monkeypatch):
+    """Stand-alone `--gpus 3`: three children, one rank each, a working process group between them; the parent never
+    touches a device (here there is none: the device count is patched, the children use gloo on the CPU)."""
+    script = tmp_path / "rank_script.py"
+    script.write_text(_RANK_SCRIPT % ROOT)
+    monkeypatch.setattr(D, "visible_devices", lambda: 3)
+    monkeypatch.setenv("SART_BENCH_BACKEND", "gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SART_BENCH_DEVICE"):
+        monkeypatch.delenv(k, raising=False)
+    out = tmp_path / "ok"
+    out.mkdir()
+    assert D.launch_ranks_if_needed(3, str(script), [str(out)]) == 0
+    got = sorted((out / f).read_text() for f in os.listdir(out))
+    assert got == ["0 3 6", "1 3 6", "2 3 6"]
+    # a failing rank gives a non-zero exit code
+    out2 = tmp_path / "fail"
+    out2.mkdir()
+    assert D.launch_ranks_if_needed(2, str(script), [str(out2), "1"]) == 7
+    # one rank: nothing to start
+    assert D.launch_ranks_if_needed(1, str(script), [str(out)]) is None
+
+
+def test_launch_refuses_what_it_cannot_honour(monkeypatch):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SART_BENCH_DEVICE", "SART_BENCH_BACKEND"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(D, "visible_devices", lambda: 1)
+    with pytest.raises(SystemExit) as e:          # more ranks than devices
+        D.launch_ranks_if_needed(8, "unused.py", [])
+    assert e.value.code == 2
+    monkeypatch.setenv("WORLD_SIZE", "2")         # under a launcher: WORLD_SIZE must be what --gpus says
+    with pytest.raises(SystemExit) as e:
+        D.launch_ranks_if_needed(4, "unused.py", [])
+    assert e.value.code == 2
+    monkeypatch.delenv("WORLD_SIZE")
+    monkeypatch.setenv("SART_BENCH_DEVICE", "0")  # several ranks on one card: gloo only, at most six
+    with pytest.raises(SystemExit):
+        D.launch_ranks_if_needed(2, "unused.py", [])
+    monkeypatch.setenv("SART_BENCH_BACKEND", "gloo")
+    with pytest.raises(SystemExit):
+        D.launch_ranks_if_needed(8, "unused.py", [])
+    monkeypatch.setenv("SART_BENCH_DEVICE", "3")  # a device that does not exist
+    with pytest.raises(SystemExit):
+        D.launch_ranks_if_needed(2, "unused.py", [])
+
+
+@pytest.mark.parametrize("script", ["bench.py", os.path.join("tools", "scan.py")])
+def test_scripts_exit_nonzero_before_touching_a_gpu(script):
+    """`python bench.py --gpus 8` where eight devices are not visible (here: none) must not print a benchmark line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SART_BENCH_DEVICE")}
+    args = ["--gpus", "8"] if script == "bench.py" else ["mass", "--gpus", "8"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "refused" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr

@@ -304,6 +304,32 @@ def test_bench_two_rank_rehearsal(scaling):
     assert d["value"] > 1e9
 
 
+def test_bench_gpus_n_starts_its_own_ranks_and_refuses_to_lie():
+    """`python bench.py --gpus 2` WITHOUT torchrun: the script starts two ranks itself (gloo rehearsal on this one card) and
+    the line says n_gpus 2; `--gpus 8` on a one-GPU box exits non-zero without a line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env = dict(base, SART_BENCH_BACKEND="gloo", SART_BENCH_DEVICE="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--rays-per-step", "2e7", "--profile-run", "--scaling", "strong"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["world_size"] == 2 and d["backend"] == "gloo" and d["scaling"] == "strong"
+    assert d["config"]["rays_per_step_per_rank"] == [10_000_000, 10_000_000] and d["config"]["total_rays"] == 6e7
+    assert d["reduce_ms"] > 0 and d["results"]["passed_fraction"] == pytest.approx(0.2144, abs=2e-3)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], env=base,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "{" not in out.stdout and "refused" in out.stderr
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "{" not in out.stdout
+
+
 @pytest.mark.parametrize("variant", ["vacuum", "gas", "rotated"])
 def test_early_rejection_stage_is_exact(variant):
     """Stage A0 (rays classified from the bore-exit radius alone) must not change any counter or the image: same

@@ -11,6 +11,7 @@
 
 Examples
   python tools/scan.py angular --angularScanMin 0 --angularScanMax 0.3 --numAngularScanPoints 16 --rays 1e7
+  python tools/scan.py mass --gpus 8 --points 32 --rays 3e8          (starts its own 8 ranks; RCCL)
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/scan.py mass --points 32 --rays 3e8
 """
 import argparse
@@ -39,11 +40,20 @@ def main():
                     help="solar emission table; default: agss09 (all terms of readOpacityFile.nim on the AGSS09 model, made by the "
                          "emission kernel) for the mass scan = BASELINE configs[4], primakoff (E1) for the angular scan")
     ap.add_argument("--out", default="gpurun_out/scan.csv")
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="number of ranks (one per GPU).  Stand-alone: N > 1 starts N copies of this script, one rank each; "
+                         "under torchrun it must equal WORLD_SIZE (default: WORLD_SIZE, or 1)")
     args = ap.parse_args()
+
+    from solaraxionraytracing_amd import distributed as D
+    n_ranks = args.gpus if args.gpus is not None else int(os.environ.get("WORLD_SIZE", "1"))
+    rc = D.launch_ranks_if_needed(n_ranks, os.path.abspath(__file__), sys.argv[1:])   # exit code 2 on a mismatch, before any GPU call
+    if rc is not None:
+        raise SystemExit(rc)
 
     import torch
     import solaraxionraytracing_amd as sa
-    from solaraxionraytracing_amd import _lib as L, distributed as D, tables
+    from solaraxionraytracing_amd import _lib as L, tables
 
     rank, world, local_rank = D.init_process_group_from_env(os.environ.get("SART_BENCH_BACKEND"))
     if "SART_BENCH_DEVICE" in os.environ:
