@@ -15,12 +15,13 @@ by distributed.shard_range (BASELINE configs[4]: "1e10 rays across 8 MI355X" = -
 
 Roofline block: the kernel is bound by f64 VALU issue, not by HBM.  PMC counters cannot be read from
 inside this process, so the per-ray counter figures come from the committed separate-pass profile of the SAME build
-and workload (profiles/pmc_current.json -> profiles/r02_*_pmc_summary.json, made by tools/pmc_profile.sh +
-tools/pmc_summary.py) and are combined with the kernel duration measured live here with HIP events on the launch
-stream:
-    achieved  [TFLOP/s] = f64_flop_per_ray x rays per launch / avg kernel duration      (peak 78.6: f64 vector)
-    hbm.achieved [GB/s] = fabric_bytes_per_ray x rays per launch / avg kernel duration  (peak 8000)
-    valu_issue_utilisation = fraction of the SIMDs' cycles in which a VALU instruction issues (from the profile run)
+and workload (profiles/pmc_current.json -> profiles/r03_*_pmc_summary.json, made by tools/pmc_profile.sh +
+tools/pmc_summary.py, which store sart_build_id() of the profiled library) and are combined with the kernel duration
+measured live here with HIP events on the launch stream.  If the library being timed has another build id than the
+profile, every counter-derived field is null and the note says why.
+    achieved  [TFLOP/s]     = f64_flop_per_ray x rays per launch / avg kernel duration      (peak 78.6: f64 vector)
+    hbm_achieved_gbs [GB/s] = fabric_bytes_per_ray x rays per launch / avg kernel duration  (peak 8000); hbm_frac = / 8000
+    valu_issue_utilisation  = fraction of the SIMDs' cycles in which a VALU instruction issues (from the profile run)
 
 Prints one JSON line on rank 0.  --profile-run skips the CPU baseline and the side workloads (for use under rocprofv3).
 """
@@ -105,9 +106,26 @@ def load_pmc(workload: str):
         return None
 
 
-def roofline_block(workload: str, rays_per_launch: float, avg_kernel_s: float, n_launch: int, summ: dict, total_rays: float):
-    """Counter-derived roofline of the trace kernel (see the module docstring for the formulas)."""
+def pmc_for_this_build(workload: str):
+    """The committed counter profile of `workload` if it was collected on THE BUILD BEING TIMED (sart_build_id() of the
+    loaded libsart.so == the id tools/pmc_summary.py stored with the profile), else (None, why).  A profile of another
+    build says nothing about this one: its figures are not reported."""
+    from solaraxionraytracing_amd import _lib
     pmc = load_pmc(workload)
+    lib_id = _lib.build_id()
+    if pmc is None:
+        return None, "no committed PMC profile for this workload (profiles/pmc_current.json)", lib_id
+    if pmc.get("build_id") != lib_id:
+        return None, ("the committed PMC profile %s belongs to build %s, the library being timed is build %s: counter-derived "
+                      "fields are null until tools/pmc_profile.sh + tools/pmc_summary.py --publish are re-run on this build"
+                      % (pmc.get("source"), pmc.get("build_id"), lib_id)), lib_id
+    return pmc, None, lib_id
+
+
+def roofline_block(workload: str, rays_per_launch: float, avg_kernel_s: float, n_launch: int, summ: dict, total_rays: float):
+    """Counter-derived roofline of the trace kernel (see the module docstring for the formulas).  Flat scalars only (the
+    driver's parsed record keeps scalars): the f64 issue roofline in achieved / peak / frac, the memory side in hbm_*."""
+    pmc, why_not, lib_id = pmc_for_this_build(workload)
     frac_det = summ["N_PASSED_TILL_WINDOW"] / total_rays
     frac_mirror = summ["N_SHELL_SELECTED"] / total_rays - frac_det
     frac_killed = 1.0 - summ["N_SHELL_SELECTED"] / total_rays
@@ -115,29 +133,46 @@ def roofline_block(workload: str, rays_per_launch: float, avg_kernel_s: float, n
     blk = {"bound": "f64-valu-issue", "achieved": None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
            "traffic": None, "kernel": "trace_histogram_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": n_launch,
            "rays_per_launch": rays_per_launch,
+           "hbm_frac": None, "hbm_achieved_gbs": None, "hbm_peak_gbs": HBM_PEAK_GBS, "fabric_bytes_per_ray": None,
+           "achieved_active_lanes": None, "frac_active_lanes": None,
+           "valu_issue_utilisation": None, "valu_lane_utilisation": None, "valu_insts_per_64_rays": None, "f64_flop_per_ray": None,
+           "l2_hit_rate": None, "build_id": lib_id, "pmc_build_id": None, "pmc_source": None,
            "reference_formulation_bytes_per_ray": ref_bytes_per_ray,
-           "note": "achieved = measured f64 flop per ray (PMC: (2 FMA + MUL + ADD + TRANS) x 64 lanes / rays, "
-                   "profiles/pmc_current.json) x rays per launch / live HIP-event kernel duration; traffic = fabric bytes per "
-                   "launch (TCC_EA0 requests by size + WRITE_SIZE, Infinity-Cache hits included).  "
-                   "reference_formulation_bytes_per_ray is SURVEY 8(d)'s probe count of the reference's formulation; the "
-                   "redesigned path does not move those bytes, so it is informational only."}
+           "note": "bound: the kernel issues f64 vector instructions in valu_issue_utilisation of the SIMDs' cycles (the wall it is "
+                   "nearest to); frac = achieved / peak of the f64 vector pipe is low by construction (a third of the vector "
+                   "instructions are f64 arithmetic) and hbm_frac is the L2-miss traffic of random 4-32-byte gathers fetched as "
+                   "128-byte lines - neither is a wall by itself (DESIGN.md 3.3).  achieved = f64 flop per ray issued (PMC: (2 FMA + "
+                   "MUL + ADD + TRANS) x 64 lanes / rays) x rays per launch / live HIP-event kernel duration; *_active_lanes = the "
+                   "same x valu_lane_utilisation (lanes switched off by EXEC do no work); traffic = fabric bytes per launch "
+                   "(TCC_EA0 read requests by size + WRITE_SIZE, Infinity-Cache hits included: upper bound on HBM bytes); "
+                   "hbm_achieved_gbs = traffic / kernel duration.  Counter figures come from the committed separate-pass profile "
+                   "of the same build (pmc_build_id == build_id).  reference_formulation_bytes_per_ray is SURVEY 8(d)'s probe "
+                   "count of the reference's formulation; the redesigned path does not move those bytes: informational only."}
     if pmc is None:
-        blk["note"] += "  NO committed PMC profile for this workload: counter-derived fields are null."
+        blk["note"] = why_not + ".  " + blk["note"]
         return blk
     tflops = pmc["f64_flop_per_ray"] * rays_per_launch / avg_kernel_s / 1e12
     blk["achieved"] = tflops
     blk["frac"] = tflops / F64_VALU_PEAK_TFLOPS
+    lane_util = pmc.get("valu_lane_utilisation")
+    if lane_util is not None:
+        blk["achieved_active_lanes"] = tflops * lane_util
+        blk["frac_active_lanes"] = tflops * lane_util / F64_VALU_PEAK_TFLOPS
     blk["valu_issue_utilisation"] = pmc.get("valu_issue_utilisation")
+    blk["valu_lane_utilisation"] = lane_util
     blk["valu_insts_per_64_rays"] = pmc.get("valu_insts_per_64_rays")
     blk["f64_flop_per_ray"] = pmc["f64_flop_per_ray"]
+    blk["l2_hit_rate"] = pmc.get("l2_hit_rate")
     blk["pmc_source"] = pmc.get("source")
+    blk["pmc_build_id"] = pmc.get("build_id")
     if pmc.get("fabric_bytes_per_ray") is not None:
         traffic = pmc["fabric_bytes_per_ray"] * rays_per_launch
         gbs = traffic / avg_kernel_s / 1e9
         blk["traffic"] = traffic
-        blk["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                      "fabric_bytes_per_ray": pmc["fabric_bytes_per_ray"]}
-        assert blk["hbm"]["frac"] <= 1.0, blk["hbm"]
+        blk["fabric_bytes_per_ray"] = pmc["fabric_bytes_per_ray"]
+        blk["hbm_achieved_gbs"] = gbs
+        blk["hbm_frac"] = gbs / HBM_PEAK_GBS
+        assert blk["hbm_frac"] <= 1.0, blk
     assert blk["frac"] <= 1.0, blk
     assert blk["valu_issue_utilisation"] is None or blk["valu_issue_utilisation"] <= 1.0, blk
     return blk
@@ -274,7 +309,9 @@ def main():
                         "shell_selected_fraction": summ["N_SHELL_SELECTED"] / total_rays},
         }
         if world == 1 and not args.profile_run:
-            out["roofline"]["energy"] = energy_block(step, stream, float(rays_rank))
+            en = energy_block(step, stream, float(rays_rank))
+            out["roofline"].update({"socket_power_w": en["socket_power_w"], "sclk_mhz": en["sclk_mhz"], "nj_per_ray": en["nj_per_ray"]})
+            out["energy"] = en
             out["cpu_baseline"] = cpu_baseline(full, int(args.cpu_sample), seed)
             if args.workload == "babyiaxo_xmm":
                 out["other_workloads"] = [other_workload_rate(w) for w in ("cast_llnl_gold", "babyiaxo_xmm_gas", "babyiaxo_xmm_rot")]
@@ -378,8 +415,11 @@ def emission_table_rate(reps: int = 5):
     kernel_s = float(np.median(ms)) * 1e-3
     blk = {"bound": "f64-valu-issue", "achieved": None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
            "kernel": "emission_table_kernel", "avg_kernel_ms": kernel_s * 1e3, "cells_per_launch": cells}
-    pmc = load_pmc("emission_table")
-    if pmc is not None:
+    pmc, why_not, lib_id = pmc_for_this_build("emission_table")
+    blk["build_id"] = lib_id
+    if pmc is None:
+        blk["note"] = why_not
+    else:
         tf = pmc["f64_flop_per_ray"] * cells / kernel_s / 1e12          # "ray" = unit of the profiled launch = one cell
         blk.update({"achieved": tf, "frac": tf / F64_VALU_PEAK_TFLOPS, "f64_flop_per_cell": pmc["f64_flop_per_ray"],
                     "valu_issue_utilisation": pmc.get("valu_issue_utilisation"), "pmc_source": pmc.get("source")})

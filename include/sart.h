@@ -336,6 +336,14 @@ int sart_reduce_across_devices(sart_context* const* contexts, double* const* acc
 int sart_enable_kernel_timing(sart_context* ctx, int enable);
 int sart_get_kernel_timing(sart_context* ctx, double* total_ms, int64_t* n_launches);
 
+/*
+ * Identity of this build of the library: hash of the device sources, their headers and the compile flags
+ * (csrc/Makefile: BUILD_ID).  Hardware-counter profiles are collected in separate runs (rocprofv3 --pmc cannot run
+ * inside the timed process); tools/pmc_summary.py stores this id beside the figures it publishes and bench.py
+ * reports counter-derived numbers only when the id of the library it times is the same.  Static string.
+ */
+const char* sart_build_id(void);
+
 /* Device properties the bench reports (CU count etc.). Any pointer may be NULL. */
 int sart_device_info(sart_context* ctx, int32_t* n_cu, int32_t* wave_size,
                      char* name_buf, size_t name_buf_len);

@@ -104,6 +104,7 @@ proc sart_reduce_across_devices*(contexts: ptr ptr SartContext, accumulatorsDevi
                                  root: int32): cint {.importc, header: sartH.}
 proc sart_enable_kernel_timing*(ctx: ptr SartContext, enable: cint): cint {.importc, header: sartH.}
 proc sart_get_kernel_timing*(ctx: ptr SartContext, totalMs: ptr cdouble, nLaunches: ptr int64): cint {.importc, header: sartH.}
+proc sart_build_id*(): cstring {.importc, header: sartH.}
 proc sart_device_info*(ctx: ptr SartContext, nCu, waveSize: ptr int32, nameBuf: cstring, nameBufLen: csize_t): cint {.importc, header: sartH.}
 
 static:

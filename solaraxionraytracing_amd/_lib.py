@@ -168,6 +168,7 @@ SART_SYMBOLS = {
     "sart_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "sart_get_kernel_timing": (C.c_int, [C.c_void_p, _dp, _P(C.c_int64)]),
     "sart_device_info": (C.c_int, [C.c_void_p, _P(_i), _P(_i), C.c_char_p, C.c_size_t]),
+    "sart_build_id": (C.c_char_p, []),
     # include/sart_emission.h
     "sart_emission_default_params": (None, [_P(EmissionParams)]),
     "sart_emission_table": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _i, _dp, _P(EmissionParams), _dp, _dp]),
@@ -231,6 +232,11 @@ def load_host() -> C.CDLL:
             raise RuntimeError(f"{LIBSART_HOST_PATH} is missing: run __graft_entry__.build()")
         _host = _bind(C.CDLL(LIBSART_HOST_PATH), SART_HOST_SYMBOLS)
     return _host
+
+
+def build_id() -> str:
+    """sart_build_id(): hash of the device sources + compile flags the loaded libsart.so was built from."""
+    return load_sart().sart_build_id().decode()
 
 
 class SartError(RuntimeError):

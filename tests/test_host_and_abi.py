@@ -230,3 +230,32 @@ def test_solar_csv_reader_roundtrip(tmp_path):
                 f.write("%s,%s,%s\n" % (repr(float(r)), repr(float(e)), repr(float(em[i, j]))))
     r2, e2, em2 = tables.read_solar_model_csv(str(p))
     np.testing.assert_array_equal(r2, radii); np.testing.assert_array_equal(e2, energies); np.testing.assert_array_equal(em2, em)
+
+
+def test_build_id_names_the_sources_the_library_was_built_from():
+    """sart_build_id() = hash of the device sources + flags (csrc/Makefile: BUILD_ID).  bench.py reports counter-derived
+    roofline figures only when the committed PMC profile carries the same id."""
+    import subprocess
+    import sys
+    want = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "solaraxionraytracing_amd", "csrc"), "print-build-id"],
+                          capture_output=True, text=True, check=True).stdout.strip()
+    assert re.fullmatch(r"[0-9a-f]{12}-[0-9a-f]{6}", want)
+    assert L.build_id() == want, "libsart.so is older than the sources: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
+    sys.path.insert(0, ROOT)
+    import bench
+    pmc, why, lib_id = bench.pmc_for_this_build("babyiaxo_xmm")
+    assert lib_id == want
+    assert (pmc is not None and pmc["build_id"] == want) or (pmc is None and "build" in why)
+    blk = bench.roofline_block("babyiaxo_xmm", 1e9, 0.0153, 20, {"N_PASSED_TILL_WINDOW": 2.2e8, "N_SHELL_SELECTED": 3.3e8}, 1e9)
+    for k in ("hbm_frac", "hbm_achieved_gbs", "fabric_bytes_per_ray", "build_id", "pmc_build_id"):   # flat scalars
+        assert k in blk and not isinstance(blk[k], (dict, list))
+    if pmc is None:
+        assert blk["achieved"] is None and blk["frac"] is None and blk["hbm_frac"] is None and blk["traffic"] is None
+    # a profile published for another build is refused
+    stale = dict(bench.load_pmc("babyiaxo_xmm") or {}, build_id="000000000000-000000")
+    orig = bench.load_pmc
+    bench.load_pmc = lambda w: stale
+    try:
+        assert bench.pmc_for_this_build("babyiaxo_xmm")[0] is None
+    finally:
+        bench.load_pmc = orig

@@ -9,6 +9,8 @@ TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
+# the build the counters belong to (tools/pmc_summary.py stores it; bench.py compares it with the library it times)
+python3 -c "import sys; sys.path.insert(0, '$ROOT'); from solaraxionraytracing_amd import _lib; print(_lib.build_id())" > $OUT/build_id.txt
 cd /tmp && export TMPDIR=/tmp
 PASSES=(
  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY"

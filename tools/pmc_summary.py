@@ -9,7 +9,11 @@ for <workload> at it (bench.py reads pmc_current.json; it cannot collect PMC cou
 
 Derived figures and their formulas (all per launch of `rays` rays, counters are means over the profiled launches):
   valu_insts_per_64_rays  = SQ_INSTS_VALU * 64 / rays
-  f64_flop_per_ray        = (2 FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) * 64 lanes / rays      (wave instructions x 64 lanes)
+  f64_flop_per_ray        = (2 FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) * 64 lanes / rays      (wave instructions x 64 lanes:
+                            what the vector unit ISSUES; lanes switched off by EXEC are included)
+  f64_flop_per_ray_active_lanes = f64_flop_per_ray x valu_lane_utilisation   (SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU):
+                            the share of issued lanes that are enabled, taken over ALL vector instructions - the f64 ones
+                            are assumed to have the average)
   valu_issue_utilisation  = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES * waves_per_simd, waves_per_simd = SQ_WAVES / (4 n_cu)
                             (both counters are quad-cycles summed over waves; every wave lives for the whole launch);
                             cross-check / short-lived waves: 4 SQ_ACTIVE_INST_VALU / (4 n_cu x GRBM_GUI_ACTIVE / 8)
@@ -61,6 +65,8 @@ def derive(w, rays, n_cu):
         f64 = g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_TRANS_F64")
         out["f64_flop_per_ray"] = (2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_ADD_F64") +
                                    g("SQ_INSTS_VALU_TRANS_F64")) * 64.0 / rays
+        if "valu_lane_utilisation" in out:
+            out["f64_flop_per_ray_active_lanes"] = out["f64_flop_per_ray"] * out["valu_lane_utilisation"]
         if "SQ_INSTS_VALU" in w:
             out["f64_share_of_valu_insts"] = f64 / g("SQ_INSTS_VALU")
             out["int_share_of_valu_insts"] = (g("SQ_INSTS_VALU_INT32") + g("SQ_INSTS_VALU_INT64")) / g("SQ_INSTS_VALU")
@@ -86,6 +92,19 @@ def derive(w, rays, n_cu):
     return out
 
 
+def library_build_id(profile_dir):
+    """The build the counters were collected on: tools/pmc_profile.sh writes sart_build_id() of the library it profiled to
+    <dir>/build_id.txt on the GPU box; without that file, the libsart.so of this tree (loading it needs no GPU)."""
+    try:
+        return open(os.path.join(profile_dir, "build_id.txt")).read().strip()
+    except OSError:
+        pass
+    import sys
+    sys.path.insert(0, ROOT)
+    from solaraxionraytracing_amd import _lib
+    return _lib.build_id()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("dir")
@@ -102,7 +121,8 @@ def main():
     print("--- derived")
     for k, v in der.items():
         print("%-48s %.6g" % (k, v))
-    out = {"workload": args.workload, "kernel": args.kernel, "rays_per_launch": args.rays, "n_cu": args.n_cu,
+    build = library_build_id(args.dir)
+    out = {"workload": args.workload, "kernel": args.kernel, "rays_per_launch": args.rays, "n_cu": args.n_cu, "build_id": build,
            "derived": der, "counters": res,
            "how": "rocprofv3 --pmc in separate passes (tools/pmc_profile.sh), mean over the profiled launches; formulas in "
                   "tools/pmc_summary.py"}
@@ -115,7 +135,7 @@ def main():
             cur = json.load(open(cur_path))
         except Exception:
             cur = {}
-        cur[args.workload] = {"source": "profiles/" + name, "rays_per_launch": args.rays, **der}
+        cur[args.workload] = {"source": "profiles/" + name, "rays_per_launch": args.rays, "build_id": build, **der}
         json.dump(cur, open(cur_path, "w"), indent=1)
         print("published profiles/%s" % name)
 
