@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--workload", default="babyiaxo_xmm", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=float, default=6e8, help="rays of the CPU-baseline sample")
+    ap.add_argument("--accumulation", default="f64", choices=["f64", "fixed64"],
+                    help="f64 (default): f64 atomics, as the reference adds on the CPU; fixed64: deterministic integer accumulation "
+                         "(SART_ACCUM_FIXED64), int64 reduce - image and sums bitwise independent of the number of GPUs")
     ap.add_argument("--profile-run", action="store_true", help="no CPU baseline / side workloads (run under rocprofv3)")
     return ap.parse_args()
 
@@ -229,7 +232,9 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     rt.set_stream(stream.cuda_stream)
-    acc = torch.zeros(sa.accumulator_len(256), dtype=torch.float64, device=dev)
+    fixed64 = args.accumulation == "fixed64"
+    rt.set_accumulation_mode(args.accumulation)
+    acc = torch.zeros(sa.accumulator_len(256), dtype=torch.float64, device=dev)   # 8-byte slots: doubles, or int64 in fixed64 mode
     seed = 299792458
 
     def step(k: int):
@@ -246,7 +251,7 @@ def main():
     for k in range(args.warmup):
         step(10_000 + k)   # ray ids outside the timed range
     if world > 1:  # warm the communicator
-        D.reduce_accumulator(acc.clone(), dst=0)
+        D.reduce_accumulator(acc.clone(), dst=0, fixed64=fixed64)
     barrier()
     acc.zero_()
     rt.enable_kernel_timing(True)
@@ -256,7 +261,9 @@ def main():
         step(k)
     stream.synchronize()                 # this rank's launches are done (the reduce would wait for them anyway)
     t_red = time.perf_counter()
-    D.reduce_accumulator(acc, dst=0)     # the single RCCL reduce of the output histograms
+    D.reduce_accumulator(acc, dst=0, fixed64=fixed64)     # the single RCCL reduce of the output histograms
+    if fixed64 and rank == 0:            # raw integer accumulator -> doubles, in place (part of the timed region)
+        rt.finalize_accumulator_device(rt.trace_params(1), acc.data_ptr())
     barrier()
     t1 = time.perf_counter()
     # MAX over ranks of the whole timed region; of the reduce (its wait for the slowest rank included) rank 0's figure
@@ -296,6 +303,7 @@ def main():
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
+            "accumulation": args.accumulation,
             "data": "synthetic",
             "reduce_ms": reduce_ms,
             "slowest_rank_compute_ms_per_step": float(times[1].item()) / args.steps * 1e3,
@@ -316,6 +324,7 @@ def main():
             if args.workload == "babyiaxo_xmm":
                 out["other_workloads"] = [other_workload_rate(w) for w in ("cast_llnl_gold", "babyiaxo_xmm_gas", "babyiaxo_xmm_rot")]
                 out["other_workloads"].append(emission_table_rate())
+                out["deterministic_accumulation"] = fixed64_block(full, value)
                 out["effective_area_rms"] = effective_area_rms()
         print(json.dumps(out))
     rt.close()
@@ -394,6 +403,44 @@ def other_workload_rate(workload: str, n: int = 100_000_000, launches: int = 20)
     avg_s = ms / 1e3 / n_launch
     return {"workload": WORKLOADS[workload], "rays_per_s": n / avg_s, "ms_per_launch": ms / n_launch,
             "passed_fraction": s["N_PASSED"] / s["N_RAYS"], "roofline": roofline_block(workload, float(n), avg_s, n_launch, s, total)}
+
+
+def fixed64_block(full, f64_rate: float, n: int = 1_000_000_000, launches: int = 10):
+    """The deterministic accumulation mode (SART_ACCUM_FIXED64: integer atomics, int64 reduce) on the headline workload:
+    its rate beside the f64 rate of the line, the distance between the two images, and a bitwise check (the same rays as
+    one launch and as three launches into another replica layout)."""
+    import numpy as np
+    import solaraxionraytracing_amd as sa
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode("fixed64")
+        for k in range(3):
+            rt.trace_histogram(n, seed=2, ray_id_offset=k * n)
+        rt.enable_kernel_timing(True)
+        for k in range(launches):
+            img, s = rt.trace_histogram(n, seed=1, ray_id_offset=k * n, accumulate=(k > 0))
+        ms, n_launch = rt.kernel_timing()
+        rt.enable_kernel_timing(False)
+        m = 100_000_000
+        img_a, s_a = rt.trace_histogram(m, seed=3)
+        q = rt.fixed_quanta()
+        rt.set_accumulation_mode("f64")
+        img_f, s_f = rt.trace_histogram(m, seed=3)
+    os.environ["SART_IMAGE_REPLICAS"] = "32"
+    try:
+        with sa.RayTracer(full) as rt:
+            rt.set_accumulation_mode("fixed64")
+            for k, (lo, hi) in enumerate(((0, 1), (1, 33_333_334), (33_333_334, m))):
+                img_b, s_b = rt.trace_histogram(hi - lo, seed=3, ray_id_offset=lo, accumulate=(k > 0))
+    finally:
+        del os.environ["SART_IMAGE_REPLICAS"]
+    assert s["N_RAYS"] == float(n) * launches and abs(img.sum() - s["SUM_WEIGHTS"]) <= 1e-12 * s["SUM_WEIGHTS"]
+    rate = n * n_launch / (ms / 1e3)
+    return {"mode": "SART_ACCUM_FIXED64", "rays_per_s": rate, "ms_per_launch": ms / n_launch, "rays_per_launch": n,
+            "vs_f64_rate": rate / f64_rate, "weight_quantum": q["weight"],
+            "bitwise_equal_across_launch_split_and_replicas": bool(np.array_equal(img_a.view(np.uint64), img_b.view(np.uint64)) and
+                                                                   s_a["SUM_WEIGHTS"] == s_b["SUM_WEIGHTS"]),
+            "max_abs_diff_to_f64_image_over_peak": float(np.abs(img_a - img_f).max() / img_f.max()),
+            "rel_diff_sum_weights_to_f64": float(abs(s_a["SUM_WEIGHTS"] / s_f["SUM_WEIGHTS"] - 1.0))}
 
 
 def emission_table_rate(reps: int = 5):

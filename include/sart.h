@@ -230,6 +230,12 @@ enum {
   SART_ACC_N_REACHED_TELESCOPE = 9, /* survived bore + pipes (:1813-1868)                 */
   SART_ACC_N_SHELL_SELECTED = 10,   /* survived opaque structures + shell selection (:1910-1957) */
   SART_ACC_N_OUTSIDE_IMAGE = 11,    /* passed rays whose (x,y) fall outside the image range */
+  /* SART_ACCUM_FIXED64 only (raw accumulators; 0 in every f64 accumulator): high limbs of the four sums that every
+   * passed ray adds to, in units of 2^40 quanta - see "accumulation mode" below */
+  SART_ACC_SUM_WEIGHTS_HI = 12,
+  SART_ACC_SUM_X_HI = 13,
+  SART_ACC_SUM_Y_HI = 14,
+  SART_ACC_SUM_R_HI = 15,
   SART_ACC_COUNT = 16
 };
 
@@ -315,10 +321,61 @@ int sart_trace_histogram(sart_context* ctx, const sart_trace_params_t* params,
 int sart_trace_histogram_spectra(sart_context* ctx, const sart_trace_params_t* params, double* image_out_host,
                                  sart_summary_t* summary_out, double* spectra_out_host);
 
+/* ---- accumulation mode -------------------------------------------------- */
+/*
+ * SART_ACCUM_F64 (default): the accumulator holds IEEE doubles and the kernel adds with f64 atomics, as prepareHeatmap
+ * does on the CPU (raytracer.nim:838-842).  Counters are exact; sums depend on the order in which the hardware retires
+ * the atomics (relative differences ~1e-13 between two runs, GPU counts, replica counts or launch splittings).
+ *
+ * SART_ACCUM_FIXED64: deterministic accumulation.  Every 8-byte slot of the accumulator is a two's-complement int64:
+ * counters count, every sum is held in integer multiples of a power-of-two quantum fixed per context, and each ray adds
+ * rint(value / quantum) with integer atomics - integer addition is associative, so the result is BITWISE independent of
+ * the number of GPUs, of the replica / LDS-tile placement and of how the rays are split over launches.  A multi-GPU
+ * reduce is an int64 sum of the raw buffers (ncclInt64 / torch.int64 view; sart_reduce_across_devices does this by
+ * itself); sart_finalize_accumulator_device converts a raw buffer to the f64 layout documented above.
+ *   quanta   weights (image pixels, SUM_WEIGHTS, radial / energy weight spectra): q_w = 2^e with
+ *            w_bound < 2^(e + 63 - headroom_bits), w_bound = the host-side upper bound of one ray's weight for the setup,
+ *            tables and flags of the launch that fixes the quantum (exposure x conversion probability x max reflectivity^2
+ *            x max window transmission x max gas absorption).  headroom_bits (default 30) = log2 of the number of
+ *            maximal-weight rays a slot can take before it wraps: a pixel holds >= 2^30 of them; the resolution of one
+ *            ray's weight is 2^-33 w_bound, the image as a whole agrees with the f64 image to ~1e-13 relative to its
+ *            largest pixel.  SUM_WEIGHTS_SQ: q = w_bound^2 2^-19 (a 44-bit ray count).  SUM_X / SUM_Y / SUM_R: 2^-32 mm.
+ *            energy_reflect spectrum: 2^-40.
+ *   limbs    SUM_WEIGHTS, SUM_X, SUM_Y, SUM_R receive every passed ray of every launch: value = (hi * 2^40 + lo) * q with
+ *            lo in slot SART_ACC_SUM_*, hi in slot SART_ACC_SUM_*_HI (after a launch 0 <= lo < 2^40; limb-wise int64 sums
+ *            over up to 2^22 ranks stay exact).
+ *   freezing the quanta are computed by the first histogram launch after sart_set_accumulation_mode (or by any launch with
+ *            accumulate == 0) and kept for the following accumulate == 1 launches of the context, so that launches that add
+ *            into one accumulator share them; a launch whose weight bound no longer fits fails with
+ *            SART_ERR_INVALID_ARGUMENT.  Contexts with equal inputs compute equal quanta (ranks of a multi-GPU job).
+ * The mode applies to sart_trace_histogram_device (raw accumulators) and to the blocking host-output calls, which
+ * finalize internally and keep returning doubles.
+ */
+enum { SART_ACCUM_F64 = 0, SART_ACCUM_FIXED64 = 1 };
+typedef struct sart_fixed_quanta_t {
+  double weight;        /* q_w: pixels, SUM_WEIGHTS (both limbs), radial_weights, energy_weights */
+  double weight_sq;     /* SUM_WEIGHTS_SQ */
+  double position;      /* SUM_X, SUM_Y, SUM_R (2^-32 mm) */
+  double reflect;       /* energy_reflect (2^-40) */
+} sart_fixed_quanta_t;
+/* headroom_bits: 0 = default (30); otherwise 16 .. 44.  Waits for the stream; resets the frozen quanta. */
+int sart_set_accumulation_mode(sart_context* ctx, int mode, int headroom_bits);
+int sart_get_accumulation_mode(sart_context* ctx, int* mode_out);
+/* The frozen quanta (SART_ERR_NOT_READY before the first FIXED64 launch). */
+int sart_get_fixed_quanta(sart_context* ctx, sart_fixed_quanta_t* out);
+/*
+ * Raw FIXED64 accumulator -> the f64 accumulator layout (image, scalars [the *_HI slots read 0], spectra if
+ * params->spectra), with the context's frozen quanta.  Both pointers are DEVICE memory of the accumulator's length;
+ * out_f64_device may equal acc_fixed_device (in place).  Asynchronous on the context's stream.
+ */
+int sart_finalize_accumulator_device(sart_context* ctx, const sart_trace_params_t* params, const void* acc_fixed_device,
+                                     double* out_f64_device);
+
 /* ---- multi-GPU ---------------------------------------------------------- */
 /*
  * Sum the fused accumulators of n contexts (one per GPU of this process) into the one of contexts[root]:
- * a single RCCL ncclReduce(ncclSum, f64) of n_doubles elements over xGMI (grouped over the devices).
+ * a single RCCL ncclReduce(ncclSum) of n_doubles 8-byte elements over xGMI (grouped over the devices): f64 elements, or
+ * int64 when the contexts are in SART_ACCUM_FIXED64 mode (all of them must be in the same mode).
  * accumulators_device[i] must live on the device of contexts[i].  Blocking.  n == 1 is a no-op.
  * A host that runs one process per GPU (e.g. under MPI / torchrun) reduces with its own communicator instead
  * (bench.py: torch.distributed, backend "nccl" = RCCL).  Returns SART_ERR_UNSUPPORTED if librccl cannot be loaded.

@@ -62,6 +62,14 @@ type
   SartSummary* {.importc: "sart_summary_t", header: sartH, bycopy.} = object
     v*: array[SartAccCount, cdouble]
 
+  ## sart_fixed_quanta_t: what one count of a raw SART_ACCUM_FIXED64 accumulator is worth
+  SartFixedQuanta* {.importc: "sart_fixed_quanta_t", header: sartH, bycopy.} = object
+    weight*, weight_sq*, position*, reflect*: cdouble
+
+const   # accumulation modes (include/sart.h)
+  AccumF64* = 0
+  AccumFixed64* = 1
+
 const   # SART_ACC_* (include/sart.h)
   AccSumWeights* = 0
   AccNPassed* = 1
@@ -75,6 +83,10 @@ const   # SART_ACC_* (include/sart.h)
   AccNReachedTelescope* = 9
   AccNShellSelected* = 10
   AccNOutsideImage* = 11
+  AccSumWeightsHi* = 12    # raw FIXED64 accumulators only: high limbs (units of 2^40 quanta)
+  AccSumXHi* = 13
+  AccSumYHi* = 14
+  AccSumRHi* = 15
 
 # ---- entry points (include/sart.h, in its order) ----------------------------------------------------------------------
 proc sart_abi_version*(): cint {.importc, header: sartH.}
@@ -100,6 +112,11 @@ proc sart_trace_histogram_device*(ctx: ptr SartContext, p: ptr SartTraceParams, 
 proc sart_trace_histogram*(ctx: ptr SartContext, p: ptr SartTraceParams, imageOutHost: ptr cdouble, summary: ptr SartSummary): cint {.importc, header: sartH.}
 proc sart_trace_histogram_spectra*(ctx: ptr SartContext, p: ptr SartTraceParams, imageOutHost: ptr cdouble, summary: ptr SartSummary,
                                    spectraOutHost: ptr cdouble): cint {.importc, header: sartH.}
+proc sart_set_accumulation_mode*(ctx: ptr SartContext, mode, headroomBits: cint): cint {.importc, header: sartH.}
+proc sart_get_accumulation_mode*(ctx: ptr SartContext, modeOut: ptr cint): cint {.importc, header: sartH.}
+proc sart_get_fixed_quanta*(ctx: ptr SartContext, quanta: ptr SartFixedQuanta): cint {.importc, header: sartH.}
+proc sart_finalize_accumulator_device*(ctx: ptr SartContext, p: ptr SartTraceParams, accFixedDevice: pointer,
+                                       outF64Device: ptr cdouble): cint {.importc, header: sartH.}
 proc sart_reduce_across_devices*(contexts: ptr ptr SartContext, accumulatorsDevice: ptr ptr cdouble, n: int32, nDoubles: csize_t,
                                  root: int32): cint {.importc, header: sartH.}
 proc sart_enable_kernel_timing*(ctx: ptr SartContext, enable: cint): cint {.importc, header: sartH.}

@@ -32,6 +32,10 @@ CF_XRAY_TEST = 1 << 4
 CF_READ_MAGNET_CONFIG = 1 << 5
 CF_READ_DET_INSTALL_CONFIG = 1 << 6
 
+ACCUM_F64, ACCUM_FIXED64 = 0, 1
+ACC_HI = dict(SUM_WEIGHTS=12, SUM_X=13, SUM_Y=14, SUM_R=15)   # SART_ACC_SUM_*_HI: high limbs of the raw FIXED64 accumulator
+FIXED_LIMB_BITS = 40
+
 ACC = dict(SUM_WEIGHTS=0, N_PASSED=1, N_PASSED_TILL_WINDOW=2, N_HIT_NICKEL=3, SUM_X=4, SUM_Y=5, SUM_R=6,
            SUM_WEIGHTS_SQ=7, N_RAYS=8, N_REACHED_TELESCOPE=9, N_SHELL_SELECTED=10, N_OUTSIDE_IMAGE=11)
 
@@ -114,6 +118,11 @@ class Summary(C.Structure):
     _fields_ = [("v", _d * SART_ACC_COUNT)]
 
 
+class FixedQuanta(C.Structure):
+    """sart_fixed_quanta_t"""
+    _fields_ = [("weight", _d), ("weight_sq", _d), ("position", _d), ("reflect", _d)]
+
+
 class MagnetConfig(C.Structure):
     _fields_ = [(n, _d) for n in ("B", "radiusCB", "lengthColdbore", "lengthB", "pGasRoom", "tGas")]
 
@@ -164,6 +173,10 @@ SART_SYMBOLS = {
     "sart_trace_histogram_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p]),
     "sart_trace_histogram": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _P(Summary)]),
     "sart_trace_histogram_spectra": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _P(Summary), _dp]),
+    "sart_set_accumulation_mode": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "sart_get_accumulation_mode": (C.c_int, [C.c_void_p, _P(C.c_int)]),
+    "sart_get_fixed_quanta": (C.c_int, [C.c_void_p, _P(FixedQuanta)]),
+    "sart_finalize_accumulator_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p, C.c_void_p]),
     "sart_reduce_across_devices": (C.c_int, [_P(C.c_void_p), _P(C.c_void_p), _i, C.c_size_t, _i]),
     "sart_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "sart_get_kernel_timing": (C.c_int, [C.c_void_p, _dp, _P(C.c_int64)]),

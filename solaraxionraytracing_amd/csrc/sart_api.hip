@@ -21,7 +21,9 @@
 
 namespace sart {
 void launch_trace_histogram(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
-                            hipStream_t stream, int variant);
+                            hipStream_t stream, int variant, bool fixed);
+void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectra, int n_radial_bins, int n_energies1, double q_w,
+                           double q_w2, double q_pos, double q_refl, hipStream_t stream);
 int histogram_block_of(int variant);
 void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream);
@@ -174,6 +176,7 @@ struct sart_context {
   DevBuf<double> d_replicas;   // kImageReplicas scratch images (kept zeroed between launches)
   DevBuf<double> d_partials;   // per-workgroup partial sums of the scalars
   DevBuf<double> d_acc;        // scratch accumulator of the blocking convenience call
+  bool d_acc_stale = false;    // its contents belong to another accumulation mode: the next call starts from zero
   DevBuf<sart_axion_t> d_rec;  // scratch records of the blocking convenience call
   bool derived_dirty = true;
   // LDS image tile (sart_device.h: TraceArgs::tile_*): centre of the focal spot in image pixels, found by a pilot launch
@@ -185,6 +188,17 @@ struct sart_context {
     int32_t x0 = 0, y0 = 0, n = 0;
   } tile;
   DevBuf<double> d_pilot;
+  DevBuf<double> d_pilot_replicas;   // the pilot's own scratch images: the caller's replica buffer keeps its layout
+
+  // accumulation mode (include/sart.h): SART_ACCUM_FIXED64 adds integers; the quanta are frozen by the first launch
+  int accum_mode = SART_ACCUM_F64;
+  int headroom_bits = 30;
+  bool quanta_frozen = false;
+  int weight_exp = 0;                // q_w = 2^weight_exp
+  int weight_sq_exp = 0;             // q_w2 = 2^weight_sq_exp
+  double weight_bound = 0.0;         // the bound the frozen quantum was derived from
+  std::vector<double> etab_max;      // max t_window / t_strongback / a_gas over the energy table, max reflectivity (hoist_*)
+  DevBuf<double> d_fin;              // f64 image of d_acc for the blocking host-output calls in FIXED64 mode
 
   // timing
   bool timing = false;
@@ -403,6 +417,13 @@ int hoist_energy_tables(sart_context* c) {
     e.mu_pipe = massAtt * density(pGas, s.room_temp) * 100;                // :109-113
     e.mu_magnet = massAtt * density(pGas, s.magnet_tGas) * 100;
   }
+  // bounds for the FIXED64 weight quantum: the solar source draws indices < nE, the X-ray test source uses row nE
+  c->etab_max.assign(4, 0.0);
+  for (const EnergyDev& e : tab) {
+    c->etab_max[0] = std::max(c->etab_max[0], std::fabs(e.t_window));
+    c->etab_max[1] = std::max(c->etab_max[1], std::fabs(e.t_strongback));
+    c->etab_max[2] = std::max(c->etab_max[2], std::fabs(e.a_gas));
+  }
   return c->d_etab.upload(tab.data(), tab.size());
 }
 
@@ -431,6 +452,11 @@ int hoist_reflectivity(sart_context* c) {
         g[i] = f0 + (f1 - f0) * yUnit;
       }
     }
+  }
+  {
+    double m = 0.0;   // |R| <= max |g| for every angle inside the grid (the kernel clamps the cell; outside it extrapolates
+    for (double v : out) m = std::max(m, std::fabs(v));   // from the edge cell: factor 2 of slack in weight_bound_of)
+    c->etab_max[3] = m;
   }
   return c->d_refl.upload(out.data(), out.size());
 }
@@ -628,6 +654,43 @@ DevTables tables_of(sart_context* c) {
   t.energy_tab = c->d_etab.p;
   t.refl = c->d_refl.p;
   return t;
+}
+
+// Upper bound of one ray's weight for the current setup, tables and flags (phase_b of sart_kernels.hip: reflectivity^2 x
+// cos(yaw) x conversion probability x absorption x window x gas x exposure): the SART_ACCUM_FIXED64 weight quantum is derived
+// from it.  Every factor is bounded generously (the conversion of a weight to quanta is exact up to 2^18 times the bound).
+double weight_bound_of(const sart_context* c, uint32_t flags) {
+  const DevParams& P = c->params;
+  double b = 1.0;
+  if (!(flags & SART_CF_IGNORE_REFLECTION)) { const double r = 2.0 * c->etab_max[3]; b *= r * r; }
+  if (!(flags & SART_CF_IGNORE_CONV_PROB)) {
+    // vacuum: conv_k pathCB^2, pathCB <= lengthB sqrt(1 + slope^2) (:363-365); gas: |integral of exp((iq - Gamma/2) z)|^2 <=
+    // L^2 in natural units (axionMassforMagnet.nim:75-98).  (1 + slope^2) <= 2.
+    const double l_nat = P.length_b * P.gas_inv_hbarc_m;
+    b *= 2.0 * (P.stage_gas ? P.gas_term1 * l_nat * l_nat : P.conv_k * P.length_b * P.length_b);
+  }
+  if (!(flags & SART_CF_IGNORE_DET_WINDOW)) b *= std::max(c->etab_max[0], c->etab_max[1]);
+  if (!(flags & SART_CF_IGNORE_GAS_ABS)) b *= c->etab_max[2];
+  if (!(flags & SART_CF_XRAY_TEST)) b *= P.exposure;
+  return b;
+}
+
+// Freezes the FIXED64 quanta from the bound `b` (or checks that `b` still fits the frozen ones).
+int freeze_quanta(sart_context* c, double b, bool refreeze) {
+  if (!std::isfinite(b) || b < 0.0) return fail(SART_ERR_INVALID_ARGUMENT, "FIXED64: the weight bound of this setup is not finite");
+  int e = 0;
+  if (b > 0.0) (void)std::frexp(b, &e);   // b < 2^e
+  if (c->quanta_frozen && !refreeze) {
+    if (e > c->weight_exp + (63 - c->headroom_bits))
+      return fail(SART_ERR_INVALID_ARGUMENT, "FIXED64: this launch's weights do not fit the quantum frozen for the accumulator "
+                                             "(flags or setup changed between accumulate == 1 launches)");
+    return 0;
+  }
+  c->weight_exp = e - (63 - c->headroom_bits);
+  c->weight_sq_exp = 2 * e - (63 - 44);
+  c->weight_bound = b;
+  c->quanta_frozen = true;
+  return 0;
 }
 
 int grid_for(uint64_t n_rays, int n_cu, int blocks_per_cu, int block) {
@@ -925,6 +988,14 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   if (int rc = sync_blob(c)) return rc;
   TraceArgs a;
   if (int rc = make_args(c, p, a)) return rc;
+  // SART_ACCUM_FIXED64 (the pilot launch that places the LDS tile reads f64 sums and always runs in f64)
+  const bool fixed = c->accum_mode == SART_ACCUM_FIXED64 && !c->tile.in_pilot;
+  a.fx_scale_w = a.fx_scale_w2 = 0.0;
+  if (fixed) {
+    if (int rc = freeze_quanta(c, weight_bound_of(c, p->flags), !p->accumulate)) return rc;
+    a.fx_scale_w = std::ldexp(1.0, -c->weight_exp);
+    a.fx_scale_w2 = std::ldexp(1.0, -c->weight_sq_exp);
+  }
   if (!p->accumulate) SART_HIP(hipMemsetAsync(acc_dev, 0, acc_len_of(c, p) * sizeof(double), c->stream));
   if (a.n_rays == 0) return 0;
   if (a.n_rays > (1ull << 31)) {   // ray indices inside one launch are 32-bit (stage A0 ring): split
@@ -966,6 +1037,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
     if (static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny) > (1u << 20)) R = std::min(R, 1);   // heat maps of millions of pixels: no scratch copies
     if (s.test_active) R = 64;
     if (c->knobs.image_replicas > 0) R = std::min(kMaxImageReplicas, c->knobs.image_replicas);
+    if (c->tile.in_pilot) R = 64;     // one-pixel image
     while (R & (R - 1)) R &= R - 1;   // power of two
     if (R > 1) {
       const size_t n_img = static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny);
@@ -973,12 +1045,14 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
       if (n_img + pad > 0xFFFFFFFFull) return fail(SART_ERR_INVALID_ARGUMENT, "image too large for replicated accumulation");
       a.replica_stride = static_cast<uint32_t>(n_img + pad);
       const size_t need = static_cast<size_t>(R) * (n_img + pad);
-      if (c->d_replicas.n != need || !c->d_replicas.p) {
+      // the pilot launch (one pixel) has scratch images of its own, so the caller's buffer keeps its layout
+      DevBuf<double>& reps = c->tile.in_pilot ? c->d_pilot_replicas : c->d_replicas;
+      if (reps.n != need || !reps.p) {
         SART_HIP(hipStreamSynchronize(c->stream));
-        if (int rc = c->d_replicas.resize(need)) return rc;
-        SART_HIP(hipMemset(c->d_replicas.p, 0, need * sizeof(double)));
+        if (int rc = reps.resize(need)) return rc;
+        SART_HIP(hipMemset(reps.p, 0, need * sizeof(double)));
       }
-      a.replicas = c->d_replicas.p;
+      a.replicas = reps.p;
       a.replica_mask = static_cast<uint32_t>(R - 1);
       // No stage A0 (its ring space in LDS is free) or the constant-path variant (the path column of ring 1 is free):
       // accumulate the centre of the spot in a per-workgroup LDS tile (CAST / LLNL: 65 % of the hits, BabyIAXO / XMM: 29 %).
@@ -992,7 +1066,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
           t.valid = false;
           t.n = 0;
           sart_trace_params_t q = *p;
-          q.n_rays = std::min<uint64_t>(p->n_rays, 200000);
+          q.n_rays = 200000;   // always the same sample, whatever the size of the call that triggers it (its first ray ids)
           q.image_nx = q.image_ny = 1;
           q.accumulate = 0;
           q.spectra = 0;
@@ -1018,12 +1092,6 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
             t.x0 = x0; t.y0 = y0; t.n = n;
           }
           t.valid = true;
-          // the pilot used (and zeroed again) the replica buffer with its own stride: make sure this launch's layout holds
-          if (c->d_replicas.n != need || !c->d_replicas.p) {
-            if (int rc2 = c->d_replicas.resize(need)) return rc2;
-            SART_HIP(hipMemset(c->d_replicas.p, 0, need * sizeof(double)));
-          }
-          a.replicas = c->d_replicas.p;
         }
         a.tile_x0 = t.x0; a.tile_y0 = t.y0; a.tile_n = t.n;
       }
@@ -1045,7 +1113,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   a.partials = c->d_partials.p;
   {
     TimedLaunch tl(c);
-    launch_trace_histogram(c->hot, c->hotb, c->d_blob.p, a, acc_dev, n_blocks, c->stream, variant);
+    launch_trace_histogram(c->hot, c->hotb, c->d_blob.p, a, acc_dev, n_blocks, c->stream, variant, fixed);
   }
   SART_HIP(hipGetLastError());
   return 0;
@@ -1062,19 +1130,69 @@ int sart_trace_histogram_spectra(sart_context* c, const sart_trace_params_t* p, 
   if (p->image_nx < 1 || p->image_ny < 1) return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
   if (p->spectra && (p->n_radial_bins < 1 || !c->have_solar)) return fail(SART_ERR_INVALID_ARGUMENT, "invalid spectra specification");
   const size_t len = acc_len_of(c, p);
-  const bool fresh = (c->d_acc.n != len) || !c->d_acc.p;
+  const bool fresh = (c->d_acc.n != len) || !c->d_acc.p || c->d_acc_stale;
   if (int rc = c->d_acc.resize(len)) return rc;
   sart_trace_params_t q = *p;
   if (fresh) q.accumulate = 0;
   if (int rc = sart_trace_histogram_device(c, &q, c->d_acc.p)) return rc;
+  c->d_acc_stale = false;
   const size_t nimg = static_cast<size_t>(p->image_nx) * p->image_ny;
-  if (image_out) SART_HIP(hipMemcpyAsync(image_out, c->d_acc.p, nimg * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  const double* src = c->d_acc.p;
+  if (c->accum_mode == SART_ACCUM_FIXED64) {   // the scratch accumulator holds integers: hand out its f64 image
+    if (int rc = c->d_fin.resize(len)) return rc;
+    if (int rc = sart_finalize_accumulator_device(c, p, c->d_acc.p, c->d_fin.p)) return rc;
+    src = c->d_fin.p;
+  }
+  if (image_out) SART_HIP(hipMemcpyAsync(image_out, src, nimg * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (summary)
-    SART_HIP(hipMemcpyAsync(summary->v, c->d_acc.p + nimg, SART_ACC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    SART_HIP(hipMemcpyAsync(summary->v, src + nimg, SART_ACC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (spectra_out && p->spectra)
-    SART_HIP(hipMemcpyAsync(spectra_out, c->d_acc.p + nimg + SART_ACC_COUNT, (len - nimg - SART_ACC_COUNT) * sizeof(double),
+    SART_HIP(hipMemcpyAsync(spectra_out, src + nimg + SART_ACC_COUNT, (len - nimg - SART_ACC_COUNT) * sizeof(double),
                             hipMemcpyDeviceToHost, c->stream));
   SART_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int sart_set_accumulation_mode(sart_context* c, int mode, int headroom_bits) {
+  if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (mode != SART_ACCUM_F64 && mode != SART_ACCUM_FIXED64) return fail(SART_ERR_INVALID_ARGUMENT, "unknown accumulation mode");
+  if (headroom_bits != 0 && (headroom_bits < 16 || headroom_bits > 44))
+    return fail(SART_ERR_INVALID_ARGUMENT, "headroom_bits must be 0 (default 30) or in [16, 44]");
+  SART_HIP(hipSetDevice(c->device));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  if (mode != c->accum_mode) c->d_acc_stale = true;
+  c->accum_mode = mode;
+  c->headroom_bits = headroom_bits ? headroom_bits : 30;
+  c->quanta_frozen = false;
+  return 0;
+}
+
+int sart_get_accumulation_mode(sart_context* c, int* mode_out) {
+  if (!c || !mode_out) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  *mode_out = c->accum_mode;
+  return 0;
+}
+
+int sart_get_fixed_quanta(sart_context* c, sart_fixed_quanta_t* out) {
+  if (!c || !out) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (!c->quanta_frozen) return fail(SART_ERR_NOT_READY, "no FIXED64 launch has fixed the quanta yet");
+  out->weight = std::ldexp(1.0, c->weight_exp);
+  out->weight_sq = std::ldexp(1.0, c->weight_sq_exp);
+  out->position = 1.0 / kFixedPositionScale;
+  out->reflect = 1.0 / kFixedReflectScale;
+  return 0;
+}
+
+int sart_finalize_accumulator_device(sart_context* c, const sart_trace_params_t* p, const void* acc_fixed_dev, double* out_dev) {
+  if (!c || !p || !acc_fixed_dev || !out_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (p->image_nx < 1 || p->image_ny < 1 || (p->spectra && p->n_radial_bins < 1))
+    return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
+  if (!c->quanta_frozen) return fail(SART_ERR_NOT_READY, "no FIXED64 launch has fixed the quanta yet");
+  SART_HIP(hipSetDevice(c->device));
+  launch_finalize_fixed(acc_fixed_dev, out_dev, static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny), p->spectra ? 1 : 0,
+                        p->spectra ? p->n_radial_bins : 0, c->n_energies + 1, std::ldexp(1.0, c->weight_exp),
+                        std::ldexp(1.0, c->weight_sq_exp), 1.0 / kFixedPositionScale, 1.0 / kFixedReflectScale, c->stream);
+  SART_HIP(hipGetLastError());
   return 0;
 }
 
@@ -1113,9 +1231,11 @@ int sart_reduce_across_devices(sart_context* const* ctxs, double* const* accs, i
   if (!ctxs || !accs || n < 1 || root < 0 || root >= n) return fail(SART_ERR_INVALID_ARGUMENT, "sart_reduce_across_devices: bad argument");
   for (int i = 0; i < n; ++i) {
     if (!ctxs[i] || !accs[i]) return fail(SART_ERR_INVALID_ARGUMENT, "NULL context / accumulator");
+    if (ctxs[i]->accum_mode != ctxs[0]->accum_mode) return fail(SART_ERR_INVALID_ARGUMENT, "contexts differ in their accumulation mode");
     for (int j = 0; j < i; ++j)
       if (ctxs[j]->device == ctxs[i]->device) return fail(SART_ERR_INVALID_ARGUMENT, "contexts must be on distinct devices");
   }
+  const int nccl_dtype = ctxs[0]->accum_mode == SART_ACCUM_FIXED64 ? 4 /* ncclInt64 */ : 8 /* ncclDouble (ncclFloat64) */;
   for (int i = 0; i < n; ++i) {   // everything queued so far must be visible to the collective
     SART_HIP(hipSetDevice(ctxs[i]->device));
     SART_HIP(hipStreamSynchronize(ctxs[i]->stream));
@@ -1141,7 +1261,7 @@ int sart_reduce_across_devices(sart_context* const* ctxs, double* const* accs, i
   int rc = r.GroupStart();
   for (int i = 0; i < n && rc == 0; ++i) {
     if (hipSetDevice(ctxs[i]->device) != hipSuccess) { rc = -1; break; }
-    rc = r.Reduce(accs[i], accs[i], n_doubles, 8 /* ncclDouble (ncclFloat64) */, 0 /* ncclSum */, root, comms[i], ctxs[i]->stream);
+    rc = r.Reduce(accs[i], accs[i], n_doubles, nccl_dtype, 0 /* ncclSum */, root, comms[i], ctxs[i]->stream);
   }
   const int rc_end = r.GroupEnd();
   if (rc == 0) rc = rc_end;

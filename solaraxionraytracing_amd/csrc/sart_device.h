@@ -208,7 +208,13 @@ struct TraceArgs {
   // [tile_y0, tile_y0 + tile_n) are accumulated per workgroup with ds_add_f64 and flushed once at the end of the kernel;
   // everything else goes to global atomics as before.  tile_n = 0: off.
   int32_t tile_x0, tile_y0, tile_n, _pad_tile;
+  // SART_ACCUM_FIXED64 (include/sart.h "accumulation mode"): 1 / quantum of the weights and of the squared weights (powers
+  // of two); positions use kFixedPositionScale, the reflectivity spectrum kFixedReflectScale.  Unused by the f64 kernels.
+  double fx_scale_w, fx_scale_w2;
 };
+constexpr double kFixedPositionScale = 4294967296.0;        // 2^32 per mm
+constexpr double kFixedReflectScale = 1099511627776.0;      // 2^40
+constexpr int kFixedLimbBits = 40;                          // two-limb sums: value = hi * 2^40 + lo
 constexpr int kImageTileMax = 45;   // 45 x 45 <= 16 waves x 128 doubles of ring-0 space
 
 }  // namespace sart

@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/sart.h"
 #include "sart_device.h"
 #include "sart_math.h"
@@ -312,6 +314,23 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
+}
+
+// SART_ACCUM_FIXED64: rint(x * scale) as an integer, |x * scale| < 2^51, in one FMA and one 64-bit subtraction: adding
+// 1.5 * 2^52 puts the sum into the binade whose unit in the last place is 1, so the FMA's single rounding (to nearest,
+// ties to even) IS the rounding to an integer, and the integer sits in the low mantissa bits.
+__device__ __forceinline__ long long to_fixed(double x, double scale) {
+  constexpr double kMagic = 6755399441055744.0;   // 1.5 * 2^52
+  return __double_as_longlong(fma(x, scale, kMagic)) - __double_as_longlong(kMagic);
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+// 8-byte slots of the accumulators hold doubles (SART_ACCUM_F64) or int64 bit patterns (SART_ACCUM_FIXED64)
+__device__ __forceinline__ void atomic_add_slot_i64(double* slot, long long v) {
+  atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)v);   // global_atomic_add_x2, no return
 }
 
 // Gather from an HBM-resident table: wave-uniform base (scalar registers) + 32-bit byte offset per lane.
@@ -971,7 +990,8 @@ __device__ __forceinline__ void reload_zones(ZoneTable& dst) {
 }
 
 // The argument block of trace_histogram_kernel as the code object lays it out (arguments in order, each at its natural
-// alignment; tools/check_kernarg_layout.py compares these offsets with the code object's metadata after every build).
+// alignment; tests/test_host_and_abi.py::test_kernel_argument_layout_matches_the_code_object compares these offsets with the
+// code object's metadata on every run of the CPU suite).
 struct HistKernArgs {
   HotA H;
   const DevBlob* blob;
@@ -979,6 +999,11 @@ struct HistKernArgs {
   double* acc;
   HotB HB;
 };
+static_assert(offsetof(HistKernArgs, H) == 0 && offsetof(HistKernArgs, blob) == (sizeof(HotA) + 7) / 8 * 8 &&
+                  offsetof(HistKernArgs, A) == offsetof(HistKernArgs, blob) + 8 &&
+                  offsetof(HistKernArgs, acc) == offsetof(HistKernArgs, A) + sizeof(TraceArgs) &&
+                  offsetof(HistKernArgs, HB) == offsetof(HistKernArgs, acc) + 8 && sizeof(HotA) % 4 == 0 && sizeof(TraceArgs) % 8 == 0,
+              "reload_hot / reload_zones / reload_kernarg read the arguments at these offsets");
 // Re-reads one argument (or a leading part of it) from the kernel-argument segment with scalar loads at the place of use.
 template <typename T>
 __device__ __forceinline__ void reload_kernarg(T& dst, size_t byte_offset) {
@@ -997,7 +1022,9 @@ __device__ __forceinline__ void reload_kernarg(T& dst, size_t byte_offset) {
 // PATHC (common configuration only): the host has proved that no ray that survives phase A entered through the bore wall
 // (sart_api.hip: build_zones), so the path in the magnetic field is the constant lengthB for every ray of phase B: ring 1
 // does not carry it, and its 128 doubles per wave hold the LDS image tile instead (with stage A0 running beside it).
-template <int BLOCK, bool FAST, bool ROT, int GAS, bool PATHC>
+// FIXED: SART_ACCUM_FIXED64 - every sum is accumulated as an integer multiple of its quantum (to_fixed), with integer
+// atomics in LDS and global memory; the slots of the replicas, of the partials and of the accumulator then hold int64.
+template <int BLOCK, bool FAST, bool ROT, int GAS, bool PATHC, bool FIXED>
 __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
                                                                 double* __restrict__ acc, HotB HBarg) {
   __shared__ TablesLds S;
@@ -1045,7 +1072,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
 
   // wave-uniform counters (ballot + popcount) and per-lane sums
   uint32_t n_reached = 0, n_shell = 0, n_nickel = 0, n_till = 0, n_passed = 0, n_outside = 0;
-  double sum_w = 0.0, sum_w2 = 0.0, sum_x = 0.0, sum_y = 0.0, sum_r = 0.0;
+  using Sum = std::conditional_t<FIXED, long long, double>;   // per-lane sums: quanta (FIXED) or f64
+  Sum sum_w = 0, sum_w2 = 0, sum_x = 0, sum_y = 0, sum_r = 0;
 #ifdef SART_STAGE_TIMING   // diagnostic build (make STAGE_TIMING=1): shader-clock cycles per stage, summed over waves, in scalars 12..15
   uint64_t cyc_a0 = 0, cyc_a1 = 0, cyc_b = 0, cyc_bs[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -1130,14 +1158,24 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     n_till += (uint32_t)__popcll(out.m_till);
     n_passed += (uint32_t)__popcll(out.m_passed);
     if (out.passed) {
-      sum_w += out.weight;
-      sum_w2 = fma(out.weight, out.weight, sum_w2);
-      sum_x += out.px;
-      sum_y += out.py;
-      sum_r += out.rdet;
       // the launch's image parameters, re-read from the kernel arguments (scalar registers, short-lived)
       TraceArgs Al;
       reload_kernarg(Al, offsetof(HistKernArgs, A));
+      long long w_fx = 0;   // FIXED: this ray's weight in quanta (what the image, the sums and the spectra add)
+      if constexpr (FIXED) {
+        w_fx = to_fixed(out.weight, Al.fx_scale_w);
+        sum_w += w_fx;
+        sum_w2 += to_fixed(out.weight * out.weight, Al.fx_scale_w2);
+        sum_x += to_fixed(out.px, kFixedPositionScale);
+        sum_y += to_fixed(out.py, kFixedPositionScale);
+        sum_r += to_fixed(out.rdet, kFixedPositionScale);
+      } else {
+        sum_w += out.weight;
+        sum_w2 = fma(out.weight, out.weight, sum_w2);
+        sum_x += out.px;
+        sum_y += out.py;
+        sum_r += out.rdet;
+      }
       // prepareHeatmap (:838-842): img[floor(y / step_y), floor(x / step_x)] += w
       // floor(t) in [0, n) <=> 0 <= t < n, and the conversion to int truncates = floor for t >= 0
       const double fx = (out.px - Al.image_x_min) * Al.image_inv_step_x;
@@ -1165,11 +1203,16 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const uint32_t tx = ix - (uint32_t)Al.tile_x0, ty = iy - (uint32_t)Al.tile_y0;   // unsigned: below the origin wraps to huge
         if ((tx < tn) & (ty < tn)) {
           const uint32_t t = ty * tn + tx;                                   // < 45 * 45 <= 16 x 128
-          __hip_atomic_fetch_add(tile_cell(t), out.weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f64
+          if constexpr (FIXED)
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell(t)), (unsigned long long)w_fx, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);                                             // ds_add_u64
+          else
+            __hip_atomic_fetch_add(tile_cell(t), out.weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ds_add_f64
         } else {
           const uint32_t pix = iy * (uint32_t)nx + ix;
           typedef __attribute__((address_space(1))) char* gbytes;
-          unsafeAtomicAdd((double*)((gbytes)img + pix * 8u), out.weight);
+          if constexpr (FIXED) atomic_add_slot_i64((double*)((gbytes)img + pix * 8u), w_fx);
+          else unsafeAtomicAdd((double*)((gbytes)img + pix * 8u), out.weight);
         }
       }
       if (Al.spectra) {   // wave-uniform: radial and per-energy histograms behind the scalars
@@ -1177,11 +1220,19 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         double* en = rad + 2 * (size_t)Al.n_radial_bins;
         const size_t ne1 = (size_t)Pb.n_energies + 1;
         const int rb = min((int)(out.rdet * Al.radial_inv_bin), Al.n_radial_bins - 1);
-        unsafeAtomicAdd(&rad[rb], 1.0);
-        unsafeAtomicAdd(&rad[(size_t)Al.n_radial_bins + rb], out.weight);
-        unsafeAtomicAdd(&en[out.e_idx], 1.0);
-        unsafeAtomicAdd(&en[ne1 + out.e_idx], out.weight);
-        unsafeAtomicAdd(&en[2 * ne1 + out.e_idx], out.reflect);
+        if constexpr (FIXED) {
+          atomic_add_slot_i64(&rad[rb], 1);
+          atomic_add_slot_i64(&rad[(size_t)Al.n_radial_bins + rb], w_fx);
+          atomic_add_slot_i64(&en[out.e_idx], 1);
+          atomic_add_slot_i64(&en[ne1 + out.e_idx], w_fx);
+          atomic_add_slot_i64(&en[2 * ne1 + out.e_idx], to_fixed(out.reflect, kFixedReflectScale));
+        } else {
+          unsafeAtomicAdd(&rad[rb], 1.0);
+          unsafeAtomicAdd(&rad[(size_t)Al.n_radial_bins + rb], out.weight);
+          unsafeAtomicAdd(&en[out.e_idx], 1.0);
+          unsafeAtomicAdd(&en[ne1 + out.e_idx], out.weight);
+          unsafeAtomicAdd(&en[2 * ne1 + out.e_idx], out.reflect);
+        }
       }
     }
   };
@@ -1279,45 +1330,52 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     double* const img = A.replicas + (size_t)((uint32_t)wave_global & A.replica_mask) * (size_t)A.replica_stride;
     for (uint32_t t = threadIdx.x; t < n_tile; t += BLOCK) {
       const double v = *tile_cell(t);
-      if (v != 0.0) {
+      if (__double_as_longlong(v) != 0ll) {   // FIXED: the cell holds an integer; f64: +0.0 is all zero bits, too
         const uint32_t ty = t / tn, tx = t - ty * tn;
-        unsafeAtomicAdd(&img[(size_t)((uint32_t)A.tile_y0 + ty) * (size_t)A.image_nx + ((uint32_t)A.tile_x0 + tx)], v);
+        double* const px = &img[(size_t)((uint32_t)A.tile_y0 + ty) * (size_t)A.image_nx + ((uint32_t)A.tile_x0 + tx)];
+        if constexpr (FIXED) atomic_add_slot_i64(px, __double_as_longlong(v));
+        else unsafeAtomicAdd(px, v);
       }
     }
   }
 
   // scalars: wave reduction -> LDS -> one plain store per workgroup and quantity (folded by fold_scalars_kernel)
-  __shared__ double red[BLOCK / 64][SART_ACC_COUNT];
-  const double sw = wave_sum(sum_w), sw2 = wave_sum(sum_w2), sxx = wave_sum(sum_x), syy = wave_sum(sum_y),
-               srr = wave_sum(sum_r);
+  // (FIXED: the slots hold int64 - sums in quanta, counters as integers - and are added as integers all the way)
+  __shared__ Sum red[BLOCK / 64][SART_ACC_COUNT];
+  Sum sw, sw2, sxx, syy, srr;
+  if constexpr (FIXED) {
+    sw = wave_sum_i64(sum_w); sw2 = wave_sum_i64(sum_w2); sxx = wave_sum_i64(sum_x); syy = wave_sum_i64(sum_y); srr = wave_sum_i64(sum_r);
+  } else {
+    sw = wave_sum(sum_w); sw2 = wave_sum(sum_w2); sxx = wave_sum(sum_x); syy = wave_sum(sum_y); srr = wave_sum(sum_r);
+  }
   if (lane == 0) {
-    double* r = red[wave];
-    for (int k = 0; k < SART_ACC_COUNT; ++k) r[k] = 0.0;
+    Sum* r = red[wave];
+    for (int k = 0; k < SART_ACC_COUNT; ++k) r[k] = 0;
     r[SART_ACC_SUM_WEIGHTS] = sw;
     r[SART_ACC_SUM_WEIGHTS_SQ] = sw2;
     r[SART_ACC_SUM_X] = sxx;
     r[SART_ACC_SUM_Y] = syy;
     r[SART_ACC_SUM_R] = srr;
-    r[SART_ACC_N_PASSED] = (double)n_passed;
-    r[SART_ACC_N_PASSED_TILL_WINDOW] = (double)n_till;
-    r[SART_ACC_N_HIT_NICKEL] = (double)n_nickel;
-    r[SART_ACC_N_REACHED_TELESCOPE] = (double)n_reached;
-    r[SART_ACC_N_SHELL_SELECTED] = (double)n_shell;
-    r[SART_ACC_N_OUTSIDE_IMAGE] = (double)n_outside;
+    r[SART_ACC_N_PASSED] = (Sum)n_passed;
+    r[SART_ACC_N_PASSED_TILL_WINDOW] = (Sum)n_till;
+    r[SART_ACC_N_HIT_NICKEL] = (Sum)n_nickel;
+    r[SART_ACC_N_REACHED_TELESCOPE] = (Sum)n_reached;
+    r[SART_ACC_N_SHELL_SELECTED] = (Sum)n_shell;
+    r[SART_ACC_N_OUTSIDE_IMAGE] = (Sum)n_outside;
 #ifdef SART_STAGE_TIMING
-    r[12] = (double)cyc_a0; r[13] = (double)cyc_a1; r[14] = (double)cyc_b;
-    r[15] = (double)(__builtin_readcyclecounter() - cyc_start);
-    r[SART_ACC_N_HIT_NICKEL] = (double)(__builtin_amdgcn_s_memrealtime() - real_start);
+    r[12] = (Sum)cyc_a0; r[13] = (Sum)cyc_a1; r[14] = (Sum)cyc_b;
+    r[15] = (Sum)(__builtin_readcyclecounter() - cyc_start);
+    r[SART_ACC_N_HIT_NICKEL] = (Sum)(__builtin_amdgcn_s_memrealtime() - real_start);
     // sub-stages of B, packed two per slot (each < 2^40, slot = hi * 2^40 + lo would lose bits in f64): use the sums of x/y/r slots
-    r[SART_ACC_SUM_X] = (double)cyc_bs[0]; r[SART_ACC_SUM_Y] = (double)cyc_bs[1]; r[SART_ACC_SUM_R] = (double)cyc_bs[2];
-    r[SART_ACC_SUM_WEIGHTS_SQ] = (double)cyc_bs[3]; r[SART_ACC_N_OUTSIDE_IMAGE] = (double)cyc_bs[4];
+    r[SART_ACC_SUM_X] = (Sum)cyc_bs[0]; r[SART_ACC_SUM_Y] = (Sum)cyc_bs[1]; r[SART_ACC_SUM_R] = (Sum)cyc_bs[2];
+    r[SART_ACC_SUM_WEIGHTS_SQ] = (Sum)cyc_bs[3]; r[SART_ACC_N_OUTSIDE_IMAGE] = (Sum)cyc_bs[4];
 #endif
   }
   __syncthreads();
   if (threadIdx.x < SART_ACC_COUNT) {
-    double t = 0.0;
+    Sum t = 0;
     for (int w = 0; w < BLOCK / 64; ++w) t += red[w][threadIdx.x];
-    A.partials[(size_t)blockIdx.x * SART_ACC_COUNT + threadIdx.x] = t;
+    reinterpret_cast<Sum*>(A.partials)[(size_t)blockIdx.x * SART_ACC_COUNT + threadIdx.x] = t;
   }
 }
 
@@ -1338,17 +1396,96 @@ __global__ __launch_bounds__(256) void fold_scalars_kernel(double* __restrict__ 
   }
 }
 
-// acc[i] += sum over replicas; replicas are left zeroed for the next launch.
-__global__ __launch_bounds__(256) void fold_replicas_kernel(double* __restrict__ acc, double* __restrict__ replicas, int n_img,
+// SART_ACCUM_FIXED64 form of the same fold, in integers.  The four sums every passed ray of every launch adds to are kept in
+// two limbs, value = hi * 2^40 + lo (include/sart.h): the workgroup partials (each < 2^57) are split before they are added,
+// so nothing can wrap, and lo is left in [0, 2^40).  Slot k's thread owns slot k and, for a two-limb sum, its *_HI slot; the
+// threads of the *_HI slots (12 .. 15, whose partials are zero) write nothing.
+__device__ __forceinline__ int fixed_hi_slot(int k) {
+  return k == SART_ACC_SUM_WEIGHTS ? SART_ACC_SUM_WEIGHTS_HI : k == SART_ACC_SUM_X ? SART_ACC_SUM_X_HI
+         : k == SART_ACC_SUM_Y ? SART_ACC_SUM_Y_HI : k == SART_ACC_SUM_R ? SART_ACC_SUM_R_HI : -1;
+}
+__global__ __launch_bounds__(256) void fold_scalars_fixed_kernel(long long* __restrict__ scalars, const long long* __restrict__ partials,
+                                                                 int n_blocks, long long n_rays) {
+  static_assert(SART_ACC_COUNT == 16, "layout of the reduction below");
+  constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
+  __shared__ long long red_lo[16][16], red_hi[16][16];
+  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
+  long long lo = 0, hi = 0;
+  for (int b = g; b < n_blocks; b += 16) {
+    const long long p = partials[(size_t)b * SART_ACC_COUNT + k];
+    lo += p & kMask;                 // arithmetic shift + mask: p = (p >> 40) * 2^40 + (p & mask) for negative p as well
+    hi += p >> kFixedLimbBits;
+  }
+  red_lo[g][k] = lo;
+  red_hi[g][k] = hi;
+  __syncthreads();
+  if (threadIdx.x < 16 && k < SART_ACC_SUM_WEIGHTS_HI) {
+    lo = 0; hi = 0;
+    for (int i = 0; i < 16; ++i) { lo += red_lo[i][k]; hi += red_hi[i][k]; }
+    const int kh = fixed_hi_slot(k);
+    if (kh >= 0) {
+      lo += scalars[k];              // < 2^40 + 2^14 * 2^40
+      scalars[k] = lo & kMask;
+      scalars[kh] += hi + (lo >> kFixedLimbBits);
+    } else {
+      scalars[k] += (hi << kFixedLimbBits) + lo + ((k == SART_ACC_N_RAYS) ? n_rays : 0ll);
+    }
+  }
+}
+
+// acc[i] += sum over replicas; replicas are left zeroed for the next launch.  T = double, or long long (SART_ACCUM_FIXED64).
+template <typename T>
+__global__ __launch_bounds__(256) void fold_replicas_kernel(T* __restrict__ acc, T* __restrict__ replicas, int n_img,
                                                             int n_replicas, uint32_t stride) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_img) return;
-  double s = 0.0;
+  T s = 0;
   for (int r = 0; r < n_replicas; ++r) {
     s += replicas[(size_t)r * (size_t)stride + i];
-    replicas[(size_t)r * (size_t)stride + i] = 0.0;
+    replicas[(size_t)r * (size_t)stride + i] = 0;
   }
   acc[i] += s;
+}
+
+// Raw SART_ACCUM_FIXED64 accumulator -> the f64 layout of include/sart.h (sart_finalize_accumulator_device).  Element-wise, so
+// `out` may alias `in`; the 16 scalars are converted by one thread, which reads all of them before it writes.
+struct FinalizeArgs {
+  long long n_img;
+  int32_t spectra, n_radial_bins, n_energies1, _pad;
+  double q_w, q_w2, q_pos, q_refl;
+};
+__global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in, double* out, FinalizeArgs F) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long n_scalar0 = F.n_img, n_spec0 = F.n_img + SART_ACC_COUNT;
+  if (i < n_scalar0) {
+    out[i] = (double)in[i] * F.q_w;                        // power-of-two quantum: the product is exact
+  } else if (i == n_scalar0) {
+    long long v[SART_ACC_COUNT];
+    for (int k = 0; k < SART_ACC_COUNT; ++k) v[k] = in[n_scalar0 + k];
+    auto two_limb = [&](int k, int kh, double q) {         // hi * 2^40 and lo are exact doubles: one rounding in the sum
+      return ((double)v[kh] * (double)(1ll << kFixedLimbBits) + (double)v[k]) * q;
+    };
+    for (int k = 0; k < SART_ACC_COUNT; ++k) {
+      double r;
+      switch (k) {
+        case SART_ACC_SUM_WEIGHTS: r = two_limb(k, SART_ACC_SUM_WEIGHTS_HI, F.q_w); break;
+        case SART_ACC_SUM_X: r = two_limb(k, SART_ACC_SUM_X_HI, F.q_pos); break;
+        case SART_ACC_SUM_Y: r = two_limb(k, SART_ACC_SUM_Y_HI, F.q_pos); break;
+        case SART_ACC_SUM_R: r = two_limb(k, SART_ACC_SUM_R_HI, F.q_pos); break;
+        case SART_ACC_SUM_WEIGHTS_SQ: r = (double)v[k] * F.q_w2; break;
+        case SART_ACC_SUM_WEIGHTS_HI: case SART_ACC_SUM_X_HI: case SART_ACC_SUM_Y_HI: case SART_ACC_SUM_R_HI: r = 0.0; break;
+        default: r = (double)v[k]; break;                  // counters
+      }
+      out[n_scalar0 + k] = r;
+    }
+  } else if (F.spectra && i >= n_spec0) {
+    // radial_counts | radial_weights | energy_counts | energy_weights | energy_reflect
+    const long long j = i - n_spec0, nr = F.n_radial_bins, ne = F.n_energies1;
+    if (j < 2 * nr + 3 * ne) {
+      const double q = j < nr ? 1.0 : j < 2 * nr ? F.q_w : j < 2 * nr + ne ? 1.0 : j < 2 * nr + 2 * ne ? F.q_w : F.q_refl;
+      out[i] = (double)in[i] * q;
+    }
+  }
 }
 
 // Literal drop-in for traceAxionWrapper: one Axion record per ray, in ray order (no compaction).
@@ -1456,11 +1593,11 @@ int histogram_block_of(int) { return 1024; }
   X(0, true, false, 0, false) X(1, false, false, -1, false) X(2, false, true, -1, false) X(3, true, false, 1, false) \
   X(4, true, true, 0, false) X(5, true, false, 0, true)
 
-int histogram_blocks_per_cu(int variant) {
+int histogram_blocks_per_cu(int variant) {   // the FIXED64 instantiations use the same LDS and launch bounds
   int n = 0;
   hipError_t e = hipErrorInvalidValue;
   switch (variant) {
-#define X(ID, F, R, G, PC) case ID: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, F, R, G, PC>, 1024, 0); break;
+#define X(ID, F, R, G, PC) case ID: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_histogram_kernel<1024, F, R, G, PC, false>, 1024, 0); break;
     SART_HIST_VARIANTS(X)
 #undef X
     default: break;
@@ -1469,18 +1606,37 @@ int histogram_blocks_per_cu(int variant) {
 }
 
 void launch_trace_histogram(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
-                            hipStream_t stream, int variant) {
-  switch (variant) {
-#define X(ID, F, R, G, PC) case ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G, PC>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB); break;
+                            hipStream_t stream, int variant, bool fixed) {
+  switch (variant + (fixed ? 100 : 0)) {
+#define X(ID, F, R, G, PC) \
+    case ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G, PC, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB); break; \
+    case 100 + ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G, PC, true>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB); break;
     SART_HIST_VARIANTS(X)
 #undef X
     default: return;
   }
   const int n_img = A.image_nx * A.image_ny;
+  if (fixed) {
+    long long* const acc_i = reinterpret_cast<long long*>(acc);
+    hipLaunchKernelGGL(fold_scalars_fixed_kernel, dim3(1), dim3(256), 0, stream, acc_i + n_img,
+                       reinterpret_cast<const long long*>(A.partials), n_blocks, (long long)A.n_rays);
+    if (A.replica_mask != 0u)
+      hipLaunchKernelGGL(fold_replicas_kernel<long long>, dim3((n_img + 255) / 256), dim3(256), 0, stream, acc_i,
+                         reinterpret_cast<long long*>(A.replicas), n_img, (int)A.replica_mask + 1, A.replica_stride);
+    return;
+  }
   hipLaunchKernelGGL(fold_scalars_kernel, dim3(1), dim3(256), 0, stream, acc + n_img, A.partials, n_blocks, (double)A.n_rays);
   if (A.replica_mask != 0u)
-    hipLaunchKernelGGL(fold_replicas_kernel, dim3((n_img + 255) / 256), dim3(256), 0, stream, acc, A.replicas, n_img,
+    hipLaunchKernelGGL(fold_replicas_kernel<double>, dim3((n_img + 255) / 256), dim3(256), 0, stream, acc, A.replicas, n_img,
                        (int)A.replica_mask + 1, A.replica_stride);
+}
+
+void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectra, int n_radial_bins, int n_energies1, double q_w,
+                           double q_w2, double q_pos, double q_refl, hipStream_t stream) {
+  FinalizeArgs F{(long long)n_img, spectra, n_radial_bins, n_energies1, 0, q_w, q_w2, q_pos, q_refl};
+  const size_t total = n_img + SART_ACC_COUNT + (spectra ? 2 * (size_t)n_radial_bins + 3 * (size_t)n_energies1 : 0);
+  hipLaunchKernelGGL(finalize_fixed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const long long*>(in), out, F);
 }
 void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream) {

@@ -5,7 +5,8 @@ the fused output accumulator (image + scalars) per image — RCCL over xGMI on t
 The reference has no distributed layer (weave threads over one ``parallelFor``, raytracer.nim:2234);
 rays are independent, so the partition is a pure index split and the only exchange is the final sum.
 Because the Philox counter is the *global* ray id, the union of the shards is the same set of rays for
-any world size; results agree up to f64 summation order.
+any world size; results agree up to f64 summation order - or bit for bit in the SART_ACCUM_FIXED64 accumulation mode
+(integer accumulators, reduced as int64).
 """
 from __future__ import annotations
 
@@ -163,22 +164,26 @@ def init_process_group_from_env(backend: str | None = None):
     return rank, world, local_rank
 
 
-def reduce_accumulator(acc, dst: int | None = 0):
+def reduce_accumulator(acc, dst: int | None = 0, fixed64: bool = False):
     """The single collective of the path: sum the fused accumulator tensor over ranks (``dst`` = root rank, or
-    None for an all-reduce).  No-op without a process group."""
+    None for an all-reduce).  No-op without a process group.  ``fixed64``: the 8-byte slots hold the int64 of a raw
+    SART_ACCUM_FIXED64 accumulator - they are summed as integers (exact, so the result does not depend on the number of
+    ranks or on the reduction tree)."""
+    import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return acc
+    buf = acc.view(torch.int64) if (fixed64 and acc.dtype != torch.int64) else acc
     if dst is None:
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     else:
-        dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM)
+        dist.reduce(buf, dst=dst, op=dist.ReduceOp.SUM)
     return acc
 
 
 def trace_sharded(trace_fn: Callable[[int, int], "np.ndarray"], n_total: int, rank: int, world_size: int,
-                  to_tensor: Callable | None = None, dst: int | None = 0):
+                  to_tensor: Callable | None = None, dst: int | None = 0, fixed64: bool = False):
     """Runs ``trace_fn(ray_id_offset, n_rays) -> accumulator`` on this rank's shard of [0, n_total) and reduces.
     ``trace_fn`` returns either a torch tensor (device accumulator on the GPU box) or a numpy array."""
     import torch
@@ -187,7 +192,7 @@ def trace_sharded(trace_fn: Callable[[int, int], "np.ndarray"], n_total: int, ra
     acc = trace_fn(lo, hi - lo)
     if not isinstance(acc, torch.Tensor):
         acc = torch.from_numpy(np.ascontiguousarray(acc)) if to_tensor is None else to_tensor(acc)
-    return reduce_accumulator(acc, dst)
+    return reduce_accumulator(acc, dst, fixed64)
 
 
 def gather_scan(values_local, indices_local, n_total: int):

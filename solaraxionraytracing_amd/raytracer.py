@@ -164,6 +164,31 @@ class RayTracer:
     def set_axion_mass(self, m_axion_ev: float):
         _lib.check(self.lib.sart_set_axion_mass(self.handle, m_axion_ev))
 
+    def set_accumulation_mode(self, mode: int | str = _lib.ACCUM_F64, headroom_bits: int = 0):
+        """SART_ACCUM_F64 (default: f64 atomics, as prepareHeatmap adds on the CPU) or SART_ACCUM_FIXED64 ("fixed64":
+        integer accumulation, results bitwise independent of GPU count, replica placement and launch splitting;
+        include/sart.h "accumulation mode").  The blocking calls keep returning doubles; trace_histogram_device then fills
+        raw int64 accumulators (reduce them as int64, convert with finalize_accumulator_device)."""
+        if isinstance(mode, str):
+            mode = {"f64": _lib.ACCUM_F64, "fixed64": _lib.ACCUM_FIXED64}[mode]
+        _lib.check(self.lib.sart_set_accumulation_mode(self.handle, int(mode), int(headroom_bits)))
+
+    def accumulation_mode(self) -> int:
+        m = C.c_int()
+        _lib.check(self.lib.sart_get_accumulation_mode(self.handle, C.byref(m)))
+        return m.value
+
+    def fixed_quanta(self) -> dict:
+        """The quanta the raw FIXED64 accumulators of this context count in (frozen by the first launch)."""
+        q = _lib.FixedQuanta()
+        _lib.check(self.lib.sart_get_fixed_quanta(self.handle, C.byref(q)))
+        return {"weight": q.weight, "weight_sq": q.weight_sq, "position": q.position, "reflect": q.reflect}
+
+    def finalize_accumulator_device(self, params: TraceParams, acc_fixed_ptr: int, out_f64_ptr: int | None = None):
+        """Raw FIXED64 accumulator (device) -> f64 accumulator layout (device; in place by default).  Asynchronous."""
+        _lib.check(self.lib.sart_finalize_accumulator_device(self.handle, C.byref(params), C.c_void_p(acc_fixed_ptr),
+                                                             C.c_void_p(out_f64_ptr if out_f64_ptr is not None else acc_fixed_ptr)))
+
     def set_stream(self, hip_stream: int | None):
         _lib.check(self.lib.sart_set_stream(self.handle, C.c_void_p(hip_stream) if hip_stream else None))
 

@@ -167,3 +167,77 @@ def test_scripts_exit_nonzero_before_touching_a_gpu(script):
     r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+# ---- SART_ACCUM_FIXED64: raw integer accumulators reduce exactly (include/sart.h "accumulation mode") -------------------
+
+def _raw_fixed_accumulator(rec, weight_exp, chip=14.0, n=256):
+    """What the FIXED64 kernels leave in a raw accumulator, rebuilt from Axion records: every passed ray adds
+    rint(weight / 2^weight_exp) to its pixel; SUM_WEIGHTS / SUM_X / SUM_Y / SUM_R in two limbs (hi * 2^40 + lo); counters."""
+    from solaraxionraytracing_amd import _lib
+    acc = np.zeros(n * n + _lib.SART_ACC_COUNT, dtype=np.int64)
+    ok = rec["passed"] == 1
+    W = np.rint(np.ldexp(rec["weights"][ok], -weight_exp)).astype(np.int64)
+    ix = np.floor(rec["pointdataX"][ok] / (chip / n)).astype(np.int64)
+    iy = np.floor(rec["pointdataY"][ok] / (chip / n)).astype(np.int64)
+    inside = (ix >= 0) & (ix < n) & (iy >= 0) & (iy < n)
+    np.add.at(acc, (iy * n + ix)[inside], W[inside])
+    mask = (1 << _lib.FIXED_LIMB_BITS) - 1
+
+    def two_limb(name, total):
+        acc[n * n + _lib.ACC[name]] = total & mask
+        acc[n * n + _lib.ACC_HI[name]] = total >> _lib.FIXED_LIMB_BITS
+    two_limb("SUM_WEIGHTS", int(W.astype(object).sum()) if W.size else 0)
+    for name, col in (("SUM_X", "pointdataX"), ("SUM_Y", "pointdataY"), ("SUM_R", "pointdataR")):
+        v = np.rint(rec[col][ok] * 2.0 ** 32).astype(np.int64)
+        two_limb(name, int(v.astype(object).sum()) if v.size else 0)
+    acc[n * n + _lib.ACC["N_PASSED"]] = int(ok.sum())
+    acc[n * n + _lib.ACC["N_RAYS"]] = rec.size
+    acc[n * n + _lib.ACC["N_OUTSIDE_IMAGE"]] = int((~inside).sum())
+    return acc
+
+
+def _value(acc, name, n=256):
+    from solaraxionraytracing_amd import _lib
+    return (int(acc[n * n + _lib.ACC_HI[name]]) << _lib.FIXED_LIMB_BITS) + int(acc[n * n + _lib.ACC[name]])
+
+
+def _fixed_worker(rank, world, port, n_total, seed, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from tests.conftest import make_setup
+    from oracle.oracle import Oracle
+    D.init_process_group_from_env("gloo")
+    o = Oracle(make_setup("babyiaxo_xmm"))
+
+    def trace_fn(offset, n):   # stands in for trace_histogram_device in FIXED64 mode on this rank's GPU
+        return torch.from_numpy(_raw_fixed_accumulator(o.trace_records(n, seed=seed, ray_id_offset=offset), -61))
+
+    acc = D.trace_sharded(trace_fn, n_total, rank, world, dst=0, fixed64=True)
+    assert acc.dtype == torch.int64
+    if rank == 0:
+        np.save(out_path, acc.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fixed64_reduce_is_exact(tmp_path):
+    """Integer accumulators: the 2-rank result equals the single-process one bit for bit (the f64 mode above: 1e-12)."""
+    from tests.conftest import make_setup
+    from oracle.oracle import Oracle
+    from solaraxionraytracing_amd import _lib
+    n_total, seed = 40_001, 78
+    out = str(tmp_path / "acc_fixed.npy")
+    mp.spawn(_fixed_worker, args=(2, 29613, n_total, seed, out), nprocs=2, join=True)
+    acc = np.load(out)
+    one = _raw_fixed_accumulator(Oracle(make_setup("babyiaxo_xmm")).trace_records(n_total, seed=seed), -61)
+    n_img = 256 * 256
+    assert np.array_equal(acc[:n_img], one[:n_img]) and acc[:n_img].sum() > 0
+    for name in ("SUM_WEIGHTS", "SUM_X", "SUM_Y", "SUM_R"):
+        assert _value(acc, name) == _value(one, name), name       # the limbs of a sum need not be normalised, its value is exact
+    for name in ("N_PASSED", "N_RAYS", "N_OUTSIDE_IMAGE"):
+        assert acc[n_img + _lib.ACC[name]] == one[n_img + _lib.ACC[name]], name
+    assert _value(acc, "SUM_WEIGHTS") == int(acc[:n_img].astype(object).sum())   # image sums to SUM_WEIGHTS exactly
+    # f64 tensors that carry int64 bit patterns (a caller that allocated doubles) reduce the same way
+    t = torch.from_numpy(one.copy()).view(torch.float64)
+    assert D.reduce_accumulator(t, dst=0, fixed64=True) is t

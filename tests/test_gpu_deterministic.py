@@ -1,0 +1,198 @@
+"""SART_ACCUM_FIXED64 — the deterministic accumulation mode (include/sart.h "accumulation mode"; run on the MI355X box).
+
+The reference adds f64 weights into its heat map one after the other on the CPU (prepareHeatmap, raytracer.nim:838-842; flux
+sum :2800).  On the GPU the order in which f64 atomics retire depends on the number of GPUs, on the replica / LDS-tile
+placement and on how the rays are split over launches, so f64 images agree only to ~1e-13.  In FIXED64 mode every ray adds
+rint(weight / quantum) as an integer: the tests below demand BITWISE equal images and scalars under all of those changes,
+and agreement with the f64 mode to 1e-12 of the largest pixel."""
+import os
+
+import numpy as np
+import pytest
+
+import solaraxionraytracing_amd as sa
+from solaraxionraytracing_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+N = 20_000_000
+COUNTERS = ("N_RAYS", "N_PASSED", "N_PASSED_TILL_WINDOW", "N_HIT_NICKEL", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_OUTSIDE_IMAGE")
+SUMS = ("SUM_WEIGHTS", "SUM_X", "SUM_Y", "SUM_R", "SUM_WEIGHTS_SQ")
+
+_cache = {}
+
+
+def full_setup(name):
+    if name not in _cache:
+        if name == "babyiaxo_xmm":        # constant-path variant: stage A0 + LDS tile in ring 1's path column, 8 replicas
+            _cache[name] = sa.initFullSetup()
+        elif name == "cast_llnl_gold":    # no stage A0: LDS tile in ring 0, 64 replicas
+            _cache[name] = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
+        elif name == "babyiaxo_xmm_gas":  # gas-stage specialisation
+            _cache[name] = sa.initFullSetup(stage=L.SK_GAS)
+        else:
+            raise KeyError(name)
+    return _cache[name]
+
+
+def run(name, mode, splits=(N,), env=None, seed=5, spectra=False):
+    """One image of N rays in `mode`, traced as len(splits) accumulating launches, in a fresh context (the SART_* knobs are
+    read when a context is created)."""
+    env = env or {}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with sa.RayTracer(full_setup(name)) as rt:
+            rt.set_accumulation_mode(mode)
+            off = 0
+            for k, n in enumerate(splits):
+                if spectra:
+                    img, s, spec = rt.trace_spectra(n, seed=seed, ray_id_offset=off, accumulate=(k > 0), n_radial_bins=2000, radial_max=10.0)
+                else:
+                    img, s = rt.trace_histogram(n, seed=seed, ray_id_offset=off, accumulate=(k > 0))
+                    spec = None
+                off += n
+            quanta = rt.fixed_quanta() if mode == "fixed64" else None
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    assert off == N
+    return img, s, spec, quanta
+
+
+def assert_bitwise(a, b, what):
+    img_a, s_a = a[0], a[1]
+    img_b, s_b = b[0], b[1]
+    assert np.array_equal(img_a.view(np.uint64), img_b.view(np.uint64)), what + ": image differs"
+    for k in COUNTERS + SUMS:
+        assert np.float64(s_a[k]).view(np.uint64) == np.float64(s_b[k]).view(np.uint64), (what, k, s_a[k], s_b[k])
+
+
+@pytest.mark.parametrize("name", ["babyiaxo_xmm", "cast_llnl_gold", "babyiaxo_xmm_gas"])
+def test_fixed64_is_bitwise_independent_of_placement_and_splitting(name):
+    base = run(name, "fixed64")
+    assert base[1]["N_RAYS"] == N and base[1]["N_PASSED"] > 1e5
+    # replica count (8 <-> 64: another wave -> image mapping and another fold)
+    assert_bitwise(base, run(name, "fixed64", env={"SART_IMAGE_REPLICAS": "64" if name != "cast_llnl_gold" else "8"}), "replicas")
+    assert_bitwise(base, run(name, "fixed64", env={"SART_IMAGE_REPLICAS": "1"}), "one image")
+    # LDS tile off: every hit goes to a global atomic
+    assert_bitwise(base, run(name, "fixed64", env={"SART_NO_IMAGE_TILE": "1"}), "tile off")
+    # two other splittings of the same ray ids over accumulating launches (not multiples of the 256-ray chunks)
+    assert_bitwise(base, run(name, "fixed64", splits=(7_000_001, 12_999_999)), "two launches")
+    assert_bitwise(base, run(name, "fixed64", splits=(1, 999, 9_999_000, 10_000_000)), "four launches")
+    # stage A0 off: other ring traffic, another wave -> ray assignment, other per-workgroup partial sums
+    assert_bitwise(base, run(name, "fixed64", env={"SART_NO_EARLY_REJECT": "1"}), "stage A0 off")
+
+
+@pytest.mark.parametrize("name", ["babyiaxo_xmm", "cast_llnl_gold"])
+def test_fixed64_agrees_with_f64_accumulation(name):
+    fx = run(name, "fixed64")
+    fl = run(name, "f64")
+    for k in COUNTERS:
+        assert fx[1][k] == fl[1][k], k
+    peak = fl[0].max()
+    assert np.abs(fx[0] - fl[0]).max() <= 1e-12 * peak, np.abs(fx[0] - fl[0]).max() / peak
+    for k in ("SUM_WEIGHTS", "SUM_X", "SUM_Y", "SUM_R"):
+        assert fx[1][k] == pytest.approx(fl[1][k], rel=1e-12), k
+    assert fx[1]["SUM_WEIGHTS_SQ"] == pytest.approx(fl[1]["SUM_WEIGHTS_SQ"], rel=1e-8)   # coarse quantum by design (44-bit ray count)
+    # integers all the way: the image sums to SUM_WEIGHTS exactly (no ray fell outside the image)
+    q = fx[3]["weight"]
+    assert fx[1]["N_OUTSIDE_IMAGE"] == 0
+    pix = np.rint(fx[0] / q).astype(np.int64)
+    assert np.array_equal(pix * q, fx[0])                       # every pixel is a whole number of quanta
+    total = int(pix.astype(object).sum())                       # exact (Python integers); may exceed 2^53
+    assert float(total) * q == fx[1]["SUM_WEIGHTS"]             # two limbs -> one correctly rounded double
+    # the quanta are powers of two below the weight of any ray
+    assert np.log2(q) == np.floor(np.log2(q)) and q < fl[1]["SUM_WEIGHTS"] / fl[1]["N_PASSED"] * 1e-8
+
+
+def test_fixed64_spectra():
+    fx = run("babyiaxo_xmm", "fixed64", spectra=True)
+    fx2 = run("babyiaxo_xmm", "fixed64", spectra=True, splits=(3_333_333, 16_666_667), env={"SART_IMAGE_REPLICAS": "16"})
+    fl = run("babyiaxo_xmm", "f64", spectra=True)
+    assert_bitwise(fx, fx2, "spectra run")
+    for k in ("radial_counts", "radial_weights", "energy_counts", "energy_weights", "energy_reflect"):
+        assert np.array_equal(fx[2][k].view(np.uint64), fx2[2][k].view(np.uint64)), k
+        scale = np.abs(fl[2][k]).max()
+        assert np.abs(fx[2][k] - fl[2][k]).max() <= 1e-11 * scale, k
+    assert fx[2]["radial_counts"].sum() == fx[1]["N_PASSED"] == fx[2]["energy_counts"].sum()
+
+
+def test_fixed64_raw_accumulators_sum_like_integers():
+    """The multi-GPU form on one card: two contexts trace the two halves of the ray ids into raw int64 accumulators, the
+    buffers are added as integers (what an int64 reduce does) and finalized: bit for bit the single-context result."""
+    import torch
+    full = full_setup("babyiaxo_xmm")
+    n_acc = sa.accumulator_len(256)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        def traced(ranges):
+            acc = torch.zeros(n_acc, dtype=torch.int64, device=dev)
+            with sa.RayTracer(full) as rt:
+                rt.set_stream(stream.cuda_stream)
+                rt.set_accumulation_mode("fixed64")
+                for lo, hi in ranges:
+                    p = rt.trace_params(hi - lo, seed=9, ray_id_offset=lo, accumulate=True)
+                    rt.trace_histogram_device(p, acc.data_ptr())
+                rt.synchronize()
+                return acc, rt.fixed_quanta()
+        whole, q0 = traced([(0, N)])
+        a, q1 = traced([(0, N // 2 + 12345)])
+        b, q2 = traced([(N // 2 + 12345, N)])
+        assert q0 == q1 == q2                                   # equal inputs -> equal quanta on every rank
+        both = a + b                                            # limb-wise integer sum
+        with sa.RayTracer(full) as rt:
+            rt.set_stream(stream.cuda_stream)
+            rt.set_accumulation_mode("fixed64")
+            p = rt.trace_params(1000, seed=9, accumulate=False)
+            scratch = torch.zeros(n_acc, dtype=torch.int64, device=dev)
+            rt.trace_histogram_device(p, scratch.data_ptr())    # freezes this context's quanta
+            assert rt.fixed_quanta() == q0
+            out_w = torch.empty(n_acc, dtype=torch.float64, device=dev)
+            out_s = torch.empty(n_acc, dtype=torch.float64, device=dev)
+            rt.finalize_accumulator_device(p, whole.data_ptr(), out_w.data_ptr())
+            rt.finalize_accumulator_device(p, both.data_ptr(), out_s.data_ptr())
+            rt.synchronize()
+        stream.synchronize()
+    assert torch.equal(out_w.view(torch.int64), out_s.view(torch.int64))
+    n_img = 256 * 256
+    assert out_w[n_img + L.ACC["N_RAYS"]].item() == N
+    for k, i in L.ACC_HI.items():                               # high limbs read 0 in the f64 layout
+        assert out_w[n_img + i].item() == 0.0
+    lo = whole[n_img + L.ACC["SUM_WEIGHTS"]].item()
+    assert 0 <= lo < 2 ** L.FIXED_LIMB_BITS                      # normalised low limb
+
+
+def test_fixed64_errors():
+    full = full_setup("babyiaxo_xmm")
+    with sa.RayTracer(full) as rt:
+        assert rt.accumulation_mode() == L.ACCUM_F64
+        with pytest.raises(L.SartError):
+            rt.set_accumulation_mode(7)
+        with pytest.raises(L.SartError):
+            rt.set_accumulation_mode("fixed64", headroom_bits=60)
+        rt.set_accumulation_mode("fixed64")
+        with pytest.raises(L.SartError) as e:
+            rt.fixed_quanta()
+        assert e.value.code == -3                                # SART_ERR_NOT_READY
+        rt.trace_histogram(100_000, seed=1)
+        q = rt.fixed_quanta()["weight"]
+        # the next accumulating launch drops the conversion probability (weights ~1e22 times larger): does not fit the quantum
+        with pytest.raises(L.SartError) as e:
+            rt.trace_histogram(100_000, seed=1, ray_id_offset=100_000, accumulate=True, flags=L.CF_IGNORE_CONV_PROB)
+        assert e.value.code == -1 and "quantum" in str(e.value)
+        # a launch that zeroes the accumulator re-freezes
+        rt.trace_histogram(100_000, seed=1, flags=L.CF_IGNORE_CONV_PROB)
+        assert rt.fixed_quanta()["weight"] > q * 1e15
+        # back to f64: the scratch accumulator of the blocking call starts from zero again
+        rt.set_accumulation_mode("f64")
+        img, s = rt.trace_histogram(100_000, seed=1, accumulate=True)
+        assert s["N_RAYS"] == 100_000 and img.sum() == pytest.approx(s["SUM_WEIGHTS"], rel=1e-12)
+        # larger headroom = coarser quantum
+        rt.set_accumulation_mode("fixed64", headroom_bits=40)
+        rt.trace_histogram(100_000, seed=1)
+        assert rt.fixed_quanta()["weight"] == q * 2.0 ** 10

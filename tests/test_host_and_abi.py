@@ -64,7 +64,7 @@ def test_kernel_argument_layout_matches_the_code_object(tmp_path):
         assert [o for o, _ in explicit] == list(want[:5]), (m.group(1), explicit, list(want))
         assert explicit[-1][0] + explicit[-1][1] <= want[5]
         seen += 1
-    assert seen == 6   # specialised (vacuum with and without the constant path, gas, rotated), generic, generic rotated
+    assert seen == 12  # {specialised (vacuum with and without the constant path, gas, rotated), generic, generic rotated} x {f64, FIXED64}
 
 
 def test_nim_binding_declares_every_header_field():
