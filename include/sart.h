@@ -283,6 +283,25 @@ int sart_set_axion_mass(sart_context* ctx, double m_axion_ev);
 int sart_set_solar_tables(sart_context* ctx, const double* flux_radius_cdf,
                           const double* diff_flux_cdfs, const double* energies_kev,
                           int32_t n_radii, int32_t n_energies);
+/*
+ * The same tables built ON THE DEVICE from an emission-rate table that already lives there (e.g. the output of
+ * sart_emission_table_device): the CDF construction of initFullSetup (raytracer.nim:2670-2705) - per radius row the
+ * running sum of emRate * E^2 * r^2 over the energies in the reference's order, normalised by its last element; the running
+ * sum of the row sums, normalised - and the guide tables in front of both, without a device -> host -> device round trip.
+ * Bit-identical to sart_host_build_cdfs + sart_set_solar_tables on the same numbers.
+ *   em_rates_device [n_radii][n_energies] row-major, DEVICE memory (not modified)
+ *   radii [n_radii] (fractions of the solar radius, :2651), energies_kev [n_energies]: HOST memory
+ * Blocking.  SART_ERR_INVALID_ARGUMENT if a row does not give a CDF (negative or non-finite rates, a row that sums to 0).
+ */
+int sart_set_solar_tables_device(sart_context* ctx, const double* em_rates_device, const double* radii,
+                                 const double* energies_kev, int32_t n_radii, int32_t n_energies);
+/*
+ * Host copies of the sampling tables the context holds, whichever call set them (any pointer may be NULL):
+ * flux_radius_cdf_out[n_radii], diff_flux_cdfs_out[n_radii][n_energies], and the library's guide tables
+ * radius_guide_out[2049], energy_guide_out[n_radii][3586] (u16; layout in csrc/sart_device.h - for tests and debugging).
+ */
+int sart_get_solar_tables(sart_context* ctx, double* flux_radius_cdf_out, double* diff_flux_cdfs_out,
+                          uint16_t* radius_guide_out, uint16_t* energy_guide_out);
 /* Reflectivity grids as read by initReflectivity (:1160-1231): data[coating][angle][energy],
  * uniform grid defined by (min,max) of the axes (newBilinearSpline :1181/:1204/:1226). */
 int sart_set_reflectivity(sart_context* ctx, int32_t n_coatings, int32_t n_angles,
@@ -334,13 +353,14 @@ int sart_trace_histogram_spectra(sart_context* ctx, const sart_trace_params_t* p
  * reduce is an int64 sum of the raw buffers (ncclInt64 / torch.int64 view; sart_reduce_across_devices does this by
  * itself); sart_finalize_accumulator_device converts a raw buffer to the f64 layout documented above.
  *   quanta   weights (image pixels, SUM_WEIGHTS, radial / energy weight spectra): q_w = 2^e with
- *            w_bound < 2^(e + 63 - headroom_bits), w_bound = the host-side upper bound of one ray's weight for the setup,
- *            tables and flags of the launch that fixes the quantum (exposure x conversion probability x max reflectivity^2
- *            x max window transmission x max gas absorption).  headroom_bits (default 30) = log2 of the number of
- *            maximal-weight rays a slot can take before it wraps: a pixel holds >= 2^30 of them; the resolution of one
- *            ray's weight is 2^-33 w_bound, the image as a whole agrees with the f64 image to ~1e-13 relative to its
- *            largest pixel.  SUM_WEIGHTS_SQ: q = w_bound^2 2^-19 (a 44-bit ray count).  SUM_X / SUM_Y / SUM_R: 2^-32 mm.
- *            energy_reflect spectrum: 2^-40.
+ *            w_bound < 2^(e + 63 - headroom_bits), w_bound = the host's scale of the largest weight of one ray for the setup,
+ *            tables and flags of the launch that fixes the quantum (exposure x conversion probability over lengthB x max
+ *            reflectivity^2 x max window transmission x max gas absorption).  headroom_bits (default 27) = log2 of the
+ *            number of w_bound-weight rays a slot can take before it wraps: a pixel holds 2^27 = 1.3e8 of them (a 256 x 256
+ *            BabyIAXO image reaches that after ~1e13 traced rays); the resolution of one ray's weight is 2^-36 w_bound, and
+ *            a pixel that n rays hit carries a rounding error of ~q_w sqrt(n / 12): an image of 2e7 rays agrees with the f64
+ *            image to < 1e-12 of its largest pixel, larger images better.  SUM_WEIGHTS_SQ: q = w_bound^2 2^-19 (a 44-bit
+ *            ray count).  SUM_X / SUM_Y / SUM_R: 2^-32 mm.  energy_reflect spectrum: 2^-40.
  *   limbs    SUM_WEIGHTS, SUM_X, SUM_Y, SUM_R receive every passed ray of every launch: value = (hi * 2^40 + lo) * q with
  *            lo in slot SART_ACC_SUM_*, hi in slot SART_ACC_SUM_*_HI (after a launch 0 <= lo < 2^40; limb-wise int64 sums
  *            over up to 2^22 ranks stay exact).
@@ -358,7 +378,7 @@ typedef struct sart_fixed_quanta_t {
   double position;      /* SUM_X, SUM_Y, SUM_R (2^-32 mm) */
   double reflect;       /* energy_reflect (2^-40) */
 } sart_fixed_quanta_t;
-/* headroom_bits: 0 = default (30); otherwise 16 .. 44.  Waits for the stream; resets the frozen quanta. */
+/* headroom_bits: 0 = default (27); otherwise 16 .. 44.  Waits for the stream; resets the frozen quanta. */
 int sart_set_accumulation_mode(sart_context* ctx, int mode, int headroom_bits);
 int sart_get_accumulation_mode(sart_context* ctx, int* mode_out);
 /* The frozen quanta (SART_ERR_NOT_READY before the first FIXED64 launch). */

@@ -79,6 +79,14 @@ int sart_emission_table_device(sart_context* ctx, const sart_solar_zone_t* zones
                                const double* energies_kev, int32_t n_energies, const double* abs_coefs_dev,
                                const sart_emission_params_t* params, double* em_rates_dev, double* components_dev);
 
+/* The whole front end of BASELINE configs[4] on the device: emission table of the solar model (as above, kept on the
+ * GPU) -> sart_set_solar_tables_device (fluxRadiusCDF, diffFluxCDFs and their guide tables, raytracer.nim:2670-2705).
+ * Replaces calculateOpacities -> solar_model_dataframe.csv -> initFullSetup's readCsv + CDF loops for the context's
+ * sampling tables; radii = zones[i].radius_frac.  Blocking. */
+int sart_emission_to_solar_tables(sart_context* ctx, const sart_solar_zone_t* zones, int32_t n_radii,
+                                  const double* energies_kev, int32_t n_energies, const double* abs_coefs_dev,
+                                  const sart_emission_params_t* params);
+
 /* Duration in ms of the last emission-table kernel this process launched (HIP events on the launch stream). */
 double sart_emission_last_kernel_ms(void);
 

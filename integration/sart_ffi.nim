@@ -101,6 +101,10 @@ proc sart_set_telescope_angles*(ctx: ptr SartContext, turnedXDeg, turnedYDeg: cd
 proc sart_set_axion_mass*(ctx: ptr SartContext, mAxionEv: cdouble): cint {.importc, header: sartH.}
 proc sart_set_solar_tables*(ctx: ptr SartContext, fluxRadiusCdf, diffFluxCdfs, energiesKev: ptr cdouble,
                             nRadii, nEnergies: int32): cint {.importc, header: sartH.}
+proc sart_set_solar_tables_device*(ctx: ptr SartContext, emRatesDevice: pointer, radii, energiesKev: ptr cdouble,
+                                   nRadii, nEnergies: int32): cint {.importc, header: sartH.}
+proc sart_get_solar_tables*(ctx: ptr SartContext, fluxRadiusCdfOut, diffFluxCdfsOut: ptr cdouble,
+                            radiusGuideOut, energyGuideOut: ptr uint16): cint {.importc, header: sartH.}
 proc sart_set_reflectivity*(ctx: ptr SartContext, nCoatings, nAngles, nEnergies: int32,
                             angleMinDeg, angleMaxDeg, energyMinKev, energyMaxKev: cdouble, data: ptr cdouble): cint {.importc, header: sartH.}
 proc sart_set_detector_tables*(ctx: ptr SartContext, strongbackX, strongbackY: ptr cdouble, nStrongback: int32,

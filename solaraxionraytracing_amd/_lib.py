@@ -166,6 +166,8 @@ SART_SYMBOLS = {
     "sart_set_telescope_angles": (C.c_int, [C.c_void_p, _d, _d]),
     "sart_set_axion_mass": (C.c_int, [C.c_void_p, _d]),
     "sart_set_solar_tables": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _i, _i]),
+    "sart_set_solar_tables_device": (C.c_int, [C.c_void_p, C.c_void_p, _dp, _dp, _i, _i]),
+    "sart_get_solar_tables": (C.c_int, [C.c_void_p, _dp, _dp, C.c_void_p, C.c_void_p]),
     "sart_set_reflectivity": (C.c_int, [C.c_void_p, _i, _i, _i, _d, _d, _d, _d, _dp]),
     "sart_set_detector_tables": (C.c_int, [C.c_void_p, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _i]),
     "sart_trace_records": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p]),
@@ -187,6 +189,7 @@ SART_SYMBOLS = {
     "sart_emission_table": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _i, _dp, _P(EmissionParams), _dp, _dp]),
     "sart_emission_table_device": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _i, C.c_void_p, _P(EmissionParams),
                                              C.c_void_p, C.c_void_p]),
+    "sart_emission_to_solar_tables": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _i, C.c_void_p, _P(EmissionParams)]),
     "sart_emission_last_kernel_ms": (_d, []),
 }
 

@@ -29,6 +29,9 @@ void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, co
                           hipStream_t stream);
 int records_block();
 int histogram_blocks_per_cu(int variant);
+void launch_build_solar_tables(const double* em_dev, const double* radii_dev, const double* energies_dev, int n_radii, int n_energies,
+                               double* cdf_dev, double* row_sum_dev, double* rcdf_dev, uint16_t* rguide_dev, uint16_t* eguide_dev,
+                               uint32_t* status_dev, hipStream_t stream);
 }  // namespace sart
 
 using namespace sart;
@@ -192,7 +195,7 @@ struct sart_context {
 
   // accumulation mode (include/sart.h): SART_ACCUM_FIXED64 adds integers; the quanta are frozen by the first launch
   int accum_mode = SART_ACCUM_F64;
-  int headroom_bits = 30;
+  int headroom_bits = 27;
   bool quanta_frozen = false;
   int weight_exp = 0;                // q_w = 2^weight_exp
   int weight_sq_exp = 0;             // q_w2 = 2^weight_sq_exp
@@ -658,16 +661,18 @@ DevTables tables_of(sart_context* c) {
 
 // Upper bound of one ray's weight for the current setup, tables and flags (phase_b of sart_kernels.hip: reflectivity^2 x
 // cos(yaw) x conversion probability x absorption x window x gas x exposure): the SART_ACCUM_FIXED64 weight quantum is derived
-// from it.  Every factor is bounded generously (the conversion of a weight to quanta is exact up to 2^18 times the bound).
+// from it.  It is the scale of the largest weights, not a guarantee: the factor 1 + slope^2 of the path length (< 1.00003 for
+// rays from the Sun) and reflectivities extrapolated beyond the edge of their grid are left out, which is harmless - the
+// conversion of a weight to quanta stays exact up to 2^(51 - 63 + headroom) >= 2^4 times the bound, it only uses up headroom.
 double weight_bound_of(const sart_context* c, uint32_t flags) {
   const DevParams& P = c->params;
   double b = 1.0;
-  if (!(flags & SART_CF_IGNORE_REFLECTION)) { const double r = 2.0 * c->etab_max[3]; b *= r * r; }
+  if (!(flags & SART_CF_IGNORE_REFLECTION)) b *= c->etab_max[3] * c->etab_max[3];
   if (!(flags & SART_CF_IGNORE_CONV_PROB)) {
-    // vacuum: conv_k pathCB^2, pathCB <= lengthB sqrt(1 + slope^2) (:363-365); gas: |integral of exp((iq - Gamma/2) z)|^2 <=
-    // L^2 in natural units (axionMassforMagnet.nim:75-98).  (1 + slope^2) <= 2.
+    // vacuum: conv_k pathCB^2, pathCB ~ lengthB (:363-365); gas: |integral of exp((iq - Gamma/2) z)|^2 <= L^2 in natural
+    // units (axionMassforMagnet.nim:75-98)
     const double l_nat = P.length_b * P.gas_inv_hbarc_m;
-    b *= 2.0 * (P.stage_gas ? P.gas_term1 * l_nat * l_nat : P.conv_k * P.length_b * P.length_b);
+    b *= P.stage_gas ? P.gas_term1 * l_nat * l_nat : P.conv_k * P.length_b * P.length_b;
   }
   if (!(flags & SART_CF_IGNORE_DET_WINDOW)) b *= std::max(c->etab_max[0], c->etab_max[1]);
   if (!(flags & SART_CF_IGNORE_GAS_ABS)) b *= c->etab_max[2];
@@ -924,6 +929,59 @@ int sart_set_solar_tables(sart_context* c, const double* rcdf, const double* ecd
   return 0;
 }
 
+// The same tables as sart_set_solar_tables, built on the device from a device-resident emission-rate table
+// (csrc/sart_tables.hip: bit-identical to sart_host_build_cdfs + the guide construction above).
+int sart_set_solar_tables_device(sart_context* c, const double* em_rates_dev, const double* radii, const double* energies,
+                                 int32_t nR, int32_t nE) {
+  if (!c || !em_rates_dev || !radii || !energies) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (nR < 1 || nR > 2048) return fail(SART_ERR_INVALID_ARGUMENT, "n_radii must be in [1, 2048] (LDS-resident radius CDF)");
+  if (nE < 2 || nE > 65535) return fail(SART_ERR_INVALID_ARGUMENT, "n_energies must be in [2, 65535]");
+  SART_HIP(hipSetDevice(c->device));
+  SART_HIP(hipStreamSynchronize(c->stream));   // launches still in flight read the tables that are replaced below
+  DevBuf<double> d_radii, d_energies, d_row_sum;
+  DevBuf<uint32_t> d_status;
+  if (int rc = d_radii.upload(radii, nR)) return rc;
+  if (int rc = d_energies.upload(energies, nE)) return rc;
+  if (int rc = d_row_sum.resize(nR)) return rc;
+  if (int rc = d_status.resize(2)) return rc;
+  if (int rc = c->d_rcdf.resize(nR)) return rc;
+  if (int rc = c->d_ecdf.resize(static_cast<size_t>(nR) * (static_cast<size_t>(nE) + kEnergyCdfPad))) return rc;
+  if (int rc = c->d_rguide.resize(kRadiusGuide + 1)) return rc;
+  if (int rc = c->d_eguide.resize(static_cast<size_t>(nR) * kEnergyGuideEntries)) return rc;
+  c->have_solar = false;                       // until the new tables are known to be CDFs
+  launch_build_solar_tables(em_rates_dev, d_radii.p, d_energies.p, nR, nE, c->d_ecdf.p, d_row_sum.p, c->d_rcdf.p, c->d_rguide.p,
+                            c->d_eguide.p, d_status.p, c->stream);
+  SART_HIP(hipGetLastError());
+  uint32_t status[2] = {0, 0};
+  SART_HIP(hipMemcpyAsync(status, d_status.p, sizeof status, hipMemcpyDeviceToHost, c->stream));
+  SART_HIP(hipStreamSynchronize(c->stream));   // also keeps the temporaries alive until the kernels are done
+  if (status[0] & 1u) return fail(SART_ERR_INVALID_ARGUMENT, "emission table: a radius row does not give a CDF (negative / non-finite rates, or a row that sums to zero)");
+  if (status[0] & 2u) return fail(SART_ERR_INVALID_ARGUMENT, "emission table: fluxRadiusCDF is not monotone or does not end at 1.0");
+  c->radius_span = static_cast<int>(status[1]);
+  c->energies.assign(energies, energies + nE);
+  c->n_radii = nR;
+  c->n_energies = nE;
+  c->have_solar = true;
+  c->derived_dirty = true;
+  return 0;
+}
+
+// Host copies of the sampling tables the context holds (whichever entry point set them).
+int sart_get_solar_tables(sart_context* c, double* rcdf_out, double* ecdf_out, uint16_t* radius_guide_out, uint16_t* energy_guide_out) {
+  if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  if (!c->have_solar) return fail(SART_ERR_NOT_READY, "no solar tables");
+  SART_HIP(hipSetDevice(c->device));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  const size_t nR = static_cast<size_t>(c->n_radii), nE = static_cast<size_t>(c->n_energies);
+  if (rcdf_out) SART_HIP(hipMemcpy(rcdf_out, c->d_rcdf.p, nR * sizeof(double), hipMemcpyDeviceToHost));
+  if (ecdf_out)   // drop the pad behind every row
+    SART_HIP(hipMemcpy2D(ecdf_out, nE * sizeof(double), c->d_ecdf.p, (nE + kEnergyCdfPad) * sizeof(double), nE * sizeof(double), nR,
+                         hipMemcpyDeviceToHost));
+  if (radius_guide_out) SART_HIP(hipMemcpy(radius_guide_out, c->d_rguide.p, (kRadiusGuide + 1) * sizeof(uint16_t), hipMemcpyDeviceToHost));
+  if (energy_guide_out) SART_HIP(hipMemcpy(energy_guide_out, c->d_eguide.p, nR * kEnergyGuideEntries * sizeof(uint16_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int sart_set_reflectivity(sart_context* c, int32_t nC, int32_t nA, int32_t nE, double amin, double amax, double emin,
                           double emax, const double* data) {
   if (!c || !data) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1157,12 +1215,12 @@ int sart_set_accumulation_mode(sart_context* c, int mode, int headroom_bits) {
   if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (mode != SART_ACCUM_F64 && mode != SART_ACCUM_FIXED64) return fail(SART_ERR_INVALID_ARGUMENT, "unknown accumulation mode");
   if (headroom_bits != 0 && (headroom_bits < 16 || headroom_bits > 44))
-    return fail(SART_ERR_INVALID_ARGUMENT, "headroom_bits must be 0 (default 30) or in [16, 44]");
+    return fail(SART_ERR_INVALID_ARGUMENT, "headroom_bits must be 0 (default 27) or in [16, 44]");
   SART_HIP(hipSetDevice(c->device));
   SART_HIP(hipStreamSynchronize(c->stream));
   if (mode != c->accum_mode) c->d_acc_stale = true;
   c->accum_mode = mode;
-  c->headroom_bits = headroom_bits ? headroom_bits : 30;
+  c->headroom_bits = headroom_bits ? headroom_bits : 27;
   c->quanta_frozen = false;
   return 0;
 }

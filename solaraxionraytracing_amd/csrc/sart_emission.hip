@@ -358,6 +358,23 @@ int sart_emission_table(sart_context* ctx, const sart_solar_zone_t* zones, int32
   return 0;
 }
 
+/* AGSS09 zones -> emission table -> fluxRadiusCDF / diffFluxCDFs / guide tables, all on the device (BASELINE configs[4]:
+ * readOpacityFile.nim:745-860 followed by raytracer.nim:2670-2705 without the solar_model_dataframe.csv in between). */
+int sart_emission_to_solar_tables(sart_context* ctx, const sart_solar_zone_t* zones, int32_t n_radii, const double* energies_kev,
+                                  int32_t n_energies, const double* abs_coefs_dev, const sart_emission_params_t* params) {
+  if (!ctx || !zones || !energies_kev || !params || n_radii < 1 || n_energies < 2)
+    return sart::set_error(SART_ERR_INVALID_ARGUMENT, "sart_emission_to_solar_tables: bad argument");
+  EM_HIP(hipSetDevice(sart::context_device(ctx)));
+  Scoped d_em;
+  EM_HIP(hipMalloc(&d_em.p, (size_t)n_radii * n_energies * sizeof(double)));
+  if (int rc = sart_emission_table_device(ctx, zones, n_radii, energies_kev, n_energies, abs_coefs_dev, params,
+                                          static_cast<double*>(d_em.p), nullptr))
+    return rc;
+  std::vector<double> radii((size_t)n_radii);
+  for (int32_t r = 0; r < n_radii; ++r) radii[r] = zones[r].radius_frac;
+  return sart_set_solar_tables_device(ctx, static_cast<const double*>(d_em.p), radii.data(), energies_kev, n_radii, n_energies);
+}
+
 /* Duration of the last emission_table_kernel launch of this process in ms (HIP events on the launch stream). */
 double sart_emission_last_kernel_ms(void) { return g_last_kernel_ms; }
 

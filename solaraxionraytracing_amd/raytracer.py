@@ -41,6 +41,14 @@ class FullRaytraceSetup:
     flags: int = 0
     outpath: str = "out"
     meta: dict = field(default_factory=dict)
+    # emission="agss09-device": the sampling tables are made on the GPU by the context that uploads this setup (emission
+    # kernel -> CDFs -> guides, nothing crosses PCIe); fluxRadiusCDF / diffFluxCDFs stay None until fetch_solar_tables()
+    device_emission: dict | None = None
+
+    def fetch_solar_tables(self, tracer: "RayTracer"):
+        """Host copies of the CDFs a context built on the device (for the CPU oracle, plots, files)."""
+        self.fluxRadiusCDF, self.diffFluxCDFs = tracer.solar_tables()
+        return self
 
 
 def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_INGRIDIAXO,
@@ -53,6 +61,7 @@ def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_IN
     (BabyIAXO / InGridIAXO / vacuum / XMM).  ``emission`` / ``reflectivity`` choose the synthetic stand-ins of
     tables.py when the reference's own input files are not available."""
     setup = newFullSetup(experiment, detector, stage, telescope, flags, magnet_cfg, source_cfg, install_cfg)
+    dev_em = None
     if solar_model_csv is not None:
         radii, energies, em = tables.read_solar_model_csv(solar_model_csv)
         meta_em = "csv:" + solar_model_csv
@@ -68,11 +77,16 @@ def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_IN
         elif emission == "agss09":   # all analytic terms of readOpacityFile.nim on the AGSS09 model, made on the GPU (BASELINE configs[4])
             from . import emission as _emission
             em, meta_em = _emission.agss09_emission_table(n_radii, n_energies)[2], "E0-agss09-all-terms-gpu"
+        elif emission == "agss09-device":   # the same table, but it never leaves the GPU: RayTracer builds CDFs + guides on the device
+            from . import emission as _emission
+            zones = _emission.solar_zones(n_radii)
+            dev_em = {"zones": zones, "params": _emission.default_params()}
+            em, meta_em = None, "E0-agss09-all-terms-gpu-device-cdfs"
         elif emission == "flat":
             em, meta_em = tables.flat_emission_table(n_radii, n_energies), "E3-flat"
         else:
             raise ValueError("unknown emission table %r" % (emission,))
-    rcdf, ecdf = tables.build_cdfs(em, radii, energies)
+    rcdf, ecdf = tables.build_cdfs(em, radii, energies) if em is not None else (None, None)
     if isinstance(reflectivity, tables.ReflectivityGrid):
         refl, meta_r = reflectivity, "user"
     else:
@@ -93,7 +107,7 @@ def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_IN
             raise ValueError("unknown reflectivity %r" % (reflectivity,))
     det = tables.detector_tables()
     return FullRaytraceSetup(setup, np.ascontiguousarray(energies), rcdf, ecdf, refl, det, flags,
-                             meta={"emission": meta_em, "reflectivity": meta_r})
+                             meta={"emission": meta_em, "reflectivity": meta_r}, device_emission=dev_em)
 
 
 class RayTracer:
@@ -115,9 +129,15 @@ class RayTracer:
     def _upload(self, full: FullRaytraceSetup):
         lib, h = self.lib, self.handle
         _lib.check(lib.sart_set_setup(h, C.byref(full.setup)))
-        n_r, n_e = full.diffFluxCDFs.shape
-        _lib.check(lib.sart_set_solar_tables(h, _lib.as_dp(full.fluxRadiusCDF), _lib.as_dp(full.diffFluxCDFs),
-                                             _lib.as_dp(full.energies), n_r, n_e))
+        if full.device_emission is not None:
+            # BASELINE configs[4]'s front end without a host round trip: emission kernel -> CDFs -> guide tables on the device
+            de = full.device_emission
+            _lib.check(lib.sart_emission_to_solar_tables(h, de["zones"], len(de["zones"]), _lib.as_dp(full.energies),
+                                                         full.energies.size, None, C.byref(de["params"])))
+        else:
+            n_r, n_e = full.diffFluxCDFs.shape
+            _lib.check(lib.sart_set_solar_tables(h, _lib.as_dp(full.fluxRadiusCDF), _lib.as_dp(full.diffFluxCDFs),
+                                                 _lib.as_dp(full.energies), n_r, n_e))
         r = full.reflectivity
         n_c, n_a, n_er = r.data.shape
         _lib.check(lib.sart_set_reflectivity(h, n_c, n_a, n_er, r.angle_min, r.angle_max, r.energy_min, r.energy_max,
@@ -188,6 +208,38 @@ class RayTracer:
         """Raw FIXED64 accumulator (device) -> f64 accumulator layout (device; in place by default).  Asynchronous."""
         _lib.check(self.lib.sart_finalize_accumulator_device(self.handle, C.byref(params), C.c_void_p(acc_fixed_ptr),
                                                              C.c_void_p(out_f64_ptr if out_f64_ptr is not None else acc_fixed_ptr)))
+
+    def set_solar_tables_device(self, em_rates_device_ptr: int, radii: np.ndarray, energies: np.ndarray):
+        """sart_set_solar_tables_device: CDFs + guide tables built on the device from a device-resident emission table
+        [n_radii][n_energies] (``torch_tensor.data_ptr()``)."""
+        radii = np.ascontiguousarray(radii, dtype=np.float64)
+        energies = np.ascontiguousarray(energies, dtype=np.float64)
+        _lib.check(self.lib.sart_set_solar_tables_device(self.handle, C.c_void_p(em_rates_device_ptr), _lib.as_dp(radii),
+                                                         _lib.as_dp(energies), radii.size, energies.size))
+        self.full.energies = energies
+        self._n_radii_set = radii.size
+
+    def solar_tables(self, guides: bool = False):
+        """Host copies of (fluxRadiusCDF, diffFluxCDFs) as the context holds them; with ``guides`` also the library's
+        guide tables (radius guide [2049], energy guide [n_radii][3586], u16)."""
+        n_e = self.full.energies.size
+        n_r = self._n_radii()
+        rcdf, ecdf = np.empty(n_r), np.empty((n_r, n_e))
+        rg = np.empty(2049, dtype=np.uint16) if guides else None
+        eg = np.empty((n_r, 3586), dtype=np.uint16) if guides else None
+        _lib.check(self.lib.sart_get_solar_tables(self.handle, _lib.as_dp(rcdf), _lib.as_dp(ecdf),
+                                                  rg.ctypes.data_as(C.c_void_p) if guides else None,
+                                                  eg.ctypes.data_as(C.c_void_p) if guides else None))
+        return (rcdf, ecdf, rg, eg) if guides else (rcdf, ecdf)
+
+    def _n_radii(self) -> int:
+        if getattr(self, "_n_radii_set", None):
+            return self._n_radii_set
+        if self.full.device_emission is not None:
+            return len(self.full.device_emission["zones"])
+        if self.full.diffFluxCDFs is not None:
+            return self.full.diffFluxCDFs.shape[0]
+        raise RuntimeError("number of radii unknown")
 
     def set_stream(self, hip_stream: int | None):
         _lib.check(self.lib.sart_set_stream(self.handle, C.c_void_p(hip_stream) if hip_stream else None))

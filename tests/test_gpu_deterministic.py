@@ -195,4 +195,4 @@ def test_fixed64_errors():
         # larger headroom = coarser quantum
         rt.set_accumulation_mode("fixed64", headroom_bits=40)
         rt.trace_histogram(100_000, seed=1)
-        assert rt.fixed_quanta()["weight"] == q * 2.0 ** 10
+        assert rt.fixed_quanta()["weight"] == q * 2.0 ** 13     # default headroom: 27 bits

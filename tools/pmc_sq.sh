@@ -1,6 +1,7 @@
 #!/bin/bash
 # Sequencer-side counters of the ray kernel (instruction fetch, scalar unit, in-flight levels = latencies, FIFO stalls),
 # separate rocprofv3 --pmc passes.  Usage on the GPU box:  bash tools/pmc_sq.sh <tag> [bench args...] -> gpurun_out/pmc_sq_<tag>/
+set -e
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_sq_$TAG
@@ -16,7 +17,11 @@ i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
   if [ -n "$PMC_PASSES" ] && ! echo " $PMC_PASSES " | grep -q " $i "; then continue; fi
-  timeout -k 5 150 rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --profile-run --steps 2 --warmup 1 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+  if ! timeout -k 5 150 rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --profile-run --steps 2 --warmup 1 "$@" > $OUT/pass$i.log 2>&1; then
+    echo "pass $i FAILED ($P): tail of $OUT/pass$i.log" >&2
+    tail -5 $OUT/pass$i.log >&2
+    exit 1
+  fi
   echo "pass $i done: $P"
 done
 python3 - <<PY

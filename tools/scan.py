@@ -36,9 +36,10 @@ def main():
     ap.add_argument("--shard", default="bins", choices=["bins", "rays"],
                     help="bins: every scan point is a full run on one rank (BASELINE config 4); rays: every rank traces its "
                          "share of the ray ids of every point and the accumulators are reduced once per point (config 5)")
-    ap.add_argument("--emission", default=None, choices=["agss09", "primakoff", "legacy", "flat"],
-                    help="solar emission table; default: agss09 (all terms of readOpacityFile.nim on the AGSS09 model, made by the "
-                         "emission kernel) for the mass scan = BASELINE configs[4], primakoff (E1) for the angular scan")
+    ap.add_argument("--emission", default=None, choices=["agss09-device", "agss09", "primakoff", "legacy", "flat"],
+                    help="solar emission table; default: agss09-device (all terms of readOpacityFile.nim on the AGSS09 model; emission "
+                         "kernel -> CDFs -> guide tables without leaving the GPU, sart_emission_to_solar_tables) for the mass scan = "
+                         "BASELINE configs[4]; agss09 = the same table through the host; primakoff (E1) for the angular scan")
     ap.add_argument("--out", default="gpurun_out/scan.csv")
     ap.add_argument("--gpus", type=int, default=None,
                     help="number of ranks (one per GPU).  Stand-alone: N > 1 starts N copies of this script, one rank each; "
@@ -59,7 +60,7 @@ def main():
     if "SART_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["SART_BENCH_DEVICE"])
     n_rays = int(args.rays)
-    emission = args.emission or ("agss09" if args.mode == "mass" else "primakoff")
+    emission = args.emission or ("agss09-device" if args.mode == "mass" else "primakoff")
     if args.mode == "angular":
         full = sa.initFullSetup(emission=emission)
         full.setup.chip_x_max = full.setup.chip_y_max = args.chip       # ChipXMax = 100 mm alternative (raytracer.nim:262-264)
