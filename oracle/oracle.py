@@ -105,6 +105,10 @@ def load(variant: str = "f64") -> C.CDLL:
         lib.sart_oracle_vector_after_mirror.restype = None
         lib.sart_oracle_mirror_angle_deg.argtypes = [_dp, _dp, _dp, _d, _d, _d, _d, C.c_int]
         lib.sart_oracle_mirror_angle_deg.restype = _d
+        lib.sart_oracle_trace_records_uniforms.argtypes = [C.POINTER(Setup), C.POINTER(OracleTables), C.c_uint32, _dp, C.c_int64, vp, C.c_int]
+        lib.sart_oracle_trace_records_uniforms.restype = C.c_int
+        lib.sart_oracle_mass_attenuation.argtypes = [_d]
+        lib.sart_oracle_mass_attenuation.restype = _d
         lib.sart_oracle_length_telescope.argtypes = [C.POINTER(Setup)]
         lib.sart_oracle_length_telescope.restype = _d
         _libs[variant] = lib
@@ -153,6 +157,17 @@ class Oracle:
         p = self.params(n_rays, seed, ray_id_offset, flags)
         s = setup if setup is not None else self.full.setup
         self.lib.sart_oracle_trace_records(C.byref(s), C.byref(self.tables), C.byref(p), buf.ctypes.data_as(C.c_void_p), n_threads)
+        return buf
+
+    def trace_records_uniforms(self, uniforms, flags=None, n_threads=0, setup=None) -> np.ndarray:
+        """Records of the rays whose six uniforms are the rows of ``uniforms`` [n][6] (draw order of SURVEY App. B)."""
+        u = np.ascontiguousarray(uniforms, dtype=np.float64)
+        assert u.ndim == 2 and u.shape[1] == 6
+        buf = np.zeros(u.shape[0], dtype=AXION_DTYPE)
+        s = setup if setup is not None else self.full.setup
+        fl = self.full.flags if flags is None else flags
+        self.lib.sart_oracle_trace_records_uniforms(C.byref(s), C.byref(self.tables), fl, u.ctypes.data_as(_dp), u.shape[0],
+                                                    buf.ctypes.data_as(C.c_void_p), n_threads)
         return buf
 
     def trace_records_nim_stream(self, n_rays, seed=299792458, ray_id_offset=0, flags=None, init_variant=1, setup=None) -> np.ndarray:

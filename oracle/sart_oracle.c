@@ -1019,6 +1019,8 @@ double sart_oracle_intensity_suppression2(double e, double dm, double dp, double
   return (double)intensity_suppression2_r(e, dm, dp, p, tm, tp);
 }
 double sart_oracle_length_telescope(const sart_setup_t* s) { return (double)length_telescope_r(s); }
+/* exp(logMassAttenuation(E)) in cm^2 / g, axionMassforMagnet.nim:70-73 (a fit to mass_attenuation_nist_data.txt) */
+double sart_oracle_mass_attenuation(double energy_kev) { return (double)M_EXP(log_mass_attenuation((real)energy_kev)); }
 
 /* ------------------------------------------------------------------------------------------
  * traceAxionWrapper (:2223-2244) and the accumulation that follows (:818-842, :2252-2257, :2800)
@@ -1044,6 +1046,22 @@ int sart_oracle_trace_records(const sart_setup_t* setup, const sart_oracle_table
     memset(&res, 0, sizeof res); /* newSeq[Axion] zero-initialises (:2760) */
     sart_oracle_uniforms(params->seed, params->ray_id_offset + (uint64_t)i, u);
     sart_oracle_trace_axion(&res, setup, tables, params->flags, u);
+    ax_buf[i] = res;
+  }
+  return nt;
+}
+
+/* The records of n rays whose six uniforms are GIVEN (u[n][6], draw order of SURVEY App. B: :433, :434, :436, :418, :419,
+ * :464) instead of drawn: what tests/golden/uniform_keyed_*.npz store, so that those fixtures pin the physics of
+ * traceAxion whatever maps (seed, ray id) to uniforms. */
+int sart_oracle_trace_records_uniforms(const sart_setup_t* setup, const sart_oracle_tables_t* tables, uint32_t flags,
+                                       const double* u, int64_t n, sart_axion_t* ax_buf, int n_threads) {
+  int nt = resolve_threads(n_threads);
+#pragma omp parallel for num_threads(nt) schedule(static, 4096)
+  for (int64_t i = 0; i < n; ++i) {
+    sart_axion_t res;
+    memset(&res, 0, sizeof res);
+    sart_oracle_trace_axion(&res, setup, tables, flags, u + 6 * i);
     ax_buf[i] = res;
   }
   return nt;

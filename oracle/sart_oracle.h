@@ -52,6 +52,10 @@ int sart_oracle_trace_records(const sart_setup_t* setup, const sart_oracle_table
                               const sart_trace_params_t* params, sart_axion_t* ax_buf,
                               int n_threads);
 
+/* Records of n rays with GIVEN uniforms u[n][6] (draw order of SURVEY App. B). Returns threads used. */
+int sart_oracle_trace_records_uniforms(const sart_setup_t* setup, const sart_oracle_tables_t* tables, uint32_t flags,
+                                       const double* u, int64_t n, sart_axion_t* ax_buf, int n_threads);
+
 /* ---- the reference's own random stream (for fixtures produced by a Nim build of the reference) ----------------------
  * Nim std/random = xoroshiro128+ (rotations 55 / 14 / 36), ONE global stream seeded by `randomize(299792458)`
  * (raytracer.nim:276); rand(1.0) = 52 mantissa bits of next() under the exponent of 1.0, minus 1.0.
@@ -85,6 +89,7 @@ double sart_oracle_axion_conversion_prob2(double m_a, double energy_kev, double 
 double sart_oracle_intensity_suppression2(double energy_kev, double distance_magnet_m,
                                           double distance_pipe_m, double pressure,
                                           double temp_magnet, double temp_pipe);
+double sart_oracle_mass_attenuation(double energy_kev);
 double sart_oracle_bilinear(const double* z, int32_t nx, int32_t ny, double xmin, double xmax,
                             double ymin, double ymax, double x, double y);
 double sart_oracle_linear1d(const double* xs, const double* ys, int32_t n, double x);

@@ -26,7 +26,7 @@ void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectr
                            double q_w2, double q_pos, double q_refl, hipStream_t stream);
 int histogram_block_of(int variant);
 void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
-                          hipStream_t stream);
+                          hipStream_t stream, const double* uniforms_dev);
 int records_block();
 int histogram_blocks_per_cu(int variant);
 void launch_build_solar_tables(const double* em_dev, const double* radii_dev, const double* energies_dev, int n_radii, int n_energies,
@@ -1010,7 +1010,7 @@ int sart_set_detector_tables(sart_context* c, const double* sbx, const double* s
   return 0;
 }
 
-int sart_trace_records_device(sart_context* c, const sart_trace_params_t* p, sart_axion_t* out_dev) {
+static int trace_records_impl(sart_context* c, const sart_trace_params_t* p, sart_axion_t* out_dev, const double* uniforms_dev) {
   if (!c || !out_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
   SART_HIP(hipSetDevice(c->device));
   if (int rc = refresh_derived(c)) return rc;
@@ -1022,9 +1022,30 @@ int sart_trace_records_device(sart_context* c, const sart_trace_params_t* p, sar
   {
     TimedLaunch tl(c);
     launch_trace_records(c->hot, c->hotb, c->d_blob.p, a, out_dev,
-                         grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_rec, records_block()), c->stream);
+                         grid_for(a.n_rays, c->n_cu, c->blocks_per_cu_rec, records_block()), c->stream, uniforms_dev);
   }
   SART_HIP(hipGetLastError());
+  return 0;
+}
+
+int sart_trace_records_device(sart_context* c, const sart_trace_params_t* p, sart_axion_t* out_dev) {
+  return trace_records_impl(c, p, out_dev, nullptr);
+}
+
+// Test entry (not in sart.h): the records of params->n_rays rays whose six uniforms are GIVEN (uniforms_host[n][6], draw order
+// of SURVEY App. B) instead of drawn from the Philox stream: tests/golden/uniform_keyed_*.npz pin the physics independently
+// of the seed -> uniform mapping.  Host buffers, blocking.
+__attribute__((visibility("default"))) int sart_internal_trace_records_uniforms(sart_context* c, const sart_trace_params_t* p,
+                                                                               const double* uniforms_host, sart_axion_t* out_host) {
+  if (!c || !p || !uniforms_host || !out_host) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (p->n_rays == 0) return 0;
+  SART_HIP(hipSetDevice(c->device));
+  DevBuf<double> d_u;
+  if (int rc = d_u.upload(uniforms_host, 6 * p->n_rays)) return rc;
+  if (int rc = c->d_rec.resize(p->n_rays)) return rc;
+  if (int rc = trace_records_impl(c, p, c->d_rec.p, d_u.p)) return rc;
+  SART_HIP(hipMemcpyAsync(out_host, c->d_rec.p, p->n_rays * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->stream));
+  SART_HIP(hipStreamSynchronize(c->stream));
   return 0;
 }
 

@@ -66,6 +66,10 @@ __device__ __forceinline__ uint32_t word_of(const U4& b, uint32_t k) {
   return k == 0u ? b.x : (k == 1u ? b.y : (k == 2u ? b.z : b.w));
 }
 
+// Assembly comment at the head of a pipeline stage: tools/isa_histogram.py attributes the instructions of the compiler's
+// listing to stages by these markers.  No instruction, no operands, no clobbers.
+#define SART_STAGE_MARK(name) asm volatile("; SART_STAGE " name)
+
 // Lane mask of a predicate.  HIP's __ballot() materialises the predicate as 0 / 1 and compares again (two VALU
 // instructions); the builtin takes the compare's lane mask as it is.
 __device__ __forceinline__ uint64_t ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
@@ -131,70 +135,80 @@ __device__ __forceinline__ void sincos_turns(double u, const double* __restrict_
 // asin for the grazing angles of the path (|x| < ~0.03): odd Taylor series
 // asin x = x + x^3/6 + 3x^5/40 + 5x^7/112 + 35x^9/1152 + 63x^11/2816 + 231x^13/13312 + 143x^15/10240,
 // truncation error < 1e-19 below 0.06; the library function outside.
+// The series is evaluated unconditionally (straight-line code the scheduler can interleave with its surroundings); the
+// library call is a divergent alternative that a wave skips when no lane needs it.
 __device__ __forceinline__ double asin_small(double x, double x2) {   // x2 = x^2 (the caller has it)
-  if (fabs(x) < 0.06) {
-    double p = 0.01396484375;                      // 143/10240
-    p = HORNER(p, x2, 0.017352764423076924);       // 231/13312
-    p = HORNER(p, x2, 0.022372159090909092);       // 63/2816
-    p = HORNER(p, x2, 0.030381944444444444);       // 35/1152
-    p = HORNER(p, x2, 0.044642857142857144);       // 5/112
-    p = HORNER(p, x2, 0.075);                      // 3/40
-    p = HORNER(p, x2, 0.16666666666666666);        // 1/6
-    return fma(x * x2, p, x);
+  double p = 0.01396484375;                        // 143/10240
+  p = HORNER(p, x2, 0.017352764423076924);         // 231/13312
+  p = HORNER(p, x2, 0.022372159090909092);         // 63/2816
+  p = HORNER(p, x2, 0.030381944444444444);         // 35/1152
+  p = HORNER(p, x2, 0.044642857142857144);         // 5/112
+  p = HORNER(p, x2, 0.075);                        // 3/40
+  p = HORNER(p, x2, 0.16666666666666666);          // 1/6
+  double r = fma(x * x2, p, x);
+  if (!(fabs(x) < 0.06)) {
+    asm volatile("; rare: asin outside the series' range");
+    r = asin(x);
   }
-  return asin(x);
+  return r;
 }
 
 // atan for ray slopes (|x| < 0.05): alternating series to x^15; library outside.
 __device__ __forceinline__ double atan_small(double x) {
-  if (fabs(x) < 0.05) {
-    const double x2 = x * x;
-    double p = -1.0 / 15.0;
-    p = fma(p, x2, 1.0 / 13.0);
-    p = fma(p, x2, -1.0 / 11.0);
-    p = fma(p, x2, 1.0 / 9.0);
-    p = fma(p, x2, -1.0 / 7.0);
-    p = fma(p, x2, 1.0 / 5.0);
-    p = fma(p, x2, -1.0 / 3.0);
-    return fma(x * x2, p, x);
+  const double x2 = x * x;
+  double p = -1.0 / 15.0;
+  p = fma(p, x2, 1.0 / 13.0);
+  p = fma(p, x2, -1.0 / 11.0);
+  p = fma(p, x2, 1.0 / 9.0);
+  p = fma(p, x2, -1.0 / 7.0);
+  p = fma(p, x2, 1.0 / 5.0);
+  p = fma(p, x2, -1.0 / 3.0);
+  double r = fma(x * x2, p, x);
+  if (!(fabs(x) < 0.05)) {
+    asm volatile("; rare: atan outside the series' range");
+    r = atan(x);
   }
-  return atan(x);
+  return r;
 }
 
 // cos on |x| <= 1 by its Taylor series to x^20 (error < 1e-19 there); library outside.
 __device__ __forceinline__ double cos_small(double x) {
-  if (fabs(x) <= 1.0) {
-    const double x2 = x * x;
-    double p = 4.110317623312165e-19;          //  1/20!
-    p = fma(p, x2, -1.5619206968586225e-16);   // -1/18!
-    p = fma(p, x2, 4.779477332387385e-14);     //  1/16!
-    p = fma(p, x2, -1.1470745597729725e-11);   // -1/14!
-    p = fma(p, x2, 2.08767569878681e-09);      //  1/12!
-    p = fma(p, x2, -2.755731922398589e-07);    // -1/10!
-    p = fma(p, x2, 2.48015873015873e-05);      //  1/8!
-    p = fma(p, x2, -0.001388888888888889);     // -1/6!
-    p = fma(p, x2, 0.041666666666666664);      //  1/4!
-    p = fma(p, x2, -0.5);
-    return fma(p, x2, 1.0);
+  const double x2 = x * x;
+  double p = 4.110317623312165e-19;            //  1/20!
+  p = fma(p, x2, -1.5619206968586225e-16);     // -1/18!
+  p = fma(p, x2, 4.779477332387385e-14);       //  1/16!
+  p = fma(p, x2, -1.1470745597729725e-11);     // -1/14!
+  p = fma(p, x2, 2.08767569878681e-09);        //  1/12!
+  p = fma(p, x2, -2.755731922398589e-07);      // -1/10!
+  p = fma(p, x2, 2.48015873015873e-05);        //  1/8!
+  p = fma(p, x2, -0.001388888888888889);       // -1/6!
+  p = fma(p, x2, 0.041666666666666664);        //  1/4!
+  p = fma(p, x2, -0.5);
+  double r = fma(p, x2, 1.0);
+  if (!(fabs(x) <= 1.0)) {
+    asm volatile("; rare: cos outside the series' range");
+    r = cos(x);
   }
-  return cos(x);
+  return r;
 }
 
 // cos(ya) for the yaw angle ya = -deg(atan(t)) of a ray with slope t, the degree value taken as radians - sic
 // (:1598, :2101-2115): cos((180 / pi) atan t) as ONE even power series in t (composed at 60 digits, mpmath), valid for
 // |t| < 0.006 (every ray from the Sun: |slope| < 4.7e-3), truncation error < 7e-18; the two-step evaluation outside.
 __device__ __forceinline__ double cos_yaw_of_slope(double t) {
-  if (fabs(t) < 0.006) {
-    const double x = t * t;
-    double p = 2976939695167.2104;                // t^12
-    p = HORNER(p, x, -112889008417.68803);        // t^10
-    p = HORNER(p, x, 2979383355.295581);          // t^8
-    p = HORNER(p, x, -49735946.89381117);         // t^6
-    p = HORNER(p, x, 450128.3326032301);          // t^4
-    p = HORNER(p, x, -1641.403175005872);         // t^2 : -(180 / pi)^2 / 2
-    return fma(p, x, 1.0);
+  const double x = t * t;
+  double p = 2976939695167.2104;                  // t^12
+  p = HORNER(p, x, -112889008417.68803);          // t^10
+  p = HORNER(p, x, 2979383355.295581);            // t^8
+  p = HORNER(p, x, -49735946.89381117);           // t^6
+  p = HORNER(p, x, 450128.3326032301);            // t^4
+  p = HORNER(p, x, -1641.403175005872);           // t^2 : -(180 / pi)^2 / 2
+  double r = fma(p, x, 1.0);
+  if (!(fabs(t) < 0.006)) {
+    asm volatile("; rare: slope outside the composed series' range");
+    r = cos_small(-atan_small(t) * 57.29577951308232);
   }
-  return cos_small(-atan_small(t) * 57.29577951308232);
+  return r;
 }
 
 // The table pointers of a launch are read from the LDS copy of the parameter blob, where the compiler cannot see
@@ -408,15 +422,17 @@ __device__ __forceinline__ EnergyDev load_energy_row(const HotB& HB, int e_idx) 
 // scaled form, one FMA each: with u = c^2 - 1/2, v = u^2 - 1/8, w = v^2 - 1/128, z = w^2 - 1/32768 the doublings give
 // T2 = 2u, T4 = 8v, T8 = 128w, T16 = 32768 z (powers of two: exact), so the function returns z and the host stores the
 // threshold divided by 32768 (sart_api.hip: hot_of).
+// The addends are scalar operands (HORNER: v_fma_f64 v, v, v, s): as literals LLVM copies each of them into the destination
+// of a two-address v_fmac_f64 first, two v_mov_b32 per step (16 of the vector instructions of a phase-A pass).
 __device__ __forceinline__ double spoke_measure(int n, double c) {
   if (n == 16) {
-    const double u = fma(c, c, -0.5);
-    const double v = fma(u, u, -0.125);
-    const double w = fma(v, v, -0.0078125);
-    return fma(w, w, -1.0 / 32768.0);
+    const double u = HORNER(c, c, -0.5);
+    const double v = HORNER(u, u, -0.125);
+    const double w = HORNER(v, v, -0.0078125);
+    return HORNER(w, w, -1.0 / 32768.0);
   }
-  const double t3 = c * fma(4.0 * c, c, -3.0);
-  return fma(2.0 * t3, t3, -1.0);
+  const double t3 = c * HORNER(4.0 * c, c, -3.0);
+  return HORNER(2.0 * t3, t3, -1.0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -435,25 +451,19 @@ __device__ __forceinline__ double spoke_measure(int n, double c) {
 // ROT: telescope rotation known at compile time (0 / 1) or read at run time (-1).
 // ZEXT: st.path_cb carries the z extent of the path in the magnetic field instead of its length (phase B of the vacuum,
 // unrotated specialisation multiplies pathCB^2 by 1 + slope^2 itself and needs no square root here).
+// The six uniforms of a ray in the reference's draw order: solar source u0, u1 -> angles of the solar point
+// (:433-434), u2 -> radius CDF (:436), u3 -> disc radius (:418), u4 -> disc angle (:419), u5 -> energy CDF (:464).
+struct Uniforms { double u0, u1, u2, u3, u4, u5; };
+
 template <bool FAST, int ROT, bool ZEXT>
-__device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const LdsTables& L, uint32_t seed_lo,
-                                        uint32_t seed_hi, uint64_t ray_id, uint32_t u3_hi, RayState& st, bool& sampled,
-                                        bool& reached) {
+__device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, const LdsTables& L, const Uniforms& U, RayState& st,
+                                             bool& sampled, bool& reached) {
   static_assert(!ZEXT || (FAST && ROT == 0), "the z-extent form needs the magnet-frame slopes in phase B");
   const bool cfg_test = FAST ? false : (H.test_active != 0);
   const bool cfg_rotated = (ROT < 0) ? (H.rotated != 0) : (ROT != 0);
   const bool cfg_holes = FAST ? false : (H.telescope_kind == SART_TK_XMM && H.inner_blocks < 0);
-  const uint32_t id_lo = (uint32_t)ray_id, id_hi = (uint32_t)(ray_id >> 32);
-  // The six uniforms of a ray from TWO counter blocks (256 bits) + its word of the shared stream (sart_oracle_uniforms):
-  // the two CDF draws (u2, u5) and the disc angle (u4) have 52 random mantissa bits, the two angles of the solar point
-  // (u0, u1) and the disc radius (u3) 44: a high word of their own + the 12 bits the 52-bit fills leave over in a word.
-  const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, seed_lo, seed_hi);
-  const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, seed_lo, seed_hi);
-  const double u2 = u52(b0.x, b0.y);
-  st.u5 = u52(b0.z, b0.w);
-  const double u0 = u52(b1.x, b0.y << 20), u1 = u52(b1.y, b0.w << 20);
-  const double u4 = u52(b1.z, b1.w);
-  const double u3 = u52(u3_hi, b1.w << 20);   // u3_hi = word ray_id of the shared stream
+  const double u0 = U.u0, u1 = U.u1, u2 = U.u2, u3 = U.u3, u4 = U.u4;
+  st.u5 = U.u5;
   st.r_idx = 0;
 
   bool ok = true;
@@ -485,7 +495,9 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
     // getRandomPointOnDisk (:412-422)
     double sp, cp;
     sincos_turns<2>(u4, L.sincos, K, &sp, &cp);
-    const double rr = H.radius_cb * fsqrt(u3);
+    // + 1e-300: exact no-op unless u3 == 0 (one ray in 2^44: its point lands 1e-150 R from the axis instead of on it); saves
+    // the zero / negative special-casing of fsqrt() (two compares, four selects) in every pass
+    const double rr = H.radius_cb * fsqrt_pos(u3 + 1e-300);
     ex = cp * rr;
     ey = sp * rr;
     const double inv_dz = frcp(H.length_b - oz);
@@ -546,7 +558,9 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   const double x1 = fma(H.dz1, sx, ex), y1 = fma(H.dz1, sy, ey);
   const double x2 = fma(H.dz2, sx, ex), y2 = fma(H.dz2, sy, ey);
   const double x3 = fma(H.dz3, sx, ex), y3 = fma(H.dz3, sy, ey);
-  ok = ok && (fma(x1, x1, y1 * y1) < H.radius_cb_sq) && (fma(x2, x2, y2 * y2) < H.pipe1_radius_sq) &&
+  // bitwise on purpose: `&&` keeps the short-circuit as three nested divergent regions (exec-mask bookkeeping around eight
+  // f64 operations that nearly every lane needs anyway)
+  ok = ok & (fma(x1, x1, y1 * y1) < H.radius_cb_sq) & (fma(x2, x2, y2 * y2) < H.pipe1_radius_sq) &
        (fma(x3, x3, y3 * y3) < H.pipe1_radius_sq);
   reached = ok;
 
@@ -597,8 +611,9 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
     const double c_ent = X0 * inv_radial;
     const double xs = fma(H.spider_z, tsx, X0), ys = fma(H.spider_z, tsy, Y0);
     const double c_sp = xs * frsq(fma(xs, xs, ys * ys));
-    const bool spoke = (spoke_measure(H.spoke_n, c_ent) >= H.spoke_cos_thr) || (spoke_measure(H.spoke_n, c_sp) >= H.spoke_cos_thr);
-    bool blocked = inner || ring || spoke;
+    // (bitwise: the second test is needed by every lane the first one does not block - no divergent region around it)
+    const bool spoke = (spoke_measure(H.spoke_n, c_ent) >= H.spoke_cos_thr) | (spoke_measure(H.spoke_n, c_sp) >= H.spoke_cos_thr);
+    bool blocked = inner | ring | spoke;
     if (cfg_holes) {
       // hole loop (:1675-1688) with lineIntersectsObject (:494-527) on the entrance plane; replaces the
       // verdict for rays inside the inner disc
@@ -630,11 +645,11 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
       }
       if (inner) blocked = res;
     }
-    ok = ok && !blocked;
+    ok = ok & !blocked;
   }
 
   // ---- shell selection (:1932-1957) ----
-  ok = ok && !(radial > H.r1_last);
+  ok = ok & !(radial > H.r1_last);
   // R1 ascending: the nearest shell above is the first j with R1[j] > radial; the look-up cell (narrower
   // than any shell spacing) gives it up to one step
   const int nS = H.n_shells;
@@ -645,13 +660,34 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   const double b_r1 = L.shells[jb].r1, b_ro = L.shells[jb].r1_outer;
   const bool step = (j0 < nS) & !(c_r1 > radial);
   const int j = j0 + (step ? 1 : 0);
-  ok = ok && (j < nS);   // radial == R1[last] exactly (measure zero; the reference then uses a zero shell)
+  ok = ok & (j < nS);    // radial == R1[last] exactly (measure zero; the reference then uses a zero shell)
   // glass front (:1942-1944): only the shell just below the selected one can contain radial (thickness < spacing, checked on
   // the host): the cell's shell after a step, the one below it otherwise
   const double g_r1 = step ? c_r1 : b_r1, g_ro = step ? c_ro : b_ro;
-  ok = ok && !(j > 0 && radial > g_r1 && radial < g_ro);
+  ok = ok & !((j > 0) & (radial > g_r1) & (radial < g_ro));
   st.shell = min(j, nS - 1);
   return ok;
+}
+
+// Phase A of the ray with global id `ray_id`: its six uniforms from TWO Philox counter blocks (256 bits) + its word of the
+// shared stream (sart_oracle_uniforms): the two CDF draws (u2, u5) and the disc angle (u4) have 52 random mantissa bits, the
+// two angles of the solar point (u0, u1) and the disc radius (u3) 44: a high word of their own + the 12 bits the 52-bit fills
+// leave over in a word.  u3_hi = word ray_id of the shared stream.
+template <bool FAST, int ROT, bool ZEXT>
+__device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const LdsTables& L, uint32_t seed_lo,
+                                        uint32_t seed_hi, uint64_t ray_id, uint32_t u3_hi, RayState& st, bool& sampled,
+                                        bool& reached) {
+  const uint32_t id_lo = (uint32_t)ray_id, id_hi = (uint32_t)(ray_id >> 32);
+  const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, seed_lo, seed_hi);
+  const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, seed_lo, seed_hi);
+  Uniforms U;
+  U.u2 = u52(b0.x, b0.y);
+  U.u5 = u52(b0.z, b0.w);
+  U.u0 = u52(b1.x, b0.y << 20);
+  U.u1 = u52(b1.y, b0.w << 20);
+  U.u4 = u52(b1.z, b1.w);
+  U.u3 = u52(u3_hi, b1.w << 20);
+  return phase_a_core<FAST, ROT, ZEXT>(H, P, L, U, st, sampled, reached);
 }
 
 // Results of phase B for one ray (record mode needs all of them; histogram mode a few).
@@ -740,7 +776,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const double Q1 = fma(X1, X1, Y1 * Y1);
   double z2;
   const bool hit2 = pick_root(A1 - sh.m2_k, D1 + sh.m2_hb, Q1 - sh.m2_cc, sh.m2_zlo, sh.m2_zhi, z2);
-  live = live && hit2;                        // almostEqual(z1, z2) (:2055)
+  live = live & hit2;                         // almostEqual(z1, z2) (:2055)
   if (!hit2) z2 = sh.m2_zlo;
   const double m2x = fma(z2, s2x, X1), m2y = fma(z2, s2y, Y1);
   const double n2z = wolter ? sh.n2_r3t * fma(2.0 * (P.l_mirror - z2), sh.n2_invF, 1.0)
@@ -820,11 +856,11 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   // ---- geometry of the detector window / chip (:2138-2147) and of the window strips (:2149-2187: rotateAroundZ by theta,
   // strips along x): none of it needs the gathers, so it runs before they are consumed ----
   const double rdet2 = fma(pdx, pdx, pdy * pdy);
-  const bool on_chip = !(!(flags & SART_CF_IGNORE_DET_WINDOW) && rdet2 > P.radius_window_sq) &&
-                       !(fabs(pdx) > P.chip_cx || fabs(pdy) > P.chip_cy);
+  const bool on_chip = !((!(flags & SART_CF_IGNORE_DET_WINDOW)) & (rdet2 > P.radius_window_sq)) &
+                       !((fabs(pdx) > P.chip_cx) | (fabs(pdy) > P.chip_cy));
   const double yt = fabs(fma(pdy, P.theta_c, -pdx * P.theta_s));
   bool in_strip = false;
-  for (int i = 0; i < n_half_strips; ++i) in_strip = in_strip || (yt > P.strip_lo[i] && yt < P.strip_hi[i]);
+  for (int i = 0; i < n_half_strips; ++i) in_strip = in_strip | ((yt > P.strip_lo[i]) & (yt < P.strip_hi[i]));
 
   // ---- weights (:2116-2128) ----
   const double path_cb = st.path_cb;
@@ -864,7 +900,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const bool till_window = live & (weight != 0.0);
   out.m_till = ballot64(till_window);
   if (RECORDS && till_window) rec->passedTillWindow = 1;
-  live = live && on_chip;
+  live = live & on_chip;
 
   const double trans_window = (n_half_strips > 0) ? (in_strip ? en.t_strongback : en.t_window) : 0.0;
   const uint8_t kind_w = in_strip ? SART_MK_SI : SART_MK_SI3N4;
@@ -1092,6 +1128,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
 
   // stage A1 for the ray with id id_base + rel (valid lanes only count); u3_hi = its word of the shared stream
   auto run_phase_a = [&](uint32_t rel, bool valid, uint32_t u3_hi) {
+    SART_STAGE_MARK("A1");
     RayState st;
     bool sampled = false, reached = false;
     HotA Hl;
@@ -1108,6 +1145,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     const uint32_t cnt = (uint32_t)__popcll(mask);
     n_shell += cnt;
     if (alive) {
+      asm volatile("; hot: ring 1 write");
       const uint32_t slot = (t1 + prefix_of(mask)) % kQueue;
       Q.w[wave].X0[slot] = st.X0; Q.w[wave].Y0[slot] = st.Y0;
       Q.w[wave].tsx[slot] = st.tsx; Q.w[wave].tsy[slot] = st.tsy;
@@ -1119,6 +1157,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   };
 
   auto run_phase_b = [&](uint32_t n_valid) {
+    SART_STAGE_MARK("B");
     RayState st;
     const bool valid = (uint32_t)lane < n_valid;
     const uint32_t slot = (h1 + (uint32_t)lane) % kQueue;
@@ -1158,6 +1197,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     n_till += (uint32_t)__popcll(out.m_till);
     n_passed += (uint32_t)__popcll(out.m_passed);
     if (out.passed) {
+      SART_STAGE_MARK("ACC");
       // the launch's image parameters, re-read from the kernel arguments (scalar registers, short-lived)
       TraceArgs Al;
       reload_kernarg(Al, offsetof(HistKernArgs, A));
@@ -1252,9 +1292,14 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
 #endif
   for (;;) {
     const bool have_new = chunk < n_chunks;   // wave-uniform
+    SART_STAGE_MARK("LOOP");
     if (have_new) {
+      SART_STAGE_MARK("A0");
       SART_STAMP(ts_a0);
-      if (pass == 0u) stream = stream_block(((first_chunk + (uint64_t)chunk) << 6) + (uint64_t)lane, A.seed_lo, A.seed_hi);
+      if (pass == 0u) {
+        asm volatile("; hot x0.25: one block of the shared word stream per four passes");
+        stream = stream_block(((first_chunk + (uint64_t)chunk) << 6) + (uint64_t)lane, A.seed_lo, A.seed_hi);
+      }
       const uint32_t w = word_of(stream, pass);                      // high word of u3 (:418) of this pass' ray
       const uint32_t rel = ((chunk << 8) + pass) + lane4;
       if (early_reject) {
@@ -1281,6 +1326,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const uint64_t mask = valid_m & ~dead_m;
 #endif
         if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
+          asm volatile("; hot: ring 0 write");
           const uint32_t slot = (t0 + prefix_of(mask)) % kQueue;
           Q.w[wave].ray[slot] = rel;
           Q.w[wave].u3hi[slot] = w;
@@ -1294,6 +1340,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       ring_sync();
       SART_SPAN(cyc_a0, ts_a0);
     }
+    SART_STAGE_MARK("LOOP");
     if (early_reject) {
       // ---- stage A1 on a full wave of A0 survivors (or on the remainder once the input is exhausted) ----
       const uint32_t n0 = t0 - h0;
@@ -1312,6 +1359,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       }
     }
     // ---- stage B on a full wave of A1 survivors (or on the remainder at the very end) ----
+    SART_STAGE_MARK("LOOP");
     const uint32_t n1 = t1 - h1;
     const bool draining = !have_new & (t0 == h0);
     if ((n1 >= 64u) | (draining & (n1 > 0u))) {
@@ -1323,6 +1371,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     if (draining & (t1 == h1)) break;
   }
 
+  SART_STAGE_MARK("EPILOGUE");
   // flush of the LDS image tile: one global atomic per non-empty tile pixel and workgroup
   if (A.tile_n > 0) {
     __syncthreads();   // every wave of the workgroup has left the loop (uniform condition: kernel argument)
@@ -1490,8 +1539,12 @@ __global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in
 
 // Literal drop-in for traceAxionWrapper: one Axion record per ray, in ray order (no compaction).
 constexpr int kRecBlock = 256;
+// `uniforms` != nullptr (sart_internal_trace_records_uniforms, a test entry): ray i takes its six uniforms from
+// uniforms[6 i .. 6 i + 5] (draw order of SURVEY App. B) instead of from its Philox blocks - physics fixtures keyed by
+// explicit uniforms survive a re-mapping of the random stream.
 __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
-                                                                   sart_axion_t* __restrict__ out, HotB HB) {
+                                                                   sart_axion_t* __restrict__ out, HotB HB,
+                                                                   const double* __restrict__ uniforms) {
   __shared__ TablesLds S;
   __shared__ DevBlob B;
   {
@@ -1510,8 +1563,15 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
     RayState st;
     bool sampled, reached;
     const uint64_t ray_id = A.ray_id_offset + i;
-    const uint32_t u3_hi = word_of(stream_block(ray_id >> 2, A.seed_lo, A.seed_hi), (uint32_t)ray_id & 3u);
-    const bool alive = phase_a<false, -1, false>(H, P, L, A.seed_lo, A.seed_hi, ray_id, u3_hi, st, sampled, reached);
+    bool alive;
+    if (uniforms) {   // wave-uniform
+      const double* u = uniforms + 6 * i;
+      const Uniforms U{u[0], u[1], u[2], u[3], u[4], u[5]};
+      alive = phase_a_core<false, -1, false>(H, P, L, U, st, sampled, reached);
+    } else {
+      const uint32_t u3_hi = word_of(stream_block(ray_id >> 2, A.seed_lo, A.seed_hi), (uint32_t)ray_id & 3u);
+      alive = phase_a<false, -1, false>(H, P, L, A.seed_lo, A.seed_hi, ray_id, u3_hi, st, sampled, reached);
+    }
     int e_idx = -1;
     if (sampled) {
       e_idx = H.test_active ? P.n_energies : sample_energy_index(HB, st.r_idx, st.u5);
@@ -1639,8 +1699,8 @@ void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectr
                      reinterpret_cast<const long long*>(in), out, F);
 }
 void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
-                          hipStream_t stream) {
-  hipLaunchKernelGGL(trace_records_kernel, dim3(n_blocks), dim3(kRecBlock), 0, stream, H, blob, A, out, HB);
+                          hipStream_t stream, const double* uniforms_dev) {
+  hipLaunchKernelGGL(trace_records_kernel, dim3(n_blocks), dim3(kRecBlock), 0, stream, H, blob, A, out, HB, uniforms_dev);
 }
 
 }  // namespace sart

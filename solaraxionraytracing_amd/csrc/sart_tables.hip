@@ -5,12 +5,15 @@
 //
 // Results are BIT-IDENTICAL to the host path (sart_host_build_cdfs + the guide construction of sart_set_solar_tables):
 // the reference's order of the floating-point operations is kept - one lane walks one radius row from the first energy to
-// the last - and every product, sum and quotient is a separately rounded IEEE operation (no FMA contraction:
-// __dmul_rn / __dadd_rn / __ddiv_rn).
+// the last - and every product, sum and quotient is a separately rounded IEEE operation: floating-point contraction is
+// switched off for this translation unit (HIP's __dmul_rn / __dadd_rn are plain operators, which clang's default
+// -ffp-contract=fast fuses into FMAs - one rounding where the reference, and the host path, have two).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "sart_device.h"
+
+#pragma clang fp contract(off)
 
 namespace sart {
 

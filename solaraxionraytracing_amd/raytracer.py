@@ -257,6 +257,18 @@ class RayTracer:
         _lib.check(self.lib.sart_trace_records(self.handle, C.byref(p), buf.ctypes.data_as(C.c_void_p)))
         return buf
 
+    def trace_records_uniforms(self, uniforms: np.ndarray, flags: int | None = None) -> np.ndarray:
+        """Test entry (sart_internal_trace_records_uniforms, not part of include/sart.h): the records of the rays whose six
+        uniforms are the rows of ``uniforms`` [n][6] (draw order of SURVEY App. B) instead of draws from the Philox stream."""
+        u = np.ascontiguousarray(uniforms, dtype=np.float64)
+        assert u.ndim == 2 and u.shape[1] == 6
+        buf = np.zeros(u.shape[0], dtype=AXION_DTYPE)
+        p = self.trace_params(u.shape[0], flags=flags)
+        fn = self.lib.sart_internal_trace_records_uniforms
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.POINTER(TraceParams), C.c_void_p, C.c_void_p]
+        _lib.check(fn(self.handle, C.byref(p), u.ctypes.data_as(C.c_void_p), buf.ctypes.data_as(C.c_void_p)))
+        return buf
+
     def trace_histogram(self, n_rays: int, seed: int = 299792458, ray_id_offset: int = 0, flags: int | None = None,
                         image_n: int = 256, accumulate: bool = False):
         """Fused trace + prepareHeatmap(256,256,norm=1) + flux sum + counters.  Returns (image[ny][nx], summary
