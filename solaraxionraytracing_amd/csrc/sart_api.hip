@@ -5,9 +5,14 @@
 // SART_ERR_NO_DEVICE, and nothing here links or loads oracle/.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,6 +147,8 @@ struct sart_context {
     bool no_early_reject = false;    // SART_NO_EARLY_REJECT: stage A0 off
     bool no_image_tile = false;      // SART_NO_IMAGE_TILE: small focal spots go to global atomics only (as before the tile)
     bool no_path_const = false;      // SART_NO_PATH_CONST: never use the constant-path kernel variant (5)
+    bool no_host_prefault = false;   // SART_NO_HOST_PREFAULT: sart_trace_records leaves the caller's buffer as it finds it
+    int records_chunk = 0;           // SART_RECORDS_CHUNK: records per chunk of sart_trace_records (0 = 1 Mi)
     bool force_generic = false;      // SART_FORCE_GENERIC: never use the specialised kernel variant
     int image_replicas = 0;          // SART_IMAGE_REPLICAS: 0 = chosen from the plate scale
     int hist_blocks_per_cu = 0;      // SART_HIST_BLOCKS_PER_CU: 0 = occupancy query
@@ -181,6 +188,9 @@ struct sart_context {
   DevBuf<double> d_acc;        // scratch accumulator of the blocking convenience call
   bool d_acc_stale = false;    // its contents belong to another accumulation mode: the next call starts from zero
   DevBuf<sart_axion_t> d_rec;  // scratch records of the blocking convenience call
+  DevBuf<sart_axion_t> d_rec2; // its second half-buffer (chunked, double-buffered record path)
+  hipStream_t copy_stream = nullptr;   // D2H of the record chunks, beside the kernels on `stream`
+  hipEvent_t rec_traced[2] = {nullptr, nullptr}, rec_copied[2] = {nullptr, nullptr};
   bool derived_dirty = true;
   // LDS image tile (sart_device.h: TraceArgs::tile_*): centre of the focal spot in image pixels, found by a pilot launch
   // for the current setup and image binning
@@ -776,6 +786,8 @@ int sart_create(int device_ordinal, sart_context** out) {
     c->knobs.no_early_reject = flag("SART_NO_EARLY_REJECT");
     c->knobs.no_image_tile = flag("SART_NO_IMAGE_TILE");
     c->knobs.no_path_const = flag("SART_NO_PATH_CONST");
+    c->knobs.no_host_prefault = flag("SART_NO_HOST_PREFAULT");
+    c->knobs.records_chunk = number("SART_RECORDS_CHUNK");
     c->knobs.force_generic = flag("SART_FORCE_GENERIC");
     c->knobs.image_replicas = number("SART_IMAGE_REPLICAS");
     c->knobs.hist_blocks_per_cu = number("SART_HIST_BLOCKS_PER_CU");
@@ -789,6 +801,11 @@ int sart_destroy(sart_context* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& ev : c->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (int k = 0; k < 2; ++k) {
+    if (c->rec_traced[k]) (void)hipEventDestroy(c->rec_traced[k]);
+    if (c->rec_copied[k]) (void)hipEventDestroy(c->rec_copied[k]);
+  }
+  if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return 0;
@@ -1049,14 +1066,119 @@ __attribute__((visibility("default"))) int sart_internal_trace_records_uniforms(
   return 0;
 }
 
+// ---- the literal drop-in: records into CALLER memory ------------------------------------------------------------------------
+// The kernel writes records at ~1.3 TB/s; what bounds this call is the way into the caller's buffer (raytracer.nim:2760:
+// newSeq[Axion] - zero pages that nobody has touched yet).  Measured on the MI355X boxes (tools/microbench/d2h_rates*.hip,
+// profiles/r03_microbench_d2h_rates.txt): PCIe D2H 57 GB/s into pinned memory, 51-55 GB/s through the runtime's staging path
+// into pageable memory that is already mapped - but 10-20 GB/s into a fresh mapping, where every 4 KiB page faults on its
+// first write.  Hence: (1) the interior of the caller's buffer is advised MADV_HUGEPAGE (a hint; the boxes run transparent
+// huge pages in `madvise` mode) and faulted in by a few host threads ahead of the copy, one chunk at a time (2 MiB pages
+// fault at 100-220 GB/s: the pre-fault of chunk k + 1 hides behind the copy of chunk k); every byte touched is a byte this
+// call overwrites with records; (2) the rays are traced in chunks into two device buffers, chunk k + 1 on the context's stream
+// while chunk k crosses PCIe on a second stream.  SART_NO_HOST_PREFAULT switches (1) off.
+namespace {
+
+class HostPrefault {   // faults [base, base + bytes) in, chunk by chunk, on a background thread; wait(k) blocks until chunk k is mapped
+ public:
+  HostPrefault(char* base, size_t bytes, size_t chunk_bytes, bool enabled) : base_(base), bytes_(bytes), chunk_(chunk_bytes) {
+    n_chunks_ = (bytes + chunk_bytes - 1) / chunk_bytes;
+    if (!enabled || bytes < (size_t(8) << 20)) { done_ = n_chunks_; return; }   // small buffers: not worth a thread
+    const long page = sysconf(_SC_PAGESIZE);
+    page_ = page > 0 ? static_cast<size_t>(page) : 4096;
+    const uintptr_t lo = (reinterpret_cast<uintptr_t>(base) + page_ - 1) / page_ * page_;
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(base) + bytes) / page_ * page_;
+    if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);   // a hint: failure changes nothing
+    worker_ = std::thread([this] { run(); });
+  }
+  ~HostPrefault() { if (worker_.joinable()) worker_.join(); }
+  void wait(size_t k) {
+    std::unique_lock<std::mutex> lock(m_);
+    cv_.wait(lock, [&] { return done_ > k; });
+  }
+
+ private:
+  void run() {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned n_threads = std::min(8u, hw);
+    for (size_t k = 0; k < n_chunks_; ++k) {
+      // whole pages inside this chunk (the partial pages at the ends of the buffer are mapped by the copy itself)
+      const uintptr_t b = reinterpret_cast<uintptr_t>(base_) + k * chunk_;
+      const uintptr_t e = reinterpret_cast<uintptr_t>(base_) + std::min(bytes_, (k + 1) * chunk_);
+      const uintptr_t lo = (b + page_ - 1) / page_ * page_, hi = e / page_ * page_;
+      if (hi > lo) {
+        const size_t pages = (hi - lo) / page_, per = (pages + n_threads - 1) / n_threads;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < n_threads; ++t) {
+          const size_t p0 = std::min(pages, per * t), p1 = std::min(pages, per * (t + 1));
+          if (p1 > p0)
+            th.emplace_back([=] {
+              volatile char* q = reinterpret_cast<volatile char*>(lo);
+              for (size_t pg = p0; pg < p1; ++pg) q[pg * page_] = 0;   // one write per page: overwritten by the records
+            });
+        }
+        for (auto& t : th) t.join();
+      }
+      {
+        std::lock_guard<std::mutex> lock(m_);
+        done_ = k + 1;
+      }
+      cv_.notify_all();
+    }
+  }
+  char* base_;
+  size_t bytes_, chunk_, n_chunks_ = 0, page_ = 4096, done_ = 0;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::thread worker_;
+};
+
+}  // namespace
+
 int sart_trace_records(sart_context* c, const sart_trace_params_t* p, sart_axion_t* out) {
   if (!c || !p || (!out && p->n_rays)) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
   if (p->n_rays == 0) return 0;
   SART_HIP(hipSetDevice(c->device));
-  if (int rc = c->d_rec.resize(p->n_rays)) return rc;
-  if (int rc = sart_trace_records_device(c, p, c->d_rec.p)) return rc;
-  SART_HIP(hipMemcpyAsync(out, c->d_rec.p, p->n_rays * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->stream));
-  SART_HIP(hipStreamSynchronize(c->stream));
+  const uint64_t n = p->n_rays;
+  const uint64_t chunk = c->knobs.records_chunk > 0 ? static_cast<uint64_t>(c->knobs.records_chunk) : (uint64_t(1) << 20);   // 208 MiB of records
+  if (n <= chunk) {   // one launch, one copy
+    if (int rc = c->d_rec.resize(n)) return rc;
+    if (int rc = sart_trace_records_device(c, p, c->d_rec.p)) return rc;
+    SART_HIP(hipMemcpyAsync(out, c->d_rec.p, n * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->stream));
+    SART_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  if (int rc = c->d_rec.resize(chunk)) return rc;
+  if (int rc = c->d_rec2.resize(chunk)) return rc;
+  if (!c->copy_stream) SART_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  for (int k = 0; k < 2; ++k) {
+    if (!c->rec_traced[k]) SART_HIP(hipEventCreateWithFlags(&c->rec_traced[k], hipEventDisableTiming));
+    if (!c->rec_copied[k]) SART_HIP(hipEventCreateWithFlags(&c->rec_copied[k], hipEventDisableTiming));
+  }
+  sart_axion_t* const bufs[2] = {c->d_rec.p, c->d_rec2.p};
+  const uint64_t n_chunks = (n + chunk - 1) / chunk;
+  HostPrefault prefault(reinterpret_cast<char*>(out), n * sizeof(sart_axion_t), chunk * sizeof(sart_axion_t), !c->knobs.no_host_prefault);
+  sart_trace_params_t q = *p;
+  int rc = 0;
+  for (uint64_t k = 0; k <= n_chunks && rc == 0; ++k) {
+    if (k < n_chunks) {   // trace chunk k into buffer k & 1 once the copy of chunk k - 2 has left it
+      if (k >= 2) SART_HIP(hipStreamWaitEvent(c->stream, c->rec_copied[k & 1], 0));
+      q.n_rays = std::min(chunk, n - k * chunk);
+      q.ray_id_offset = p->ray_id_offset + k * chunk;
+      rc = sart_trace_records_device(c, &q, bufs[k & 1]);
+      if (rc) break;
+      SART_HIP(hipEventRecord(c->rec_traced[k & 1], c->stream));
+    }
+    if (k > 0) {          // chunk k - 1 crosses PCIe while chunk k is traced (the call may block the host: pageable destination)
+      const uint64_t j = k - 1, cnt = std::min(chunk, n - j * chunk);
+      prefault.wait(j);
+      SART_HIP(hipStreamWaitEvent(c->copy_stream, c->rec_traced[j & 1], 0));
+      SART_HIP(hipMemcpyAsync(out + j * chunk, bufs[j & 1], cnt * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->copy_stream));
+      SART_HIP(hipEventRecord(c->rec_copied[j & 1], c->copy_stream));
+    }
+  }
+  const hipError_t e1 = hipStreamSynchronize(c->copy_stream), e2 = hipStreamSynchronize(c->stream);
+  if (rc) return rc;
+  if (e1 != hipSuccess || e2 != hipSuccess) return fail(SART_ERR_NO_DEVICE, std::string("sart_trace_records: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
   return 0;
 }
 

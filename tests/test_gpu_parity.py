@@ -304,6 +304,33 @@ def test_bench_two_rank_rehearsal(scaling):
     assert d["value"] > 1e9
 
 
+def test_trace_records_chunked_path_is_byte_identical():
+    """sart_trace_records above one chunk: rays traced chunk by chunk into two device buffers, copied out on a second stream
+    into a pre-faulted caller buffer.  Same bytes as one launch + one copy, for ragged sizes and unaligned destinations."""
+    import os
+    full = make_setup("cast_llnl")
+    n = 150_001
+    with sa.RayTracer(full) as rt:
+        one = rt.traceAxionWrapper(n, seed=31, ray_id_offset=7)          # n < 1 Mi records: one launch, one copy
+    for chunk, prefault in ((65_536, True), (40_000, False), (149_999, True)):
+        os.environ["SART_RECORDS_CHUNK"] = str(chunk)
+        if not prefault:
+            os.environ["SART_NO_HOST_PREFAULT"] = "1"
+        try:
+            with sa.RayTracer(full) as rt:
+                raw = np.empty(n * 208 + 24, dtype=np.uint8)              # destination 24 bytes off any page boundary
+                view = raw[24:].view(L.AXION_DTYPE)
+                p = rt.trace_params(n, seed=31, ray_id_offset=7)
+                L.check(rt.lib.sart_trace_records(rt.handle, C.byref(p), view.ctypes.data_as(C.c_void_p)))
+                again = rt.traceAxionWrapper(n, seed=31, ray_id_offset=7)
+        finally:
+            os.environ.pop("SART_RECORDS_CHUNK", None)
+            os.environ.pop("SART_NO_HOST_PREFAULT", None)
+        assert view.tobytes() == one.tobytes(), (chunk, prefault)
+        assert again.tobytes() == one.tobytes()
+        assert raw[:24].tobytes() != b"" and one["passed"].sum() > 0.5 * n
+
+
 def test_bench_gpus_n_starts_its_own_ranks_and_refuses_to_lie():
     """`python bench.py --gpus 2` WITHOUT torchrun: the script starts two ranks itself (gloo rehearsal on this one card) and
     the line says n_gpus 2; `--gpus 8` on a one-GPU box exits non-zero without a line."""
