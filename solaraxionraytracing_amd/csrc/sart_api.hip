@@ -173,6 +173,7 @@ struct sart_context {
   HotB hotb;         // table bases of phase B's gathers, by value too
   DevBuf<DevBlob> d_blob;
   bool blob_dirty = true;
+  bool spot_may_have_moved = true;   // geometry, tables or angles changed since the LDS image tile was placed
   std::vector<ShellDev> shells;
   std::vector<uint8_t> shell_lut;
   int radius_span = 0;
@@ -491,6 +492,7 @@ int refresh_derived(sart_context* c) {
   if (int rc = hoist_reflectivity(c)) return rc;
   c->derived_dirty = false;
   c->blob_dirty = true;
+  c->spot_may_have_moved = true;
   return 0;
 }
 
@@ -511,7 +513,7 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   a.flags = p->flags;
 #ifdef SART_DEBUG_KNOBS
   if (c->knobs.no_image_atomics) a.flags |= 0x40000000u;
-  a.flags |= c->knobs.debug_flags & 0x38000000u;
+  a.flags |= c->knobs.debug_flags & 0x3F000000u;
 #endif
   a.image_nx = p->image_nx;
   a.image_ny = p->image_ny;
@@ -651,7 +653,8 @@ int sync_blob(sart_context* c) {
   if (!c->knobs.no_early_reject) build_zones(c->setup, c->params, c->n_radii, c->hot);
   c->path_const = path_is_constant(c->params, c->hot, c->n_radii);
   c->blob_dirty = false;
-  c->tile.valid = false;   // the focal spot may have moved
+  if (c->spot_may_have_moved) c->tile.valid = false;   // a new axion mass alone (weights only) keeps the tile where it is
+  c->spot_may_have_moved = false;
   return 0;
 }
 
@@ -873,6 +876,7 @@ int sart_set_telescope_angles(sart_context* c, double tx, double ty) {
   // cheap path: only the parameter blob changes (the shell table does not depend on the angles); sync_blob() waits
   // for the launches that still read the old blob before it uploads the new one
   c->blob_dirty = true;
+  c->spot_may_have_moved = true;
   return hoist_setup(c);
 }
 
@@ -904,7 +908,7 @@ int sart_set_solar_tables(sart_context* c, const double* rcdf, const double* ecd
   for (int k = 0; k < kRadiusGuide; ++k) span = std::max(span, static_cast<int>(rg[k + 1]) - static_cast<int>(rg[k]));
   c->radius_span = span;
   // Energy guide (sart_device.h: kEnergyGuide*): entry k of a row brackets bucket k from below, entry k + 1 from above.
-  //   k <= 1984:      lowerBound(row, k / 2048)                       buckets [k / 2048, (k + 1) / 2048)
+  //   k <= Uniform:   lowerBound(row, k / Div)                        buckets [k / Div, (k + 1) / Div), Uniform = Div * 31/32
   //   k = 1984 + j:   upperBound(row, 1 - decode(code0 - j + 1))      buckets (1 - v_hi, 1 - v_lo] of the codes of v = 1 - u
   // (a bucket open from below needs the upper bound of its lower edge: lowerBound(u) >= upperBound(a) for every u > a.)
   // lowerBound(row, u) of any u in bucket k then lies in [entry k, entry k + 1].  The last entry is n_energies - 1.
@@ -925,7 +929,7 @@ int sart_set_solar_tables(sart_context* c, const double* rcdf, const double* ecd
     uint16_t* g = eg.data() + static_cast<size_t>(r) * kEnergyGuideEntries;
     const size_t last = static_cast<size_t>(nE) - 1;
     for (int k = 0; k <= kEnergyGuideUniform; ++k)
-      g[k] = static_cast<uint16_t>(std::min(lower_bound_idx(row, nE, static_cast<double>(k) / 2048.0), last));
+      g[k] = static_cast<uint16_t>(std::min(lower_bound_idx(row, nE, static_cast<double>(k) / static_cast<double>(kEnergyGuideDiv)), last));
     for (int j = 1; j <= kEnergyGuideLogMax; ++j) {
       const double edge = 1.0 - decode(kEnergyGuideCode0 - static_cast<uint32_t>(j) + 1u);   // exact: v <= 1/32
       const size_t ub = static_cast<size_t>(std::upper_bound(row, row + nE, edge) - row);
@@ -983,6 +987,7 @@ int sart_set_solar_tables_device(sart_context* c, const double* em_rates_dev, co
   return 0;
 }
 
+static_assert(kEnergyGuideEntries == 2594, "include/sart.h (sart_get_solar_tables) and _lib.py (ENERGY_GUIDE_ENTRIES) state this number");
 // Host copies of the sampling tables the context holds (whichever entry point set them).
 int sart_get_solar_tables(sart_context* c, double* rcdf_out, double* ecdf_out, uint16_t* radius_guide_out, uint16_t* energy_guide_out) {
   if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");

@@ -19,11 +19,18 @@ constexpr int kMaxShells = 64;
 constexpr int kMaxStrips = 16;       // half the number of window strips that are looped over
 constexpr int kRadiusGuide = 2048;   // buckets of the guide table in front of fluxRadiusCDF
 // Guide table in front of every row of diffFluxCDFs (lowerBound of the energy draw, raytracer.nim:464-468).  Buckets in the
-// uniform u of the draw: width 1/2048 below u = 31/32; above, where a solar spectrum's CDF creeps towards 1 over hundreds
+// uniform u of the draw: width 1/kEnergyGuideDiv below u = 31/32; above, where a solar spectrum's CDF creeps towards 1 over hundreds
 // of energies, buckets of constant RELATIVE width in v = 1 - u (64 per octave of v, read off the bits of the double v) down
 // to v = 2^-30.  A bucket then holds 0-2 table entries almost everywhere, and the draw resolves with ONE gather of four
 // consecutive CDF values instead of a data-dependent binary search (a chain of dependent HBM / Infinity-Cache round trips).
-constexpr int kEnergyGuideUniform = 1984;                 // buckets [k / 2048, (k + 1) / 2048), k < 1984 = 2048 * 31/32
+// 1024 rather than 2048 uniform buckets: the guide shrinks from 14.1 to 10.2 MB (its hot part from 2 to 1 MB per 500 radius
+// rows) while a bucket still holds fewer than four entries wherever the CDF rises; measured -1.3 % on CAST / LLNL, -1 % on
+// BabyIAXO, 512 buckets: no further gain (profiles/r03_exp_guide_density.txt).  Results do not depend on the density.
+#ifndef SART_ENERGY_GUIDE_DIV
+#define SART_ENERGY_GUIDE_DIV 1024
+#endif
+constexpr int kEnergyGuideDiv = SART_ENERGY_GUIDE_DIV;    // uniform buckets per unit of u (a power of two)
+constexpr int kEnergyGuideUniform = kEnergyGuideDiv / 32 * 31;   // buckets [k / Div, (k + 1) / Div), k < Div * 31/32
 constexpr int kEnergyGuideLogMax = 25 * 64;               // log buckets j = 1 .. 1600 (j = 0: the single point u = 31/32)
 constexpr int kEnergyGuideBuckets = kEnergyGuideUniform + kEnergyGuideLogMax + 1;
 constexpr int kEnergyGuideEntries = kEnergyGuideBuckets + 1;   // u16 per row: bucket k is bracketed by entries k, k + 1

@@ -369,16 +369,17 @@ struct EnergyDraw {
   uint32_t lo, hi;
   d2 c01, c23;         // row[lo .. lo + 3]
 };
-__device__ __forceinline__ void energy_draw_begin(const HotB& HB, int r_idx, double u5, EnergyDraw& d) {
+__device__ __forceinline__ void energy_draw_begin(const HotB& HB, int r_idx, double u5, EnergyDraw& d, int r_idx_guide = -1) {
+  if (r_idx_guide < 0) r_idx_guide = r_idx;   // (experiment builds pass another row for the guide gather: working-set sensitivity)
   d.u = u5;
   const double v = 1.0 - u5;
-  const uint32_t ku = (uint32_t)(int)(u5 * 2048.0);
+  const uint32_t ku = (uint32_t)(int)(u5 * (double)kEnergyGuideDiv);
   const uint32_t code = (uint32_t)__double2hiint(v) >> 14;                       // exponent and six mantissa bits of v
   const uint32_t kl = (uint32_t)kEnergyGuideUniform + min(kEnergyGuideCode0 - code, (uint32_t)kEnergyGuideLogMax);
   const uint32_t k = (v > 0.03125) ? ku : kl;                                    // u5 < 31/32: uniform buckets
   d.row = __umul24((uint32_t)r_idx, (uint32_t)HB.cdf_stride);                    // both < 2^24
   // two adjacent u16 as one (possibly unaligned) 32-bit load
-  d.gword = gload<uint32_t>(HB.energy_guide, (__umul24((uint32_t)r_idx, (uint32_t)kEnergyGuideEntries) + k) * 2u);
+  d.gword = gload<uint32_t>(HB.energy_guide, (__umul24((uint32_t)r_idx_guide, (uint32_t)kEnergyGuideEntries) + k) * 2u);
 }
 __device__ __forceinline__ void energy_draw_candidates(const HotB& HB, EnergyDraw& d) {
   d.lo = d.gword & 0xFFFFu;
@@ -721,7 +722,14 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   // the energy draw runs beside the mirror arithmetic (its gathers are issued early, consumed late)
   const bool draw_energy = __builtin_amdgcn_readfirstlane(e_idx_in) < 0;   // wave-uniform: false for the X-ray test source
   EnergyDraw ed = {};
+#ifdef SART_DEBUG_KNOBS
+  // working-set experiments (wrong results by design): 0x04000000 guide rows folded onto 16, 0x02000000 CDF rows folded onto 16,
+  // 0x01000000 reflectivity / energy rows folded onto 32
+  const uint32_t dbg = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.flags);
+  if (draw_energy) energy_draw_begin(HB, (dbg & 0x02000000u) ? (st.r_idx & 15) : st.r_idx, st.u5, ed, (dbg & 0x04000000u) ? (st.r_idx & 15) : st.r_idx);
+#else
   if (draw_energy) energy_draw_begin(HB, st.r_idx, st.u5, ed);
+#endif
   const ShellDev& sh = L.shells[st.shell];
   // P / A may live in LDS: branch conditions are made wave-uniform (scalar branches) explicitly.
   // FAST: vacuum stage, solar source (known at compile time).
@@ -808,7 +816,11 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
 
   // ---- energy index; the energy row and the two reflectivity pairs are requested the moment it is known and consumed
   // behind the detector-plane and window geometry ----
+#ifdef SART_DEBUG_KNOBS
+  const int e_idx = (dbg & 0x01000000u) ? ((draw_energy ? energy_draw_finish(HB, ed) : e_idx_in) & 31) : (draw_energy ? energy_draw_finish(HB, ed) : e_idx_in);
+#else
   const int e_idx = draw_energy ? energy_draw_finish(HB, ed) : e_idx_in;
+#endif
   SART_B_STAMP(3, e_idx);
   const EnergyDev en = load_energy_row(HB, e_idx);
   d2 g1 = {1.0, 1.0}, g2 = {1.0, 1.0};

@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void radius_guide_kernel(const double* __restr
 }
 
 // ---- energy guide: one thread per (row, entry); entry layout of sart_device.h / sart_set_solar_tables ---------------------
-//   k <= 1984:      lowerBound(row, k / 2048)
-//   k = 1984 + j:   upperBound(row, 1 - decode(code0 - j + 1)),  j = 1 .. 1600   (decode(c) = the double whose high word is c << 14)
+//   k <= Uniform:      lowerBound(row, k / Div)                          (Div = kEnergyGuideDiv, Uniform = Div * 31/32)
+//   k = Uniform + j:   upperBound(row, 1 - decode(code0 - j + 1)),  j = 1 .. 1600   (decode(c) = the double whose high word is c << 14)
 //   last entry:     n_energies - 1
 __global__ __launch_bounds__(256) void energy_guide_kernel(const double* __restrict__ cdf, int n_radii, int n_energies,
                                                            uint16_t* __restrict__ guide) {
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void energy_guide_kernel(const double* __restr
   const int last = n_energies - 1;
   int v;
   if (k <= kEnergyGuideUniform) {
-    v = min(lower_bound_dev(row, n_energies, (double)k / 2048.0), last);
+    v = min(lower_bound_dev(row, n_energies, (double)k / (double)kEnergyGuideDiv), last);
   } else if (k < kEnergyGuideBuckets) {
     const uint32_t j = (uint32_t)(k - kEnergyGuideUniform);
     const uint64_t bits = (uint64_t)(kEnergyGuideCode0 - j + 1u) << (14 + 32);
