@@ -319,6 +319,10 @@ int sart_set_detector_tables(sart_context* ctx,
  * Literal drop-in for traceAxionWrapper (:2223-2244): traces params->n_rays rays and writes
  * one Axion record per ray to `ax_buf` (HOST memory, caller-allocated, n_rays * 208 bytes).
  * Every field of every record is written (the reference relies on zero-initialised seqs).
+ * Above 2^20 records the rays are traced in chunks into two device buffers and copied out on a second stream; the
+ * interior of `ax_buf` is advised MADV_HUGEPAGE and faulted in ahead of the copy by helper threads (every byte they touch
+ * is overwritten with records; SART_NO_HOST_PREFAULT=1 leaves the buffer alone): 2.3e8 records/s into a fresh buffer,
+ * 2.66e8 into mapped pages, PCIe bound 2.75e8.
  */
 int sart_trace_records(sart_context* ctx, const sart_trace_params_t* params, sart_axion_t* ax_buf);
 /* Same, but `ax_buf_device` is DEVICE memory and the call only enqueues on the stream. */
@@ -358,7 +362,7 @@ int sart_trace_histogram_spectra(sart_context* ctx, const sart_trace_params_t* p
  *            tables and flags of the launch that fixes the quantum (exposure x conversion probability over lengthB x max
  *            reflectivity^2 x max window transmission x max gas absorption).  headroom_bits (default 27) = log2 of the
  *            number of w_bound-weight rays a slot can take before it wraps: a pixel holds 2^27 = 1.3e8 of them (a 256 x 256
- *            BabyIAXO image reaches that after ~1e13 traced rays); the resolution of one ray's weight is 2^-36 w_bound, and
+ *            BabyIAXO image reaches that after ~5e12 traced rays); the resolution of one ray's weight is 2^-36 w_bound, and
  *            a pixel that n rays hit carries a rounding error of ~q_w sqrt(n / 12): an image of 2e7 rays agrees with the f64
  *            image to < 1e-12 of its largest pixel, larger images better.  SUM_WEIGHTS_SQ: q = w_bound^2 2^-19 (a 44-bit
  *            ray count).  SUM_X / SUM_Y / SUM_R: 2^-32 mm.  energy_reflect spectrum: 2^-40.
