@@ -22,6 +22,8 @@ Classes of vector instructions (the question of VERDICT r02 #6: what are the "ot
   cvt      v_cvt_*
   lane     v_readlane / v_readfirstlane / v_writelane / v_permlane / dpp moves (cross-lane, SGPR spills)
   other    anything else that starts with v_
+Phase A is inlined at two call sites (behind stage A0, or on its own when the setup has no zones): the listing shows A1 twice,
+a launch executes one copy, and the model below divides A1 by the number of copies.
 Per 64 launched rays a stage executes `passes` times (A0: 1; A1: the share of rays that survive stage A0, + the drain
 passes; B: N_SHELL_SELECTED / N_RAYS).  With --pmc the model  sum_stage static(stage) x passes(stage)  is compared with
 the measured SQ_INSTS_VALU x 64 / rays; passes(A1) is solved from the measured total when it is not given."""
@@ -110,6 +112,7 @@ def histogram(lines):
     stage = "PROLOGUE"
     next_id = 0
     loop_labels = {}      # label -> index of the first instruction after it (for execnz back edges)
+    copies = collections.Counter()   # a stage whose marker appears k times was inlined at k call sites: one of them runs per launch
     for raw in lines[1:]:
         l = raw.strip()
         if not l:
@@ -125,6 +128,7 @@ def histogram(lines):
             ms = re.search(r"SART_STAGE (\w+)", l)
             if ms:
                 stage = ms.group(1)
+                copies[stage] += 1
                 for r in stack:
                     regions[r]["hot"] = True
             if "; hot" in l:
@@ -164,6 +168,7 @@ def histogram(lines):
             d["mnemonics"][mn] += w
             dump.append((st, classify(mn), text))
     histogram.hot_lines = dump
+    histogram.copies = dict(copies)
     return out
 
 
@@ -190,7 +195,7 @@ def main():
         rare = sum(d["rare"][c] for c in VALU_CLASSES)
         print("%-9s %5.0f | " % (st, valu) + " ".join("%6.0f" % d["hot"][c] for c in VALU_CLASSES) +
               " | %4d %4d %4d %4d %4d | %5d" % (d["hot"]["salu"], d["hot"]["lds"], d["hot"]["vmem"], d["hot"]["vmem_atomic"], d["hot"]["s_waitcnt"], rare))
-        report["stages"][st] = {"valu": valu, **{c: d["hot"][c] for c in VALU_CLASSES}, "salu": d["hot"]["salu"], "lds": d["hot"]["lds"],
+        report["stages"][st] = {"copies_in_listing": histogram.copies.get(st, 1), "valu": valu, **{c: d["hot"][c] for c in VALU_CLASSES}, "salu": d["hot"]["salu"], "lds": d["hot"]["lds"],
                                 "vmem": d["hot"]["vmem"], "vmem_atomic": d["hot"]["vmem_atomic"], "s_waitcnt": d["hot"]["s_waitcnt"],
                                 "rare_valu": rare,
                                 "top_non_arithmetic": [[k, v] for k, v in d["mnemonics"].most_common() if classify(k) in ("cmp", "select", "mov", "cvt", "lane", "other")][:14]}
@@ -204,13 +209,14 @@ def main():
         meas = pmc["derived"]["valu_insts_per_64_rays"]
         pb = args.passes_b if args.passes_b is not None else 0.3295
         s = report["stages"]
-        g = lambda k: s.get(k, {"valu": 0})["valu"]
+        # phase A is inlined at two call sites (with / without stage A0 in front of it); a launch runs one of them
+        g = lambda k: s.get(k, {"valu": 0})["valu"] / (histogram.copies.get(k, 1) if k == "A1" else 1)
         fixed_part = g("A0") * 1.0 + (g("B") + g("ACC")) * pb
         pa = (meas - fixed_part) / max(1, g("A1"))
         report["model"] = {"measured_valu_per_64_rays": meas, "passes": {"A0": 1.0, "A1": pa, "B": pb},
                            "note": "passes(A1) solved from measured = A0 + A1 x passes(A1) + (B + ACC) x passes(B); the expected value is the "
                                    "share of rays that survive stage A0 (~0.48 for BabyIAXO) plus drain passes",
-                           "per_class_per_64_rays": {c: s.get("A0", {}).get(c, 0) + s.get("A1", {}).get(c, 0) * pa +
+                           "per_class_per_64_rays": {c: s.get("A0", {}).get(c, 0) + s.get("A1", {}).get(c, 0) / histogram.copies.get("A1", 1) * pa +
                                                      (s.get("B", {}).get(c, 0) + s.get("ACC", {}).get(c, 0)) * pb for c in VALU_CLASSES}}
         print("measured VALU / 64 rays %.1f -> passes(A1) = %.3f with passes(B) = %.4f" % (meas, pa, pb))
         print("per class per 64 launched rays:", {k: round(v, 1) for k, v in report["model"]["per_class_per_64_rays"].items()})
