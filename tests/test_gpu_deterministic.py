@@ -196,3 +196,30 @@ def test_fixed64_errors():
         rt.set_accumulation_mode("fixed64", headroom_bits=40)
         rt.trace_histogram(100_000, seed=1)
         assert rt.fixed_quanta()["weight"] == q * 2.0 ** 13     # default headroom: 27 bits
+
+
+def test_bench_fixed64_flux_is_identical_for_one_and_two_ranks():
+    """End to end through bench.py: the same 6e7 rays as one rank and as two ranks (strong scaling, gloo rehearsal on this
+    card, int64 reduce of the raw accumulators, finalize on rank 0) - the flux and the image sum come out bit for bit equal;
+    in f64 mode they agree to 1e-12 only."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+
+    def bench(gpus, accumulation):
+        env = dict(base, SART_BENCH_BACKEND="gloo", SART_BENCH_DEVICE="0") if gpus > 1 else base
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1",
+                              "--rays-per-step", "2e7", "--profile-run", "--scaling", "strong", "--accumulation", accumulation],
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == gpus and d["accumulation"] == accumulation and d["config"]["total_rays"] == 6e7
+        return d["results"]
+
+    one, two = bench(1, "fixed64"), bench(2, "fixed64")
+    assert one["flux"] == two["flux"] and one["image_sum"] == two["image_sum"]          # JSON round-trips doubles exactly
+    assert one["passed_fraction"] == two["passed_fraction"]
+    f1 = bench(1, "f64")
+    assert f1["flux"] == pytest.approx(one["flux"], rel=1e-12) and f1["passed_fraction"] == one["passed_fraction"]
