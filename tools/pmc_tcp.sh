@@ -3,7 +3,8 @@
 # Usage on the GPU box:  bash tools/pmc_tcp.sh <tag> [bench args...]   -> gpurun_out/pmc_tcp_<tag>/
 # The four TA counters of round 2's pass 4 do not fit one pass (rocprofv3 aborted with signal 6, "Request exceeds the
 # capabilities of the hardware", gpurun_out/pmc_tcp_v23/pass4.log): they are two passes now, and a pass that fails ends
-# the script with its exit code instead of being skipped.
+# the script with its exit code instead of being skipped.  Round 3: the TD pass (three TD counters + one TCP counter) aborts the
+# same way and is split as well.
 set -e
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -18,7 +19,8 @@ PASSES=(
  "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_READ_sum TCP_TOTAL_ACCESSES_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum"
  "TCP_UTCL1_STALL_INFLIGHT_MAX_sum TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_SERIALIZATION_STALL_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum"
- "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TCP_TD_TCP_STALL_CYCLES_sum"
+ "TD_TD_BUSY_sum TD_TC_STALL_sum"
+ "TD_LOAD_WAVEFRONT_sum TCP_TD_TCP_STALL_CYCLES_sum"
 )
 i=0
 for P in "${PASSES[@]}"; do
