@@ -40,6 +40,9 @@ def main():
                     help="solar emission table; default: agss09-device (all terms of readOpacityFile.nim on the AGSS09 model; emission "
                          "kernel -> CDFs -> guide tables without leaving the GPU, sart_emission_to_solar_tables) for the mass scan = "
                          "BASELINE configs[4]; agss09 = the same table through the host; primakoff (E1) for the angular scan")
+    ap.add_argument("--accumulation", default="f64", choices=["f64", "fixed64"],
+                    help="--shard rays only: fixed64 = deterministic integer accumulation + int64 reduce: the curve does not depend on "
+                         "the number of ranks to the last bit (SART_ACCUM_FIXED64)")
     ap.add_argument("--out", default="gpurun_out/scan.csv")
     ap.add_argument("--gpus", type=int, default=None,
                     help="number of ranks (one per GPU).  Stand-alone: N > 1 starts N copies of this script, one rank each; "
@@ -81,6 +84,8 @@ def main():
             stream = torch.cuda.Stream(device=acc.device)
             torch.cuda.set_stream(stream)
             rt.set_stream(stream.cuda_stream)
+            fixed64 = args.accumulation == "fixed64"
+            rt.set_accumulation_mode(args.accumulation)
             for i, x in enumerate(xs):
                 if args.mode == "angular":
                     rt.set_telescope_angles(float("nan"), float(x))
@@ -90,7 +95,12 @@ def main():
                 p = rt.trace_params(hi - lo, ray_id_offset=i * n_rays + lo, flags=flags, accumulate=True)
                 rt.trace_histogram_device(p, acc.data_ptr())
                 red = acc if use_cuda else acc.cpu()
-                D.reduce_accumulator(red, dst=0)
+                D.reduce_accumulator(red, dst=0, fixed64=fixed64)
+                if fixed64:      # raw integers -> doubles (every rank: the quanta are the same everywhere; only rank 0's sum is complete)
+                    if not use_cuda:
+                        acc.copy_(red)
+                    rt.finalize_accumulator_device(p, acc.data_ptr())
+                    red = acc if use_cuda else acc.cpu()
                 curve[i] = float(red[256 * 256 + L.ACC["SUM_WEIGHTS"]].item())
                 if rank == 0:
                     assert float(red[256 * 256 + L.ACC["N_RAYS"]].item()) == n_rays
