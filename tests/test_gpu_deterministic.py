@@ -223,3 +223,24 @@ def test_bench_fixed64_flux_is_identical_for_one_and_two_ranks():
     assert one["passed_fraction"] == two["passed_fraction"]
     f1 = bench(1, "f64")
     assert f1["flux"] == pytest.approx(one["flux"], rel=1e-12) and f1["passed_fraction"] == one["passed_fraction"]
+
+
+def test_scan_fixed64_curve_is_identical_for_one_and_two_ranks(tmp_path):
+    """tools/scan.py mass --shard rays (BASELINE configs[4]: rays of every mass point sharded over the ranks, one reduce of the
+    accumulator per point) with --accumulation fixed64: the CSV written by one rank and by two ranks is the same file."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    outs = []
+    for gpus in (1, 2):
+        env = dict(base, SART_BENCH_BACKEND="gloo", SART_BENCH_DEVICE="0") if gpus > 1 else base
+        out = str(tmp_path / ("scan%d.csv" % gpus))
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "scan.py"), "mass", "--gpus", str(gpus), "--shard", "rays",
+                            "--accumulation", "fixed64", "--points", "3", "--rays", "3e6", "--massMin", "0.004", "--massMax", "0.012",
+                            "--out", out], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(open(out).read())
+    assert outs[0] == outs[1] and outs[0].count("\n") == 4
+    flux = [float(l.split(",")[1]) for l in outs[0].splitlines()[1:]]
+    assert min(flux) > 0 and flux[1] > 1.1 * max(flux[0], flux[2])   # the middle point sits on the resonance at m_gamma = 0.008235 eV
