@@ -114,7 +114,12 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
         world = int(os.environ["WORLD_SIZE"])
         if world != n_ranks:
             raise LaunchRefused("--gpus %d but WORLD_SIZE=%d" % (n_ranks, world))
-        check_world(world, backend, shared)
+        n_dev = visible_devices()
+        if shared is None and n_dev == 1 and world > 1:
+            # a launcher that shows every rank its own card only (HIP_VISIBLE_DEVICES per rank): this rank uses device 0.  If
+            # the ranks really share one card, RCCL refuses the duplicate device when the process group comes up - loudly.
+            return None
+        check_world(world, backend, shared, n_dev)
         return None
     check_world(n_ranks, backend, shared)
     if n_ranks == 1:
@@ -144,13 +149,16 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
 
 def init_process_group_from_env(backend: str | None = None):
     """Initialises torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract).  Returns
-    (rank, world_size, local_rank).  world_size 1 needs no process group."""
+    (rank, world_size, local_rank) - local_rank = the device index of this rank: LOCAL_RANK, or 0 when the launcher shows
+    every rank one card only.  world_size 1 needs no process group."""
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and visible_devices() == 1:
+        local_rank = 0
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -144,6 +144,12 @@ def test_launch_refuses_what_it_cannot_honour(monkeypatch):
     with pytest.raises(SystemExit) as e:
         D.launch_ranks_if_needed(4, "unused.py", [])
     assert e.value.code == 2
+    monkeypatch.setenv("WORLD_SIZE", "8")         # a launcher that shows every rank one card only: accepted, the rank uses device 0
+    assert D.launch_ranks_if_needed(8, "unused.py", []) is None
+    monkeypatch.setattr(D, "visible_devices", lambda: 4)   # but four cards for eight ranks is refused
+    with pytest.raises(SystemExit):
+        D.launch_ranks_if_needed(8, "unused.py", [])
+    monkeypatch.setattr(D, "visible_devices", lambda: 1)
     monkeypatch.delenv("WORLD_SIZE")
     monkeypatch.setenv("SART_BENCH_DEVICE", "0")  # several ranks on one card: gloo only, at most six
     with pytest.raises(SystemExit):
