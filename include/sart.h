@@ -333,7 +333,9 @@ int sart_trace_records_device(sart_context* ctx, const sart_trace_params_t* para
  * Fused trace + accumulation: traceAxionWrapper + prepareHeatmap(256,256,...,norm=1) (:2629)
  * + flux sum (:2800) + the counters echoed at :2253-2257, without materialising records.
  * `accumulator_device` is DEVICE memory of sart_accumulator_len(nx,ny) doubles; the call is
- * asynchronous on the context's stream (pair with sart_synchronize).
+ * asynchronous on the context's stream (pair with sart_synchronize) - except for the first launch after the geometry,
+ * the tables or the image binning changed: it is preceded by a 2e5-ray pilot launch whose centroid places the LDS image
+ * tile, read back with one stream synchronisation (~60 us).
  */
 int sart_trace_histogram_device(sart_context* ctx, const sart_trace_params_t* params,
                                 double* accumulator_device);

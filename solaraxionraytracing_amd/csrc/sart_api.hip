@@ -149,6 +149,7 @@ struct sart_context {
     bool no_path_const = false;      // SART_NO_PATH_CONST: never use the constant-path kernel variant (5)
     bool no_host_prefault = false;   // SART_NO_HOST_PREFAULT: sart_trace_records leaves the caller's buffer as it finds it
     int records_chunk = 0;           // SART_RECORDS_CHUNK: records per chunk of sart_trace_records (0 = 1 Mi)
+    int prefault_threads = 0;        // SART_PREFAULT_THREADS: host threads that fault the caller's record buffer in (0 = 8)
     bool force_generic = false;      // SART_FORCE_GENERIC: never use the specialised kernel variant
     int image_replicas = 0;          // SART_IMAGE_REPLICAS: 0 = chosen from the plate scale
     int hist_blocks_per_cu = 0;      // SART_HIST_BLOCKS_PER_CU: 0 = occupancy query
@@ -791,6 +792,7 @@ int sart_create(int device_ordinal, sart_context** out) {
     c->knobs.no_path_const = flag("SART_NO_PATH_CONST");
     c->knobs.no_host_prefault = flag("SART_NO_HOST_PREFAULT");
     c->knobs.records_chunk = number("SART_RECORDS_CHUNK");
+    c->knobs.prefault_threads = number("SART_PREFAULT_THREADS");
     c->knobs.force_generic = flag("SART_FORCE_GENERIC");
     c->knobs.image_replicas = number("SART_IMAGE_REPLICAS");
     c->knobs.hist_blocks_per_cu = number("SART_HIST_BLOCKS_PER_CU");
@@ -1085,7 +1087,8 @@ namespace {
 
 class HostPrefault {   // faults [base, base + bytes) in, chunk by chunk, on a background thread; wait(k) blocks until chunk k is mapped
  public:
-  HostPrefault(char* base, size_t bytes, size_t chunk_bytes, bool enabled) : base_(base), bytes_(bytes), chunk_(chunk_bytes) {
+  HostPrefault(char* base, size_t bytes, size_t chunk_bytes, bool enabled, unsigned threads)
+      : base_(base), bytes_(bytes), chunk_(chunk_bytes), threads_(threads ? threads : 8u) {
     n_chunks_ = (bytes + chunk_bytes - 1) / chunk_bytes;
     if (!enabled || bytes < (size_t(8) << 20)) { done_ = n_chunks_; return; }   // small buffers: not worth a thread
     const long page = sysconf(_SC_PAGESIZE);
@@ -1104,7 +1107,7 @@ class HostPrefault {   // faults [base, base + bytes) in, chunk by chunk, on a b
  private:
   void run() {
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned n_threads = std::min(8u, hw);
+    const unsigned n_threads = std::min(threads_, hw);
     for (size_t k = 0; k < n_chunks_; ++k) {
       // whole pages inside this chunk (the partial pages at the ends of the buffer are mapped by the copy itself)
       const uintptr_t b = reinterpret_cast<uintptr_t>(base_) + k * chunk_;
@@ -1132,6 +1135,7 @@ class HostPrefault {   // faults [base, base + bytes) in, chunk by chunk, on a b
   }
   char* base_;
   size_t bytes_, chunk_, n_chunks_ = 0, page_ = 4096, done_ = 0;
+  unsigned threads_;
   std::mutex m_;
   std::condition_variable cv_;
   std::thread worker_;
@@ -1161,7 +1165,8 @@ int sart_trace_records(sart_context* c, const sart_trace_params_t* p, sart_axion
   }
   sart_axion_t* const bufs[2] = {c->d_rec.p, c->d_rec2.p};
   const uint64_t n_chunks = (n + chunk - 1) / chunk;
-  HostPrefault prefault(reinterpret_cast<char*>(out), n * sizeof(sart_axion_t), chunk * sizeof(sart_axion_t), !c->knobs.no_host_prefault);
+  HostPrefault prefault(reinterpret_cast<char*>(out), n * sizeof(sart_axion_t), chunk * sizeof(sart_axion_t), !c->knobs.no_host_prefault,
+                        static_cast<unsigned>(c->knobs.prefault_threads));
   sart_trace_params_t q = *p;
   int rc = 0;
   for (uint64_t k = 0; k <= n_chunks && rc == 0; ++k) {
