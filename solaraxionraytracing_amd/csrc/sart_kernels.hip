@@ -211,6 +211,50 @@ __device__ __forceinline__ double cos_yaw_of_slope(double t) {
   return r;
 }
 
+// exp(x) for x <= 0 - the two exponentials of the gas stage, exp(-Gamma L / 2) and exp(-(mu_pipe d + mu_magnet L))
+// (axionMassforMagnet.nim:75-113) - in 20 vector instructions instead of the library's ~40: n = rint(x log2 e),
+// r = x - n ln 2 in two pieces (|r| <= 0.3466), Taylor series to r^13 (truncation 4e-18), one v_ldexp_f64.  <= 1.5 ulp
+// (tests/test_gpu_math.py); x < -746 gives 0, like the library.
+__device__ __forceinline__ double exp_neg(double x) {
+  x = fmax(x, -746.0);
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double r = fma(n, -0.6931471805598903, x);         // ln 2, high part (low 11 bits zero: n * hi is exact)
+  r = fma(n, -5.497923018708371e-14, r);             // ln 2, low part
+  double p = 1.6059043836821613e-10;                 // 1/13!
+  p = HORNER(p, r, 2.08767569878681e-09);            // 1/12!
+  p = HORNER(p, r, 2.505210838544172e-08);           // 1/11!
+  p = HORNER(p, r, 2.755731922398589e-07);           // 1/10!
+  p = HORNER(p, r, 2.7557319223985893e-06);          // 1/9!
+  p = HORNER(p, r, 2.48015873015873e-05);            // 1/8!
+  p = HORNER(p, r, 0.0001984126984126984);           // 1/7!
+  p = HORNER(p, r, 0.001388888888888889);            // 1/6!
+  p = HORNER(p, r, 0.008333333333333333);            // 1/5!
+  p = HORNER(p, r, 0.041666666666666664);            // 1/4!
+  p = HORNER(p, r, 0.16666666666666666);             // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
+// cos(y) for the phase q L of the gas-stage conversion probability (any finite y; thousands of radians far from the
+// resonance): y / (2 pi) with 1 / (2 pi) in two pieces (the FMA keeps the product exact before the integer part is taken
+// away, the second piece corrects it: the fraction of a turn is good to ~1e-16 for |y| < 1e15), then the table-based
+// cosine of the sampling angles (sincos_turns: (cos, sin)(pi k / 64) from LDS + degree-3 polynomials).  Absolute error
+// <= 2.5e-16 + 7e-16 |y| 2^-53 ... in practice <= 1.5 ulp(1); the library's Payne-Hanek path costs ~100 instructions.
+__device__ __forceinline__ double cos_any(double y, const double* __restrict__ table, const SinCosCoef& K) {
+  const double n = __builtin_rint(y * 0.15915494309189535);
+  double f = fma(y, 0.15915494309189535, -n);        // 1 / (2 pi), high part
+  f = fma(y, -9.839338337591243e-18, f);             // low part
+  double sn, cs;
+  sincos_turns<2>(fabs(f), table, K, &sn, &cs);      // cos is even; |f| <= 0.5 + 1e-16
+  if (!(fabs(y) < 1e15)) {
+    asm volatile("; rare: cos of a huge or non-finite phase");
+    cs = cos(y);
+  }
+  return cs;
+}
+
 // The table pointers of a launch are read from the LDS copy of the parameter blob, where the compiler cannot see
 // their address space and would emit flat_load (which counts on both vmcnt and lgkmcnt and so serialises against the
 // LDS traffic of the same wave).  They always point to global memory: say so.
@@ -889,13 +933,13 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
       if (!(flags & SART_CF_IGNORE_CONV_PROB)) {
         const double q = fabs((P.gas_m_gamma_sq - P.m_axion_sq) / en.two_e_ev);
         const double g = en.gamma;
-        const double term2 = 1.0 / fma(q, q, g * g * 0.25);
-        const double eh = exp(-g * Lnat * 0.5);                        // exp(-Gamma L) = eh^2: one exp for both terms
-        const double term3 = fma(eh, eh, 1.0) - 2.0 * eh * cos(q * Lnat);
+        const double term2 = frcp(fma(q, q, g * g * 0.25));
+        const double eh = exp_neg(-g * Lnat * 0.5);                    // exp(-Gamma L) = eh^2: one exp for both terms
+        const double term3 = fma(eh, eh, 1.0) - 2.0 * eh * cos_any(q * Lnat, L.sincos, sincos_coef());
         prob = P.gas_term1 * term2 * term3;
       }
       // intensitySuppression2 (axionMassforMagnet.nim:100-113): exp(-mu_pipe d) exp(-mu_magnet L) as one exponential
-      absorb = exp(-fma(en.mu_pipe, distance_pipe_m, en.mu_magnet * (path_cb * 1e-3)));
+      absorb = exp_neg(-fma(en.mu_pipe, distance_pipe_m, en.mu_magnet * (path_cb * 1e-3)));
     }
     trans_magnet = cos_ya * prob * absorb;          // cos of a degree value taken as radians — sic (:1598)
   }
@@ -1636,6 +1680,8 @@ __global__ void math_eval_kernel(int fn, const double* __restrict__ in, double* 
     case 9: r = atan_small(x); break;
     case 10: r = cos_small(x); break;
     case 11: r = fsqrt(x); break;
+    case 12: r = exp_neg(x); break;
+    case 13: r = cos_any(x, tab, K); break;
     default: break;
   }
   out[i] = r;

@@ -95,3 +95,34 @@ def test_small_angle_series():
     assert _ulps(_eval(9, a)[0], np.arctan(a.astype(np.longdouble))).max() <= 1.5          # atan_small
     c = rng.uniform(-1.0, 1.0, 20_000)
     assert np.abs(_eval(10, c)[0] - np.cos(c.astype(np.longdouble)).astype(np.float64)).max() <= 2.3e-16   # cos_small
+
+
+def test_gas_stage_exponential_and_cosine():
+    """exp_neg (x <= 0) and cos_any (the phase q L, thousands of radians far from the resonance) of the gas-stage conversion
+    probability and absorption (axionMassforMagnet.nim:75-113), against long double / mpmath."""
+    import mpmath as mp
+    mp.mp.dps = 40
+    x = -np.concatenate([np.exp(rng.uniform(np.log(1e-12), np.log(700.0), N)), np.array([0.0, 1e-300, 0.5, 1.0, 708.0, 745.0])])
+    got = _eval(12, x)[0]
+    want = np.exp(x.astype(np.longdouble))
+    ok = want > 1e-300                                           # (long double exp is itself good to ~1e-19 relative)
+    assert _ulps(got[ok], want[ok]).max() <= 1.5, _ulps(got[ok], want[ok]).max()
+    assert _eval(12, np.array([0.0]))[0][0] == 1.0
+    assert _eval(12, np.array([-800.0, -1e6, -np.inf]))[0].tolist() == [0.0, 0.0, 0.0]
+    # a handful of points against mpmath (independent of the C library)
+    for xv in (-1e-9, -0.3, -1.0, -17.25, -300.0):
+        assert abs(mp.mpf(float(_eval(12, np.array([xv]))[0][0])) / mp.exp(mp.mpf(xv)) - 1) < 3e-16
+    y = np.concatenate([rng.uniform(0.0, 10.0, N // 2), np.exp(rng.uniform(np.log(10.0), np.log(1e9), N // 2)),
+                        np.array([0.0, np.pi / 2, np.pi, 1e12, 123456.789])])
+    got = _eval(13, y)[0]
+    want = np.array([float(mp.cos(mp.mpf(float(v)))) for v in y[-5:]] )
+    tol = 5e-16     # 2 ulp(1) = 4.4e-16 measured: the fraction of a turn is rounded to 2^-54 (3.5e-16 rad) before the table cosine's own 1.25 ulp(1)
+    assert np.abs(got[-5:] - want).max() <= tol
+    want_ld = np.cos(y.astype(np.longdouble))                    # x87 cos is accurate for |y| < 2^63 only to ~1e-19 * |y|: keep to y < 1e6 here
+    small = y < 1e6
+    assert np.abs(got[small] - want_ld[small].astype(np.float64)).max() <= tol
+    big = [float(v) for v in y[~small][:200]]
+    assert max(abs(float(mp.cos(mp.mpf(v))) - float(g)) for v, g in zip(big, got[~small][:200])) <= tol
+    assert _eval(13, -y[:1000])[0].tolist() == got[:1000].tolist()          # even
+    huge = _eval(13, np.array([3e15, 1e300]))[0]                            # beyond the fast path: the library
+    assert abs(huge[0] - float(mp.cos(mp.mpf(3e15)))) < 1e-15 and abs(huge[1]) <= 1.0
