@@ -131,19 +131,40 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SART_BENCH_BACKEND=backend)
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    import signal
+
+    def stop_children(signum, _frame):   # a killed launcher must not leave ranks behind on the GPUs (exact PIDs)
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        raise SystemExit(128 + signum)
+
+    old = {sig: signal.signal(sig, stop_children) for sig in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
     alive = list(procs)
-    while alive:
-        for p in list(alive):
-            code = p.poll()
-            if code is None:
-                continue
-            alive.remove(p)
-            if code != 0 and rc == 0:
-                rc = code if code > 0 else 1
-                for q in alive:          # a dead rank leaves the others waiting in a collective: end them
-                    q.terminate()
-        time.sleep(0.05)
+    try:
+        while alive:
+            for p in list(alive):
+                code = p.poll()
+                if code is None:
+                    continue
+                alive.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for q in alive:          # a dead rank leaves the others waiting in a collective: end them
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:                      # whatever ends the wait (an exception, a signal): no rank outlives the launcher
+            if q.poll() is None:
+                q.terminate()
+        for q in procs:
+            try:
+                q.wait(timeout=10)
+            except Exception:
+                q.kill()
+        for sig, h in old.items():
+            signal.signal(sig, h)
     return rc
 
 

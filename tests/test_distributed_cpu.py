@@ -247,3 +247,34 @@ def test_two_rank_fixed64_reduce_is_exact(tmp_path):
     # f64 tensors that carry int64 bit patterns (a caller that allocated doubles) reduce the same way
     t = torch.from_numpy(one.copy()).view(torch.float64)
     assert D.reduce_accumulator(t, dst=0, fixed64=True) is t
+
+
+def test_killed_launcher_takes_its_ranks_with_it(tmp_path):
+    """SIGTERM to the launching process (a driver's timeout) ends the ranks it started: none stays behind on a GPU."""
+    import signal
+    import subprocess
+    import time
+    rank_script = tmp_path / "sleepy_rank.py"
+    rank_script.write_text("import os, sys, time\nopen(os.path.join(sys.argv[1], 'pid%s' % os.environ['RANK']), 'w').write(str(os.getpid()))\ntime.sleep(120)\n")
+    launcher = tmp_path / "launcher.py"
+    launcher.write_text("import sys\nsys.path.insert(0, %r)\nfrom solaraxionraytracing_amd import distributed as D\nD.visible_devices = lambda: 2\n"
+                        "raise SystemExit(D.launch_ranks_if_needed(2, %r, [%r]))\n" % (ROOT, str(rank_script), str(tmp_path)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SART_BENCH_DEVICE")}
+    p = subprocess.Popen([sys.executable, str(launcher)], env=dict(env, SART_BENCH_BACKEND="gloo"))
+    deadline = time.time() + 60
+    while time.time() < deadline and not all((tmp_path / ("pid%d" % r)).exists() for r in (0, 1)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / ("pid%d" % r)).read_text()) for r in (0, 1)]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for pid in pids:
+        alive = True
+        try:
+            os.kill(pid, 0)
+            # a terminated child that has not been reaped yet shows as a zombie of init for a moment: look at its state
+            state = open("/proc/%d/stat" % pid).read().split(")")[-1].split()[0]
+            alive = state not in ("Z", "X")
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, pid
