@@ -37,6 +37,7 @@ int histogram_blocks_per_cu(int variant);
 void launch_build_solar_tables(const double* em_dev, const double* radii_dev, const double* energies_dev, int n_radii, int n_energies,
                                double* cdf_dev, double* row_sum_dev, double* rcdf_dev, uint16_t* rguide_dev, uint16_t* eguide_dev,
                                uint32_t* status_dev, hipStream_t stream);
+void launch_cdf_hi32(const double* cdf_dev, uint32_t* out_dev, size_t n, hipStream_t stream);
 }  // namespace sart
 
 using namespace sart;
@@ -183,6 +184,7 @@ struct sart_context {
   DevBuf<double> d_sincos;     // (cos, sin)(pi k / 64), k = 0 .. 128 (sampling angles, sart_kernels.hip: sincos_turns)
   DevBuf<uint8_t> d_lut;
   DevBuf<double> d_rcdf, d_ecdf, d_refl;
+  DevBuf<uint32_t> d_ecdf_hi32;   // upper 32 of the 52 bits of floor(d_ecdf 2^52): the candidates of the energy draw (HotB::cdf_hi32)
   DevBuf<uint16_t> d_rguide, d_eguide;
   DevBuf<EnergyDev> d_etab;
   DevBuf<double> d_replicas;   // kImageReplicas scratch images (kept zeroed between launches)
@@ -644,6 +646,7 @@ int sync_blob(sart_context* c) {
   if (int rc = c->d_blob.upload(&b, 1)) return rc;
   c->hot = hot_of(c->params);
   c->hotb.diff_flux_cdfs = c->d_ecdf.p;
+  c->hotb.cdf_hi32 = c->d_ecdf_hi32.p;
   c->hotb.energy_guide = c->d_eguide.p;
   c->hotb.energy_tab = c->d_etab.p;
   c->hotb.refl = c->d_refl.p;
@@ -942,6 +945,10 @@ int sart_set_solar_tables(sart_context* c, const double* rcdf, const double* ecd
   }
   if (int rc = c->d_rcdf.upload(rcdf, nR)) return rc;
   if (int rc = c->d_ecdf.upload(padded.data(), padded.size())) return rc;
+  if (int rc = c->d_ecdf_hi32.resize(padded.size())) return rc;
+  launch_cdf_hi32(c->d_ecdf.p, c->d_ecdf_hi32.p, padded.size(), c->stream);   // one definition of the 32-bit table: the device kernel
+  SART_HIP(hipGetLastError());
+  SART_HIP(hipStreamSynchronize(c->stream));
   if (int rc = c->d_rguide.upload(rg.data(), rg.size())) return rc;
   if (int rc = c->d_eguide.upload(eg.data(), eg.size())) return rc;
   c->energies.assign(energies, energies + nE);
@@ -971,9 +978,11 @@ int sart_set_solar_tables_device(sart_context* c, const double* em_rates_dev, co
   if (int rc = c->d_ecdf.resize(static_cast<size_t>(nR) * (static_cast<size_t>(nE) + kEnergyCdfPad))) return rc;
   if (int rc = c->d_rguide.resize(kRadiusGuide + 1)) return rc;
   if (int rc = c->d_eguide.resize(static_cast<size_t>(nR) * kEnergyGuideEntries)) return rc;
+  if (int rc = c->d_ecdf_hi32.resize(static_cast<size_t>(nR) * (static_cast<size_t>(nE) + kEnergyCdfPad))) return rc;
   c->have_solar = false;                       // until the new tables are known to be CDFs
   launch_build_solar_tables(em_rates_dev, d_radii.p, d_energies.p, nR, nE, c->d_ecdf.p, d_row_sum.p, c->d_rcdf.p, c->d_rguide.p,
                             c->d_eguide.p, d_status.p, c->stream);
+  launch_cdf_hi32(c->d_ecdf.p, c->d_ecdf_hi32.p, c->d_ecdf_hi32.n, c->stream);
   SART_HIP(hipGetLastError());
   uint32_t status[2] = {0, 0};
   SART_HIP(hipMemcpyAsync(status, d_status.p, sizeof status, hipMemcpyDeviceToHost, c->stream));

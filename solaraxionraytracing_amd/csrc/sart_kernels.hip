@@ -406,16 +406,26 @@ __device__ __forceinline__ T gload(const void* base, uint32_t byte_off) {
 //   candidates  bracket [lo, hi] from the guide word, gather of row[lo .. lo + 3] (rows are padded with 1.0)
 //   finish      lo + #{candidates < u5}: the row is sorted and row[hi] >= u5, so candidates at or beyond hi never count;
 //               only a lane whose four candidates are all < u5 with hi > lo + 4 goes on with a binary search
+typedef uint32_t u4v __attribute__((ext_vector_type(4)));   // native vector: loads as one 16-byte access
 struct EnergyDraw {
   double u;
+  uint32_t khi;        // upper 32 of the 52 bits of u 2^52
   uint32_t row;        // element offset of the CDF row
   uint32_t gword;      // guide entries k (low half) and k + 1 (high half)
   uint32_t lo, hi;
-  d2 c01, c23;         // row[lo .. lo + 3]
+  u4v c;               // cdf_hi32 of row[lo .. lo + 3]
 };
 __device__ __forceinline__ void energy_draw_begin(const HotB& HB, int r_idx, double u5, EnergyDraw& d, int r_idx_guide = -1) {
   if (r_idx_guide < 0) r_idx_guide = r_idx;   // (experiment builds pass another row for the guide gather: working-set sensitivity)
   d.u = u5;
+  {
+    // u5 = k 2^-52 exactly (u52: 52 random mantissa bits under the exponent of 1.0, minus 1.0): 1 + u5 carries k in its
+    // mantissa, and its upper 32 bits are one funnel shift away.  (A uniform handed in from outside - the test entry - may
+    // have bits below 2^-52: the sum then rounds k by at most 1/2, which energy_draw_finish allows for; the clamp keeps a
+    // uniform within 2^-53 of 1 out of the next binade.)
+    const double w = fmin(u5 + 1.0, 1.9999999999999998);
+    d.khi = __builtin_amdgcn_alignbit((uint32_t)__double2hiint(w), (uint32_t)__double2loint(w), 20u);
+  }
   const double v = 1.0 - u5;
   const uint32_t ku = (uint32_t)(int)(u5 * (double)kEnergyGuideDiv);
   const uint32_t code = (uint32_t)__double2hiint(v) >> 14;                       // exponent and six mantissa bits of v
@@ -428,15 +438,22 @@ __device__ __forceinline__ void energy_draw_begin(const HotB& HB, int r_idx, dou
 __device__ __forceinline__ void energy_draw_candidates(const HotB& HB, EnergyDraw& d) {
   d.lo = d.gword & 0xFFFFu;
   d.hi = d.gword >> 16;
-  const uint32_t off = (d.row + d.lo) * 8u;
-  d.c01 = gload<d2>(HB.diff_flux_cdfs, off);
-  d.c23 = gload<d2>(HB.diff_flux_cdfs, off + 16u);
+  // four consecutive u32 of a row whose stride is a multiple of four entries only by accident: the 16 bytes may straddle a
+  // 16-byte boundary, global_load_dwordx4 needs 4-byte alignment only
+  d.c = gload<u4v>(HB.cdf_hi32, (d.row + d.lo) * 4u);
 }
 __device__ __forceinline__ int energy_draw_finish(const HotB& HB, const EnergyDraw& d) {
   const double u = d.u;
-  uint32_t lo = d.lo + (uint32_t)(d.c01.x < u) + (uint32_t)(d.c01.y < u) + (uint32_t)(d.c23.x < u) + (uint32_t)(d.c23.y < u);
-  if ((d.c23.y < u) & (d.hi > d.lo + 4u)) {   // rare: a wide bucket whose first four entries are all below u
-    asm volatile("; rare: energy bucket wider than four entries");
+  // With T = floor(cdf 2^52) >> 20 (the table) and K = the upper 32 bits of u 2^52 rounded to an integer k':  T < K - 1 =>
+  // floor(cdf 2^52) <= k' - 2^20 - 1 => cdf < u;  T > K => cdf 2^52 >= k' + 1 => cdf >= u (u 2^52 lies within 1/2 of k').
+  // T in {K - 1, K}: undecided (2^-31 per candidate) - the f64 row decides, as it does in a wide bucket whose first four
+  // entries are all below u.  (The 1.0 pads behind a row read 0xFFFFFFFF.)
+  const uint32_t km1 = max(d.khi, 1u) - 1u;
+  uint32_t lo = d.lo + (uint32_t)(d.c.x < km1) + (uint32_t)(d.c.y < km1) + (uint32_t)(d.c.z < km1) + (uint32_t)(d.c.w < km1);
+  const bool tie = ((d.c.x - km1) < 2u) | ((d.c.y - km1) < 2u) | ((d.c.z - km1) < 2u) | ((d.c.w - km1) < 2u);
+  if (((d.c.w < km1) & (d.hi > d.lo + 4u)) | tie) {
+    asm volatile("; rare: energy bucket wider than four entries, or a tie in the upper 32 bits");
+    if (tie) lo = d.lo;
     uint32_t hi = d.hi;
     while (lo < hi) {
       const uint32_t mid = (lo + hi) >> 1;

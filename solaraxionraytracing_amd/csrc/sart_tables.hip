@@ -131,6 +131,17 @@ __global__ __launch_bounds__(256) void energy_guide_kernel(const double* __restr
   guide[(size_t)r * kEnergyGuideEntries + k] = (uint16_t)v;
 }
 
+// cdf_hi32[i] = min(floor(cdf[i] 2^52) >> 20, 2^32 - 1) for every entry of the padded table (HotB::cdf_hi32)
+__global__ __launch_bounds__(256) void cdf_hi32_kernel(const double* __restrict__ cdf, uint32_t* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long t = __double2ull_rd(cdf[i] * 4503599627370496.0) >> 20;   // the product is exact: cdf <= 1
+  out[i] = t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
+}
+void launch_cdf_hi32(const double* cdf_dev, uint32_t* out_dev, size_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(cdf_hi32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cdf_dev, out_dev, n);
+}
+
 // status[0]: bit 0 = a diffFluxCDFs row is not a CDF, bit 1 = fluxRadiusCDF is not; status[1] = radius_span
 void launch_build_solar_tables(const double* em_dev, const double* radii_dev, const double* energies_dev, int n_radii, int n_energies,
                                double* cdf_dev, double* row_sum_dev, double* rcdf_dev, uint16_t* rguide_dev, uint16_t* eguide_dev,

@@ -130,3 +130,30 @@ def test_energy_draw_over_the_whole_guide_matches_lower_bound():
         rec = rt.traceAxionWrapper(n, seed=31)
     ref = Oracle(full).trace_records(n, seed=31)
     np.testing.assert_array_equal(rec["energiesPre"], ref["energiesPre"])
+
+
+def test_energy_draw_on_the_cdf_entries_themselves():
+    """The four-candidate count of the energy draw compares the upper 32 bits of floor(cdf 2^52) with those of the uniform and lets
+    the f64 row decide ties (sart_kernels.hip: energy_draw_finish).  Here the uniforms ARE table entries and their f64
+    neighbours - every draw is a tie in the upper bits - fed through the explicit-uniform test entry; the energy index must be
+    std/algorithm.lowerBound's (raytracer.nim:464-468) for every one of them."""
+    full = full_setup("babyiaxo_xmm")
+    rcdf, ecdf, energies = full.fluxRadiusCDF, full.diffFluxCDFs, full.energies
+    rng = np.random.default_rng(11)
+    n = 30_000
+    rows = rng.integers(1, 700, n)                              # radius rows that carry probability
+    u2 = 0.5 * (rcdf[rows - 1] + rcdf[rows])                    # lowerBound(rcdf, u2) == rows
+    assert np.array_equal(np.searchsorted(rcdf, u2, side="left"), rows)
+    cols = rng.integers(0, energies.size - 1, n)
+    entry = ecdf[rows, cols]
+    kind = rng.integers(0, 5, n)
+    u5 = np.where(kind == 0, entry, np.where(kind == 1, np.nextafter(entry, 0.0), np.where(kind == 2, np.nextafter(entry, 1.0),
+                  np.where(kind == 3, entry * (1 - 2.0 ** -40), entry * (1 + 2.0 ** -40)))))
+    u5 = np.clip(u5, 0.0, np.nextafter(1.0, 0.0))
+    u = np.column_stack([np.full(n, 0.3), np.full(n, 0.4), u2, np.full(n, 1e-4), np.full(n, 0.7), u5])
+    with sa.RayTracer(full) as rt:
+        rec = rt.trace_records_uniforms(u)
+    want_idx = np.array([min(np.searchsorted(ecdf[r], x, side="left"), energies.size - 1) for r, x in zip(rows, u5)])
+    want = np.maximum(0.03, energies[want_idx])                 # :470-471
+    np.testing.assert_array_equal(rec["energiesPre"], want)
+    assert len(np.unique(want_idx)) > 1000                      # the whole energy range, not one corner of it
