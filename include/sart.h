@@ -368,6 +368,10 @@ int sart_trace_histogram_spectra(sart_context* ctx, const sart_trace_params_t* p
  *            a pixel that n rays hit carries a rounding error of ~q_w sqrt(n / 12): an image of 2e7 rays agrees with the f64
  *            image to < 1e-12 of its largest pixel, larger images better.  SUM_WEIGHTS_SQ: q = w_bound^2 2^-19 (a 44-bit
  *            ray count).  SUM_X / SUM_Y / SUM_R: 2^-32 mm.  energy_reflect spectrum: 2^-40.
+ *            The bound sees table maxima (for the X-ray test source: the values at its one energy), not what the rays
+ *            actually meet: every ray's rounding error is <= q_w / 2 in absolute terms whatever its weight, and the blocking
+ *            host-output calls fail with SART_ERR_INVALID_ARGUMENT when the accumulated weights average below 2^12 quanta per
+ *            ray (an outlier in a table inflated the bound): use a smaller headroom then.
  *   limbs    SUM_WEIGHTS, SUM_X, SUM_Y, SUM_R receive every passed ray of every launch: value = (hi * 2^40 + lo) * q with
  *            lo in slot SART_ACC_SUM_*, hi in slot SART_ACC_SUM_*_HI (after a launch 0 <= lo < 2^40; limb-wise int64 sums
  *            over up to 2^22 ranks stay exact).

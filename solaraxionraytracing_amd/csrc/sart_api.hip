@@ -434,13 +434,18 @@ int hoist_energy_tables(sart_context* c) {
     e.mu_pipe = massAtt * density(pGas, s.room_temp) * 100;                // :109-113
     e.mu_magnet = massAtt * density(pGas, s.magnet_tGas) * 100;
   }
-  // bounds for the FIXED64 weight quantum: the solar source draws indices < nE, the X-ray test source uses row nE
-  c->etab_max.assign(4, 0.0);
-  for (const EnergyDev& e : tab) {
+  // bounds for the FIXED64 weight quantum: the solar source draws indices < nE ([0..3]: maxima over those rows), the X-ray test
+  // source uses row nE alone ([4..7]: its values - at BabyIAXO's 0.021 keV they are orders of magnitude below the maxima)
+  c->etab_max.assign(8, 0.0);
+  for (int i = 0; i < nE; ++i) {
+    const EnergyDev& e = tab[i];
     c->etab_max[0] = std::max(c->etab_max[0], std::fabs(e.t_window));
     c->etab_max[1] = std::max(c->etab_max[1], std::fabs(e.t_strongback));
     c->etab_max[2] = std::max(c->etab_max[2], std::fabs(e.a_gas));
   }
+  c->etab_max[4] = std::fabs(tab[nE].t_window);
+  c->etab_max[5] = std::fabs(tab[nE].t_strongback);
+  c->etab_max[6] = std::fabs(tab[nE].a_gas);
   return c->d_etab.upload(tab.data(), tab.size());
 }
 
@@ -471,9 +476,17 @@ int hoist_reflectivity(sart_context* c) {
     }
   }
   {
-    double m = 0.0;   // |R| <= max |g| for every angle inside the grid (the kernel clamps the cell; outside it extrapolates
-    for (double v : out) m = std::max(m, std::fabs(v));   // from the edge cell: factor 2 of slack in weight_bound_of)
+    // |R| <= max |g| for every angle inside the grid (the kernel clamps the cell; outside it extrapolates from the edge cell);
+    // [3]: the rows of the solar energies, [7]: the rows of the test source's energy (index nE of every coating)
+    double m = 0.0, mt = 0.0;
+    for (int cc = 0; cc < nC; ++cc)
+      for (int e = 0; e <= nE; ++e) {
+        const double* g = out.data() + (static_cast<size_t>(cc) * (nE + 1) + e) * nA;
+        double& dst = (e < nE) ? m : mt;
+        for (int i = 0; i < nA; ++i) dst = std::max(dst, std::fabs(g[i]));
+      }
     c->etab_max[3] = m;
+    c->etab_max[7] = mt;
   }
   return c->d_refl.upload(out.data(), out.size());
 }
@@ -683,16 +696,17 @@ DevTables tables_of(sart_context* c) {
 // conversion of a weight to quanta stays exact up to 2^(51 - 63 + headroom) >= 2^4 times the bound, it only uses up headroom.
 double weight_bound_of(const sart_context* c, uint32_t flags) {
   const DevParams& P = c->params;
+  const double* m = c->etab_max.data() + (P.test_active ? 4 : 0);   // the test source has ONE energy: its row, not the maxima
   double b = 1.0;
-  if (!(flags & SART_CF_IGNORE_REFLECTION)) b *= c->etab_max[3] * c->etab_max[3];
+  if (!(flags & SART_CF_IGNORE_REFLECTION)) b *= m[3] * m[3];
   if (!(flags & SART_CF_IGNORE_CONV_PROB)) {
     // vacuum: conv_k pathCB^2, pathCB ~ lengthB (:363-365); gas: |integral of exp((iq - Gamma/2) z)|^2 <= L^2 in natural
     // units (axionMassforMagnet.nim:75-98)
     const double l_nat = P.length_b * P.gas_inv_hbarc_m;
     b *= P.stage_gas ? P.gas_term1 * l_nat * l_nat : P.conv_k * P.length_b * P.length_b;
   }
-  if (!(flags & SART_CF_IGNORE_DET_WINDOW)) b *= std::max(c->etab_max[0], c->etab_max[1]);
-  if (!(flags & SART_CF_IGNORE_GAS_ABS)) b *= c->etab_max[2];
+  if (!(flags & SART_CF_IGNORE_DET_WINDOW)) b *= std::max(m[0], m[1]);
+  if (!(flags & SART_CF_IGNORE_GAS_ABS)) b *= m[2];
   if (!(flags & SART_CF_XRAY_TEST)) b *= P.exposure;
   return b;
 }
@@ -1369,7 +1383,18 @@ int sart_trace_histogram_spectra(sart_context* c, const sart_trace_params_t* p, 
   if (spectra_out && p->spectra)
     SART_HIP(hipMemcpyAsync(spectra_out, src + nimg + SART_ACC_COUNT, (len - nimg - SART_ACC_COUNT) * sizeof(double),
                             hipMemcpyDeviceToHost, c->stream));
+  double check[SART_ACC_COUNT];
+  const bool fixed = c->accum_mode == SART_ACCUM_FIXED64;
+  if (fixed) SART_HIP(hipMemcpyAsync(check, src + nimg, sizeof check, hipMemcpyDeviceToHost, c->stream));
   SART_HIP(hipStreamSynchronize(c->stream));
+  if (fixed && check[SART_ACC_N_PASSED] > 0.0) {
+    // The quantum is derived from a BOUND of the weights.  If what was accumulated averages below 2^12 quanta per ray (tables
+    // or flags the bound does not see through), the integers no longer resolve the weights: say so instead of returning noise.
+    const double mean_quanta = std::ldexp(check[SART_ACC_SUM_WEIGHTS], -c->weight_exp) / check[SART_ACC_N_PASSED];
+    if (mean_quanta < 4096.0)
+      return fail(SART_ERR_INVALID_ARGUMENT, "FIXED64: the accumulated weights average below 2^12 quanta per ray (bound " +
+                                             std::to_string(c->weight_bound) + "): choose a smaller headroom or SART_ACCUM_F64");
+  }
   return 0;
 }
 
