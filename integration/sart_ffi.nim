@@ -291,6 +291,24 @@ proc performAngularScanGpu*(ctx: ptr SartContext, angles: seq[float], nRaysPerAn
     result.add s.v[AccSumWeights]
   sartCheck sart_set_telescope_angles(ctx, NaN, setup.telescope_turned_y_deg)   # the reference scans a copy (:2794)
 
+proc traceHistogramDeterministic*(ctx: ptr SartContext, nRays: int, flags: set[ConfigFlags], image: var seq[cdouble],
+                                  seed = 299792458'u64, rayIdOffset = 0'u64): SartSummary =
+  ## The same image and sums, bit for bit reproducible: integer accumulation (SART_ACCUM_FIXED64) instead of f64 atomics - the
+  ## result does not depend on the number of GPUs, on the replica layout or on how the rays are split over calls.  The call
+  ## returns doubles like traceHistogramGpu (the library converts the integer accumulator itself).
+  sartCheck sart_set_accumulation_mode(ctx, AccumFixed64.cint, 0)
+  result = traceHistogramGpu(ctx, nRays, flags, image, seed, rayIdOffset)
+  sartCheck sart_set_accumulation_mode(ctx, AccumF64.cint, 0)
+
+proc sartUploadSolarTablesFromDevice*(ctx: ptr SartContext, emRatesDevice: pointer, radii, energies: seq[float]) =
+  ## The CDF loops of initFullSetup (:2670-2705) on an emission table that already lives on the GPU (sart_emission_table_device):
+  ## cumulative sums in the reference's order, normalisation and the library's guide tables, built on the device.
+  var r = newSeq[cdouble](radii.len)
+  var e = newSeq[cdouble](energies.len)
+  for i, x in radii: r[i] = x
+  for i, x in energies: e[i] = x
+  sartCheck sart_set_solar_tables_device(ctx, emRatesDevice, addr r[0], addr e[0], r.len.int32, e.len.int32)
+
 ## calculateFluxFractions (:2755-2776) then reads:
 ##   var ctx: ptr SartContext
 ##   sartCheck sart_create(0, addr ctx)
