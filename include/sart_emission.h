@@ -11,8 +11,9 @@
  *
  * The absorption coefficient absCoef[R][E] (:790-823) is interpolated by the reference from the OPCD 3.3
  * monochromatic opacity files, which are not redistributable and not part of the reference repository.
- * A caller that has them passes the finished table (keV, same shape as the output); NULL means zero,
- * which is also what the reference computes outside 0.0732 < w < 20 (:801-808).
+ * A caller that has them builds the table with sart_emission_abs_coefs* below (files read by sart_host_opcd_load,
+ * sart_host.h) and passes it on (keV, same shape as the output); NULL means zero, which is also what the reference
+ * computes outside 0.0732 < w < 20 (:801-808).
  */
 #ifndef SART_EMISSION_H
 #define SART_EMISSION_H
@@ -86,6 +87,50 @@ int sart_emission_table_device(sart_context* ctx, const sart_solar_zone_t* zones
 int sart_emission_to_solar_tables(sart_context* ctx, const sart_solar_zone_t* zones, int32_t n_radii,
                                   const double* energies_kev, int32_t n_energies, const double* abs_coefs_dev,
                                   const sart_emission_params_t* params);
+
+/* ---- absorption coefficients from the OPCD 3.3 monochromatic opacities (readOpacityFile.nim:790-823) ----------------
+ *
+ * absCoef[R][E] = sum over the metals Z of n_Z[R][Z] * opacity_Z(T_R, n_e,R; E) * 1.97327e-8 * (0.528e-8)^2 * (1 - exp(-E / T_R))
+ * for 0.0732 < w = E / T_table(R) < 20, else 0 (:801-808).  opacity_Z is read from the density table `ne_index` of the
+ * file `fmZZ.<temp_index>` at the abscissa `table = mesh(w)`, the line number that the mesh file `fm01.mesh` assigns to w
+ * (both linear interpolations of numericalnim's newLinear1D, :217, :296, :825, :831).
+ *
+ * The tables the zones of one solar model need, flattened: one slot per distinct (temp_index, ne_index) pair, one table
+ * per slot and element.  sart_host_opcd_load (sart_host.h) builds it from an OPCD directory; all pointers are HOST
+ * pointers, the calls below copy what they need to the device. */
+typedef struct sart_opacity_tables_t {
+  const double* u_mesh;        /* [n_mesh] column `u` of fm01.mesh, strictly ascending; entry i belongs to line number i (:284-296) */
+  int32_t n_mesh;              /* 10001 in OPCD 3.3 (:281) */
+  int32_t n_slots;             /* distinct (temp_index, ne_index) pairs of the zones */
+  const int32_t* slot_of_zone; /* [n_radii] */
+  const int32_t* element_z;    /* [n_elements] proton numbers in the order of the reference's sum (ascending, :829-834) */
+  int32_t n_elements;          /* the 15 metals 6 7 8 10 11 12 13 14 16 18 20 24 25 26 28 for the reference's element list */
+  int32_t _pad;
+  const int64_t* table_y_begin; /* [n_slots][n_elements] first opacity of the table in table_y */
+  const int64_t* table_x_begin; /* [n_slots][n_elements] first abscissa in table_x, or -1: the abscissae are the line numbers
+                                   1 .. len (the 10000-line tables, :206-208) */
+  const int32_t* table_len;     /* [n_slots][n_elements] points of the table (>= 2) */
+  const double* table_x;        /* pool of abscissae (tables that carry their own first column) */
+  const double* table_y;        /* pool of opacities in atomic units (a0^2) */
+  int64_t n_table_x, n_table_y; /* pool lengths */
+} sart_opacity_tables_t;
+
+/* absCoef[n_radii][n_energies] in keV, as sart_emission_table* take it.
+ *   n_z  [n_radii][29]: number densities per proton number in 1/cm^3 (sart_host_solar_number_densities)
+ * An abscissa outside a table (numericalnim raises there) fails with SART_ERR_INVALID_ARGUMENT; nothing is clamped. */
+int sart_emission_abs_coefs(sart_context* ctx, const sart_solar_zone_t* zones, int32_t n_radii, const double* n_z,
+                            const double* energies_kev, int32_t n_energies, const sart_opacity_tables_t* tables,
+                            double* abs_coefs_out);
+/* Same with the result left on the device (for sart_emission_table_device / sart_emission_to_solar_tables). */
+int sart_emission_abs_coefs_device(sart_context* ctx, const sart_solar_zone_t* zones, int32_t n_radii, const double* n_z,
+                                   const double* energies_kev, int32_t n_energies, const sart_opacity_tables_t* tables,
+                                   double* abs_coefs_dev);
+
+/* The same front end as sart_emission_to_solar_tables with the absorption coefficients of the OPCD files in it:
+ * absCoef (above) -> emission table -> fluxRadiusCDF / diffFluxCDFs / guide tables, all on the device.  Blocking. */
+int sart_emission_to_solar_tables_opcd(sart_context* ctx, const sart_solar_zone_t* zones, int32_t n_radii, const double* n_z,
+                                       const double* energies_kev, int32_t n_energies, const sart_opacity_tables_t* tables,
+                                       const sart_emission_params_t* params);
 
 /* Duration in ms of the last emission-table kernel this process launched (HIP events on the launch stream). */
 double sart_emission_last_kernel_ms(void);

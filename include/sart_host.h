@@ -114,6 +114,34 @@ int sart_host_write_image_csv(const char* path, const double* image, int32_t wid
 int sart_host_solar_zones(const double* temp_K, const double* rho, const double* mass_fractions, int32_t n_radii,
                           sart_solar_zone_t* zones_out);
 
+/* n_Z of the same loop (:655-679): number densities per PROTON NUMBER in 1/cm^3, n_z_out[n_radii][29].  [1] hydrogen, [2]
+ * helium, [6] carbon, [7] nitrogen, [8] oxygen (isotopes joined with their mean mass), [10]..[28] neon .. nickel; the
+ * entries the reference never writes ([0], [3], [4], [5], [9]) are 0. */
+int sart_host_solar_number_densities(const double* rho, const double* mass_fractions, int32_t n_radii, double* n_z_out);
+
+/* ---- OPCD 3.3 monochromatic opacity files (readOpacityFile.nim:146-296, :731-745) -------------------------------------
+ * `<opcd_path>/OPCD_3.3/mono/fmZZ.TTT`: one header line, then per electron-density index a table = header line 1 (starts
+ * with the density index), header line 2 (unused), a line with the number of table lines (0 = 10000), the table lines
+ * (`opacity`, or `abscissa opacity`; a 10000-line table is indexed by its line count 1..10000).  `fm01.mesh`: blank-separated
+ * columns with a header line, column `u`, 10001 lines.  The data is not part of the reference repository (OPCD licence). */
+
+/* Column u of a mesh file.  u_out may be NULL (then only *n_out is set). */
+int sart_host_opcd_read_mesh(const char* path, double* u_out, int32_t capacity, int32_t* n_out);
+/* Element and temperature index from the file name, the density indices and line counts of every table in file order. */
+int sart_host_opcd_file_info(const char* path, int32_t* element, int32_t* temp_index, int32_t* n_tables, int32_t* densities_out,
+                             int32_t* lengths_out, int32_t capacity);
+/* One density table of a file: abscissae (line numbers 1..n for a 10000-line table) and opacities. */
+int sart_host_opcd_read_table(const char* path, int32_t density, double* x_out, double* y_out, int32_t capacity, int32_t* n_out);
+
+/* Everything sart_emission_abs_coefs needs for the zones of one solar model: the mesh and, for every temperature index of
+ * the zones, the files of the 17 elements the reference looks up (:827-831; a missing file or density table fails like the
+ * reference's KeyError), parsed on n_threads threads (0 = up to 16).  Only the density tables the zones use are converted. */
+typedef struct sart_opcd_set sart_opcd_set;
+int sart_host_opcd_load(const char* opcd_path, const sart_solar_zone_t* zones, int32_t n_radii, int32_t n_threads, sart_opcd_set** out);
+const sart_opacity_tables_t* sart_host_opcd_tables(const sart_opcd_set* set);   /* valid until sart_host_opcd_free */
+int sart_host_opcd_slot(const sart_opcd_set* set, int32_t slot, int32_t* temp_index, int32_t* ne_index);
+void sart_host_opcd_free(sart_opcd_set* set);
+
 /* getFluxFractionR (readOpacityFile.nim:535-584): differential flux at Earth in 1/(keV y m^2) per energy, summed over the
  * radial zones of an emission table [n_radii][n_energies] (zone r at 0.0015 + 0.0005 r solar radii). */
 int sart_host_flux_spectrum(const double* em_rates, int32_t n_radii, const double* energies_kev, int32_t n_energies,

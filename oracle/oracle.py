@@ -227,8 +227,34 @@ def load_emission() -> C.CDLL:
         lib.sart_emission_oracle_table.restype = C.c_int
         lib.sart_emission_oracle_flux_spectrum.argtypes = [_dp, _i, _dp, _i, _dp]
         lib.sart_emission_oracle_flux_spectrum.restype = None
+        lib.sart_emission_oracle_number_densities.argtypes = [_dp, _dp, _i, _dp]
+        lib.sart_emission_oracle_number_densities.restype = None
+        lib.sart_emission_oracle_abs_coefs.argtypes = [C.POINTER(SolarZone), _i, _dp, _dp, _i, C.c_void_p, _dp]
+        lib.sart_emission_oracle_abs_coefs.restype = C.c_int64
         _em_lib = lib
     return _em_lib
+
+
+def emission_number_densities(rho, mass_fractions):
+    """n_Z[n][29] by proton number (readOpacityFile.nim:655-679)."""
+    lib = load_emission()
+    rho = np.ascontiguousarray(rho, dtype=np.float64)
+    frac = np.ascontiguousarray(mass_fractions, dtype=np.float64)
+    out = np.empty((rho.size, 29))
+    lib.sart_emission_oracle_number_densities(rho.ctypes.data_as(_dp), frac.ctypes.data_as(_dp), rho.size, out.ctypes.data_as(_dp))
+    return out
+
+
+def emission_abs_coefs(zones, n_z, energies, tables):
+    """absCoefs[R][E] (readOpacityFile.nim:790-823); ``tables`` = ctypes pointer to a sart_opacity_tables_t.
+    Returns (table, number of cells whose evaluation leaves a table = where the reference raises)."""
+    lib = load_emission()
+    energies = np.ascontiguousarray(energies, dtype=np.float64)
+    n_z = np.ascontiguousarray(n_z, dtype=np.float64)
+    out = np.empty((len(zones), energies.size))
+    n_out = lib.sart_emission_oracle_abs_coefs(zones, len(zones), n_z.ctypes.data_as(_dp), energies.ctypes.data_as(_dp), energies.size,
+                                               C.cast(tables, C.c_void_p), out.ctypes.data_as(_dp))
+    return out, int(n_out)
 
 
 def emission_zones(temp_K, rho, mass_fractions):

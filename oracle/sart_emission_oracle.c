@@ -66,6 +66,113 @@ void sart_emission_oracle_zones(const double* temp, const double* rho, const dou
   }
 }
 
+/* n_Z[iRadius][.] of the same loop (:655-679): out[n][29], indexed as the reference indexes it (by proton number). */
+void sart_emission_oracle_number_densities(const double* rho, const double* mass_fractions, int32_t n, double* out) {
+  for (int32_t iRadius = 0; iRadius < n; ++iRadius) {
+    const double* e = mass_fractions + (size_t)iRadius * 29;
+    double* n_Z = out + (size_t)iRadius * 29;
+    memset(n_Z, 0, 29 * sizeof(double)); /* newSeqWith(nRadius, newSeq[float](29)) :619 */
+#define N_OF(idx) ((e[idx] / kAtomicMass[idx]) * (rho[iRadius] / kAmu)) /* template n :658-659 */
+    n_Z[1] = N_OF(0); /* :661 */
+    for (int iZmult = 1; iZmult <= 3; ++iZmult) { /* :662-670 */
+      const int iz = iZmult * 2;
+      const double nVal = (e[iz - 1] + e[iz]) / ((kAtomicMass[iz - 1] * e[iz - 1] + kAtomicMass[iz] * e[iz]) / (e[iz - 1] + e[iz])) *
+                          rho[iRadius] / kAmu;
+      if (iZmult == 1) n_Z[iz] = nVal;
+      else n_Z[iZmult + 4] = nVal;
+    }
+    n_Z[8] = (e[7] + e[8] + e[9]) / ((e[7] * kAtomicMass[7] + e[8] * kAtomicMass[8] + e[9] * kAtomicMass[9]) / (e[7] + e[8] + e[9])) *
+             rho[iRadius] / kAmu; /* :672-675 */
+    for (int iZ = 10; iZ < 29; ++iZ) n_Z[iZ] = N_OF(iZ); /* :676-677 */
+#undef N_OF
+  }
+}
+
+/* ---- absorption coefficients, :790-823 ----------------------------------------------------------------------------
+ * numericalnim's Linear1D as the reference uses it (newLinear1D :217, :296; eval :825, :831): the interval by binary search,
+ * y0 + (x - x0) (y1 - y0) / (x1 - x0); the library raises outside [x0, xN] -> *outside is set. */
+static double linear1d_strict(const double* xs, const double* ys, int64_t n, double x, int* outside) {
+  if (!(x >= xs[0]) || !(x <= xs[n - 1])) {
+    *outside = 1;
+    return 0.0;
+  }
+  int64_t lo = 0, hi = n - 1;
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) / 2;
+    if (xs[mid] <= x) lo = mid; else hi = mid;
+  }
+  return ys[lo] + (x - xs[lo]) * (ys[lo + 1] - ys[lo]) / (xs[lo + 1] - xs[lo]);
+}
+
+/* absCoefs[R, iEindex] for all cells.  `t` holds what the reference keeps in `spline` (mesh -> line number) and in
+ * opElements[temperature][Z].densityTab[n_eInt] for the (temperature, density) slot of every zone; the loop over the
+ * elements is the reference's: all of ElementKind (:28-52) without noElement (:636), every one evaluated, Z > 2 summed.
+ * Hydrogen and helium carry no table here (their value is discarded, :833).  Returns the number of cells whose
+ * evaluation leaves a table (the reference raises at the first one); those cells are NaN. */
+int64_t sart_emission_oracle_abs_coefs(const sart_solar_zone_t* zones, int32_t n_radii, const double* n_z, const double* energies_kev,
+                                       int32_t n_energies, const sart_opacity_tables_t* t, double* out) {
+  static const int element_kinds[] = {1, 2, 6, 7, 8, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28};
+  static const int no_element[] = {3, 4, 5, 9, 15, 17, 19, 21, 22, 23, 27};
+  int64_t n_outside = 0;
+  double* lines = (double*)malloc((size_t)t->n_mesh * sizeof(double)); /* linspace(0.0, 10000.0, 10001) :286 */
+  double* line_numbers = (double*)malloc(10000 * sizeof(double));      /* energy = float lineCnt + 1 :207 */
+  for (int32_t i = 0; i < t->n_mesh; ++i) lines[i] = (double)i;
+  for (int i = 0; i < 10000; ++i) line_numbers[i] = (double)(i + 1);
+  for (int32_t R = 0; R < n_radii; ++R) {
+    const sart_solar_zone_t* z = &zones[R];
+    const double temp = (double)z->temp_index;
+    const double temp_keVTable = pow(10.0, (temp * 0.025)) * 8.617e-8; /* :758 */
+    const double temp_keV = z->temp_K * 8.617e-8;                      /* :759-760 */
+    const double* n_Z = n_z + (size_t)R * 29;
+    const size_t row = (size_t)t->slot_of_zone[R] * (size_t)t->n_elements;
+    for (int32_t iE = 0; iE < n_energies; ++iE) {
+      const double energy_keV = energies_kev[iE];
+      double sum = 0.0;
+      const double w = energy_keV / temp_keVTable; /* :793 */
+      double absCoef;
+      if (w >= 20.0 || w <= 0.0732) { /* :801-808 */
+        for (size_t k = 0; k < sizeof(element_kinds) / sizeof(int); ++k) {
+          const int Z = element_kinds[k];
+          int skip = 0;
+          for (size_t j = 0; j < sizeof(no_element) / sizeof(int); ++j) skip |= (no_element[j] == Z);
+          if (skip) continue;
+          sum = sum + n_Z[Z] * 0.0;
+        }
+        absCoef = sum * 1.97327e-8 * 0.528e-8 * 0.528e-8 * (1.0 - exp(-energy_keV / temp_keV));
+      } else {
+        int outside = 0;
+        const double table = linear1d_strict(t->u_mesh, lines, t->n_mesh, w, &outside); /* :825 */
+        for (size_t k = 0; k < sizeof(element_kinds) / sizeof(int) && !outside; ++k) {
+          const int Z = element_kinds[k];
+          int skip = 0;
+          for (size_t j = 0; j < sizeof(no_element) / sizeof(int); ++j) skip |= (no_element[j] == Z);
+          if (skip) continue;
+          if (!(Z > 2)) continue; /* evaluated and dropped in the reference (:831-833) */
+          int col = -1;
+          for (int32_t c = 0; c < t->n_elements; ++c)
+            if (t->element_z[c] == Z) col = c;
+          if (col < 0) { outside = 1; break; } /* KeyError of :831 */
+          const int64_t yb = t->table_y_begin[row + (size_t)col], xb = t->table_x_begin[row + (size_t)col];
+          const int64_t len = t->table_len[row + (size_t)col];
+          const double* xs = xb < 0 ? line_numbers : t->table_x + xb;
+          if (xb < 0 && len != 10000) { outside = 1; break; }
+          const double opacity = linear1d_strict(xs, t->table_y + yb, len, table, &outside);
+          sum += n_Z[Z] * opacity; /* :834 */
+        }
+        absCoef = sum * 1.97327e-8 * 0.528e-8 * 0.528e-8 * (1.0 - exp(-energy_keV / temp_keV)); /* :838 */
+        if (outside) {
+          absCoef = NAN;
+          ++n_outside;
+        }
+      }
+      out[(size_t)R * n_energies + iE] = absCoef;
+    }
+  }
+  free(lines);
+  free(line_numbers);
+  return n_outside;
+}
+
 /* ---- fNew and its integrand, :296-326 --------------------------------------------------------------------------- */
 static double inner_integral(double t, double y) { /* :296-297 */
   return (1.0 / 2.0) * (((y * y) / (t * t + y * y)) + log(t * t + y * y));

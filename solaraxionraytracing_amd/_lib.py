@@ -147,6 +147,14 @@ class EmissionParams(C.Structure):
     _fields_ = [("g_ae", _d), ("g_agamma", _d), ("g_anuclei", _d), ("terms", C.c_uint32), ("_pad", C.c_uint32)]
 
 
+class OpacityTables(C.Structure):
+    """sart_opacity_tables_t (include/sart_emission.h): host pointers into arrays the owner keeps alive"""
+    _fields_ = [("u_mesh", C.POINTER(_d)), ("n_mesh", _i), ("n_slots", _i), ("slot_of_zone", C.POINTER(_i)),
+                ("element_z", C.POINTER(_i)), ("n_elements", _i), ("_pad", _i), ("table_y_begin", C.POINTER(C.c_int64)),
+                ("table_x_begin", C.POINTER(C.c_int64)), ("table_len", C.POINTER(_i)), ("table_x", C.POINTER(_d)),
+                ("table_y", C.POINTER(_d)), ("n_table_x", C.c_int64), ("n_table_y", C.c_int64)]
+
+
 # SART_EM_* term bits, in the order of the component planes
 EM_TERMS = ("compton", "term1", "ee_brems", "free_free", "primakoff", "long_plasmon", "trans_plasmon", "iron57")
 EM_ALL = 0xFF
@@ -191,6 +199,10 @@ SART_SYMBOLS = {
     "sart_emission_table_device": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _i, C.c_void_p, _P(EmissionParams),
                                              C.c_void_p, C.c_void_p]),
     "sart_emission_to_solar_tables": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _i, C.c_void_p, _P(EmissionParams)]),
+    "sart_emission_abs_coefs": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _dp, _i, _P(OpacityTables), _dp]),
+    "sart_emission_abs_coefs_device": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _dp, _i, _P(OpacityTables), C.c_void_p]),
+    "sart_emission_to_solar_tables_opcd": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _dp, _i, _P(OpacityTables),
+                                                     _P(EmissionParams)]),
     "sart_emission_last_kernel_ms": (_d, []),
 }
 
@@ -213,6 +225,14 @@ SART_HOST_SYMBOLS = {
                                                  _dp, _dp]),
     "sart_host_solar_zones": (C.c_int, [_dp, _dp, _dp, _i, _P(SolarZone)]),
     "sart_host_flux_spectrum": (C.c_int, [_dp, _i, _dp, _i, _dp]),
+    "sart_host_solar_number_densities": (C.c_int, [_dp, _dp, _i, _dp]),
+    "sart_host_opcd_read_mesh": (C.c_int, [C.c_char_p, _dp, _i, _P(_i)]),
+    "sart_host_opcd_file_info": (C.c_int, [C.c_char_p, _P(_i), _P(_i), _P(_i), _P(_i), _P(_i), _i]),
+    "sart_host_opcd_read_table": (C.c_int, [C.c_char_p, _i, _dp, _dp, _i, _P(_i)]),
+    "sart_host_opcd_load": (C.c_int, [C.c_char_p, _P(SolarZone), _i, _i, _P(C.c_void_p)]),
+    "sart_host_opcd_tables": (_P(OpacityTables), [C.c_void_p]),
+    "sart_host_opcd_slot": (C.c_int, [C.c_void_p, _i, _P(_i), _P(_i)]),
+    "sart_host_opcd_free": (None, [C.c_void_p]),
 }
 
 

@@ -48,6 +48,17 @@ def parse_setup(cfg: dict):
     return tuple(out)
 
 
+def resolve_opcd_path(cfg: dict, base: str):
+    """`[ReadOpacityFile].opcdPath` (parseOpcdPath, readOpacityFile.nim:114-117).  The reference uses the string as it is
+    (relative to the working directory); a relative path that is not there is also tried beside the config file."""
+    p = (cfg.get("ReadOpacityFile", {}) or {}).get("opcdPath")
+    if not p:
+        return None
+    if os.path.isabs(p) or os.path.isdir(p):
+        return os.path.normpath(p)
+    return os.path.normpath(os.path.join(base, p))
+
+
 def load_config(path: str) -> dict:
     import tomli
     with open(path, "rb") as f:
@@ -81,7 +92,15 @@ def init_full_setup_from_config(config_path: str, flags: int = 0, **overrides) -
     if os.path.exists(solar):
         kw["solar_model_csv"] = solar
     else:
-        notes.append("solarModelFile %s not found: synthetic E1 emission table" % solar)
+        # the reference would run readOpacityFile first (README.org:22-55): with the OPCD files at hand the same table is made
+        # on the GPU (emission kernel with the OPCD absorption coefficients) instead of being read back from the CSV
+        opcd = resolve_opcd_path(cfg, base)
+        if opcd and os.path.exists(os.path.join(opcd, "OPCD_3.3", "mono", "fm01.mesh")):
+            kw["emission"] = "agss09-device"
+            kw["opcd_path"] = opcd
+            notes.append("solarModelFile %s not found: emission table from the AGSS09 model and the OPCD files in %s" % (solar, opcd))
+        else:
+            notes.append("solarModelFile %s not found: synthetic E1 emission table" % solar)
     refl_key = "llnlReflFile" if tk == _lib.TK_LLNL else "goldReflFile"
     refl = os.path.join(rdir, res.get(refl_key, ""))
     if res.get(refl_key) and os.path.exists(refl):

@@ -16,12 +16,17 @@
 #include <dlfcn.h>
 
 namespace {
-
 thread_local std::string g_err;
-int fail(int code, const std::string& msg) {
+}
+namespace sart_host {
+int fail(int code, const std::string& msg) {   // also used by opcd_host.cpp
   g_err = msg;
   return code;
 }
+}  // namespace sart_host
+using sart_host::fail;
+
+namespace {
 
 constexpr double kPi = 3.14159265358979323846;
 

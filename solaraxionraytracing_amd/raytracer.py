@@ -56,7 +56,7 @@ def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_IN
                   emission: str | np.ndarray = "primakoff", n_radii: int = tables.N_RADII,
                   n_energies: int = tables.N_ENERGIES, reflectivity: str | tables.ReflectivityGrid = "henke",
                   refl_n_angles: int = 1000, refl_n_energies: int = 1000, solar_model_csv: str | None = None,
-                  magnet_cfg=None, source_cfg=None, install_cfg=None) -> FullRaytraceSetup:
+                  magnet_cfg=None, source_cfg=None, install_cfg=None, opcd_path: str | None = None) -> FullRaytraceSetup:
     """initFullSetup, raytracer.nim:2637-2753.  Defaults = config/config_default.toml:19-22
     (BabyIAXO / InGridIAXO / vacuum / XMM).  ``emission`` / ``reflectivity`` choose the synthetic stand-ins of
     tables.py when the reference's own input files are not available."""
@@ -82,6 +82,11 @@ def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_IN
             zones = _emission.solar_zones(n_radii)
             dev_em = {"zones": zones, "params": _emission.default_params()}
             em, meta_em = None, "E0-agss09-all-terms-gpu-device-cdfs"
+            if opcd_path is not None:   # with the absorption coefficients of the OPCD files (readOpacityFile.nim:731-745, :790-823)
+                from . import opacity as _opacity
+                dev_em["opcd"] = _opacity.OpcdSet(opcd_path, zones)
+                dev_em["n_z"] = _opacity.number_densities(n_radii=n_radii)
+                meta_em = "E0-agss09-all-terms-opcd-gpu-device-cdfs"
         elif emission == "flat":
             em, meta_em = tables.flat_emission_table(n_radii, n_energies), "E3-flat"
         else:
@@ -132,8 +137,13 @@ class RayTracer:
         if full.device_emission is not None:
             # BASELINE configs[4]'s front end without a host round trip: emission kernel -> CDFs -> guide tables on the device
             de = full.device_emission
-            _lib.check(lib.sart_emission_to_solar_tables(h, de["zones"], len(de["zones"]), _lib.as_dp(full.energies),
-                                                         full.energies.size, None, C.byref(de["params"])))
+            if de.get("opcd") is not None:
+                _lib.check(lib.sart_emission_to_solar_tables_opcd(h, de["zones"], len(de["zones"]), _lib.as_dp(de["n_z"]),
+                                                                  _lib.as_dp(full.energies), full.energies.size, de["opcd"].tables,
+                                                                  C.byref(de["params"])))
+            else:
+                _lib.check(lib.sart_emission_to_solar_tables(h, de["zones"], len(de["zones"]), _lib.as_dp(full.energies),
+                                                             full.energies.size, None, C.byref(de["params"])))
         else:
             n_r, n_e = full.diffFluxCDFs.shape
             _lib.check(lib.sart_set_solar_tables(h, _lib.as_dp(full.fluxRadiusCDF), _lib.as_dp(full.diffFluxCDFs),

@@ -96,6 +96,27 @@ def flat_emission_table(n_radii: int = N_RADII, n_energies: int = N_ENERGIES) ->
     return np.ones((n_radii, n_energies))
 
 
+SOLAR_MODEL_ELEMENTS = ("H1", "He4", "He3", "C12", "C13", "N14", "N15", "O16", "O17", "O18", "Ne", "Na", "Mg", "Al", "Si", "P", "S",
+                        "Cl", "Ar", "K", "Ca", "Sc", "Ti", "V", "Cr", "Mn", "Fe", "Co", "Ni")   # `elements`, readOpacityFile.nim:125-128
+
+
+def read_solar_model(path: str) -> dict:
+    """readSolarModel (readSolarModel.nim:3-7): the blank-separated AGSS09 table with a `#` header line.  Returns the columns
+    `calculateOpacities` uses: {"radius", "temp_K", "rho", "mass_fractions"[n][29]} (Radius, Temp, Rho and the 29 species)."""
+    with open(path) as f:
+        header = f.readline().lstrip("#").split()
+    data = np.loadtxt(path, skiprows=1, ndmin=2)
+    if data.shape[1] != len(header):
+        raise ValueError("%s: %d columns of data for %d column names" % (path, data.shape[1], len(header)))
+    col = {n: data[:, i] for i, n in enumerate(header)}
+    missing = [n for n in ("Radius", "Temp", "Rho") + SOLAR_MODEL_ELEMENTS if n not in col]
+    if missing:
+        raise KeyError("%s: no column %s" % (path, ", ".join(missing)))   # the data frame's KeyError in the reference
+    return {"radius": np.ascontiguousarray(col["Radius"]), "temp_K": np.ascontiguousarray(col["Temp"]),
+            "rho": np.ascontiguousarray(col["Rho"]),
+            "mass_fractions": np.ascontiguousarray(np.stack([col[n] for n in SOLAR_MODEL_ELEMENTS], axis=1))}
+
+
 def read_solar_model_csv(path: str):
     """Reads the reference's ``solar_model_dataframe.csv`` (columns Radius, Energy [keV], emRates; rows
     grouped by radius; raytracer.nim:2647-2668).  Returns (radii, energies, emRates[nR][nE])."""

@@ -106,15 +106,15 @@ def test_nim_binding_declares_every_header_field():
 
 def test_struct_sizes_match_c_header(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include "sart_emission.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sart_setup_t),'
+    src.write_text('#include "sart_emission.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sart_setup_t),'
                    ' sizeof(sart_axion_t), sizeof(sart_trace_params_t), sizeof(sart_summary_t), sizeof(sart_solar_zone_t),'
-                   ' sizeof(sart_emission_params_t));return 0;}')
+                   ' sizeof(sart_emission_params_t), sizeof(sart_opacity_tables_t));return 0;}')
     import subprocess
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     assert [int(x) for x in out] == [C.sizeof(L.Setup), C.sizeof(L.Axion), C.sizeof(L.TraceParams), C.sizeof(L.Summary),
-                                     C.sizeof(L.SolarZone), C.sizeof(L.EmissionParams)]
+                                     C.sizeof(L.SolarZone), C.sizeof(L.EmissionParams), C.sizeof(L.OpacityTables)]
     assert C.sizeof(L.Axion) == 208
 
 
