@@ -132,6 +132,9 @@ int sart_emission_to_solar_tables_opcd(sart_context* ctx, const sart_solar_zone_
                                        const double* energies_kev, int32_t n_energies, const sart_opacity_tables_t* tables,
                                        const sart_emission_params_t* params);
 
+/* Duration in ms of the last absorption-coefficient kernel this process launched (HIP events on the launch stream). */
+double sart_emission_abs_coefs_last_kernel_ms(void);
+
 /* Duration in ms of the last emission-table kernel this process launched (HIP events on the launch stream). */
 double sart_emission_last_kernel_ms(void);
 

@@ -203,6 +203,7 @@ SART_SYMBOLS = {
     "sart_emission_abs_coefs_device": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _dp, _i, _P(OpacityTables), C.c_void_p]),
     "sart_emission_to_solar_tables_opcd": (C.c_int, [C.c_void_p, _P(SolarZone), _i, _dp, _dp, _i, _P(OpacityTables),
                                                      _P(EmissionParams)]),
+    "sart_emission_abs_coefs_last_kernel_ms": (_d, []),
     "sart_emission_last_kernel_ms": (_d, []),
 }
 

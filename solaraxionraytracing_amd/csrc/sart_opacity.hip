@@ -135,6 +135,8 @@ __global__ __launch_bounds__(256) void abs_coef_kernel(AbsArgs A) {
                              std::string("sart_emission_abs_coefs: ") + #call + ": " + hipGetErrorString(e_));        \
   } while (0)
 
+double g_last_kernel_ms = 0.0;
+
 struct Scoped {  // frees device scratch on every exit path
   void* p = nullptr;
   ~Scoped() { if (p) (void)hipFree(p); }
@@ -231,11 +233,21 @@ int run(sart_context* ctx, const sart_solar_zone_t* zones, int32_t n_radii, cons
   A.n_energies = n_energies;
   A.n_mesh = T.n_mesh;
   A.n_elements = T.n_elements;
+  hipEvent_t e0, e1;
+  OP_HIP(hipEventCreate(&e0));
+  OP_HIP(hipEventCreate(&e1));
+  OP_HIP(hipEventRecord(e0, stream));
   hipLaunchKernelGGL(abs_coef_kernel, dim3((n_energies + 255) / 256, n_radii), dim3(256), 0, stream, A);
+  OP_HIP(hipEventRecord(e1, stream));
   OP_HIP(hipGetLastError());
   unsigned n_outside = 0;
   OP_HIP(hipMemcpyAsync(&n_outside, d_flag.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
   OP_HIP(hipStreamSynchronize(stream));   // the scratch buffers above die with this scope
+  float ms = 0.f;
+  OP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  g_last_kernel_ms = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   if (n_outside)
     return invalid(std::to_string(n_outside) + " cells evaluate a table outside its abscissae (the reference's interpolator raises there)");
   return 0;
@@ -278,5 +290,8 @@ int sart_emission_to_solar_tables_opcd(sart_context* ctx, const sart_solar_zone_
   if (int rc = run(ctx, zones, n_radii, n_z, energies_kev, n_energies, tables, static_cast<double*>(d_abs.p))) return rc;
   return sart_emission_to_solar_tables(ctx, zones, n_radii, energies_kev, n_energies, static_cast<const double*>(d_abs.p), params);
 }
+
+/* Duration of the last abs_coef_kernel launch of this process in ms (HIP events on the launch stream). */
+double sart_emission_abs_coefs_last_kernel_ms(void) { return g_last_kernel_ms; }
 
 }  // extern "C"
