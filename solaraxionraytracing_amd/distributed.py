@@ -108,6 +108,9 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
     import subprocess
     import time
 
+    # the pool's host driver shares device memory between processes through dmabuf only; RCCL needs this before the first
+    # HIP call of a rank (it is exported on the GPU boxes already: this keeps a hand-built environment from losing it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     backend = os.environ.get("SART_BENCH_BACKEND") or "nccl"
     shared = int(os.environ["SART_BENCH_DEVICE"]) if "SART_BENCH_DEVICE" in os.environ else None
     if "WORLD_SIZE" in os.environ:
