@@ -130,6 +130,37 @@ def test_product_path_fails_loudly_without_gpu():
         sa.RayTracer(sa.initFullSetup(n_radii=50, n_energies=40, refl_n_angles=20, refl_n_energies=20))
 
 
+def _build_c_host(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "trace_axion_wrapper")
+    lib_dir = os.path.join(ROOT, "solaraxionraytracing_amd")
+    subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "integration", "trace_axion_wrapper.c"), "-L", lib_dir, "-lsart_host", "-lsart", "-lm",
+                    "-Wl,-rpath," + lib_dir, "-o", exe], check=True)
+    return exe
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="only meaningful without a GPU")
+def test_c_host_builds_against_the_headers_and_fails_loudly_without_gpu(tmp_path):
+    """integration/trace_axion_wrapper.c: the boundary from plain C (C11, -Werror) - headers and libraries alone."""
+    import subprocess
+    r = subprocess.run([_build_c_host(tmp_path), "1000"], capture_output=True, text=True)
+    assert r.returncode == 2 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_c_host_records_agree_with_histogram(tmp_path):
+    """The drop-in call from a C program (no Python, no torch in the process): 2e5 records binned by the caller against the
+    fused histogram of the same ray ids - counters exactly, flux and image to rounding (the program's own exit code)."""
+    import json
+    import subprocess
+    r = subprocess.run([_build_c_host(tmp_path), "200000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = json.loads(r.stdout)
+    assert out["agree"] is True and out["passed"] > 10000 and out["build"] == L.build_id()
+    assert abs(out["flux_records"] - out["flux_histogram"]) <= 1e-11 * out["flux_histogram"]
+
+
 def test_product_does_not_link_or_import_the_oracle():
     import subprocess
     for lib in ("libsart.so", "libsart_host.so"):
