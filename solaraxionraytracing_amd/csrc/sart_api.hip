@@ -146,6 +146,7 @@ struct sart_context {
     uint32_t debug_flags = 0;        // SART_DEBUG_FLAGS=<hex>: 0x20000000 stage A0 drops every ray, 0x10000000 stage A1 does
 #endif
     bool no_early_reject = false;    // SART_NO_EARLY_REJECT: stage A0 off
+    bool no_sure_miss = false;       // SART_NO_SURE_MISS: rays that provably miss the innermost shell's mirror go through phase B
     bool no_image_tile = false;      // SART_NO_IMAGE_TILE: small focal spots go to global atomics only (as before the tile)
     bool no_path_const = false;      // SART_NO_PATH_CONST: never use the constant-path kernel variant (5)
     bool no_host_prefault = false;   // SART_NO_HOST_PREFAULT: sart_trace_records leaves the caller's buffer as it finds it
@@ -572,6 +573,7 @@ HotA hot_of(const DevParams& P) {
   h.ring_lo = P.ring_lo; h.ring_hi = P.ring_hi;
   h.test_active = P.test_active; h.rotated = P.rotated; h.telescope_kind = P.telescope_kind; h.spoke_n = P.spoke_n;
   h.n_shells = P.n_shells; h.lut_n = P.lut_n; h.radius_span = P.radius_span; h.inner_blocks = P.inner_blocks;
+  h.shell0_miss_radius = -1.0;   // set by build_zones where it can be proved
   return h;
 }
 
@@ -585,12 +587,29 @@ HotA hot_of(const DevParams& P) {
 void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h) {
   h.n_zones = 0;
   h.zone_reached = 0;
+  h.shell0_miss_radius = -1.0;
   for (int z = 0; z < kMaxZones; ++z) { h.zone_lo[z] = 1u; h.zone_hi[z] = 0u; }   // empty
   if (P.test_active || n_radii < 1) return;   // the bound on |slope| holds for rays from the Sun only
   const double R = P.radius_cb;
   const double r_sun_max = (0.0015 + (n_radii - 1) * 0.0005) * P.sun_radius;
   const double s_max = (r_sun_max + R) / (P.sun_distance + P.length_b - r_sun_max) * (1.0 + 1e-6);
   const double eps = 1e-6;  // mm
+  // Innermost shell of a Wolter telescope (XMM, Abrixas: findPosParabolic, :1985-1988): its first mirror is the surface
+  // rho(z)^2 = r3^2 + e (l - z), 0 < z < l cos(beta), never closer to the axis than r3 (:668-675).  In the telescope's frame
+  // (where phase A measures the radial distance rho0 at the entrance plane z = 0, :1897-1905) the ray is a straight line whose
+  // angle to the telescope axis is at most atan(s_max) + the tilt of the telescope (a rotation is rigid), so over that range
+  // it stays within rho0 + s_tel l cos(beta) of the axis: below r3 it cannot cross the surface there, neither root is accepted
+  // (:677-682), `s = 0` returns the input point, lineHitsNickel is false for the lowest shell (:1719) and the no-hit test ends
+  // the ray (:2055).  Offsets of the entrance do not enter (rho0 is measured behind them).  1e-3 mm of margin against rounding
+  // in either evaluation.
+  if (P.telescope_wolter && s.n_shells > 0) {
+    const double tilt = P.rotated ? std::acos(std::min(1.0, P.rx_c * P.ry_c)) : 0.0;   // angle between magnet and telescope axis
+    const double s_tel = std::tan(std::atan(s_max) + tilt) * (1.0 + 1e-6);
+    const double beta = s.all_angles_deg[0] * (kPi / 180.0), l = s.l_mirror, r1 = s.all_r1[0];
+    const double tl = std::tan(beta) * l;
+    const double r3 = -tl + std::sqrt(tl * tl + r1 * r1);
+    h.shell0_miss_radius = std::max(-1.0, r3 - s_tel * l * std::cos(beta) - 1e-3);
+  }
   const double dz[3] = {h.dz1, h.dz2, h.dz3};
   const double Rk[3] = {R, std::sqrt(P.pipe1_radius_sq), std::sqrt(P.pipe1_radius_sq)};
   // (a) r >= K_dead => dead
@@ -668,6 +687,7 @@ int sync_blob(sart_context* c) {
   c->hotb.cdf_stride = c->n_energies + kEnergyCdfPad;
   c->hotb._pad = 0;
   if (!c->knobs.no_early_reject) build_zones(c->setup, c->params, c->n_radii, c->hot);
+  if (c->knobs.no_sure_miss) c->hot.shell0_miss_radius = -1.0;
   c->path_const = path_is_constant(c->params, c->hot, c->n_radii);
   c->blob_dirty = false;
   if (c->spot_may_have_moved) c->tile.valid = false;   // a new axion mass alone (weights only) keeps the tile where it is
@@ -805,6 +825,7 @@ int sart_create(int device_ordinal, sart_context** out) {
     if (const char* e = std::getenv("SART_DEBUG_FLAGS")) c->knobs.debug_flags = static_cast<uint32_t>(std::strtoul(e, nullptr, 16));
 #endif
     c->knobs.no_early_reject = flag("SART_NO_EARLY_REJECT");
+    c->knobs.no_sure_miss = flag("SART_NO_SURE_MISS");
     c->knobs.no_image_tile = flag("SART_NO_IMAGE_TILE");
     c->knobs.no_path_const = flag("SART_NO_PATH_CONST");
     c->knobs.no_host_prefault = flag("SART_NO_HOST_PREFAULT");
@@ -1093,6 +1114,16 @@ __attribute__((visibility("default"))) int sart_internal_trace_records_uniforms(
   if (int rc = trace_records_impl(c, p, c->d_rec.p, d_u.p)) return rc;
   SART_HIP(hipMemcpyAsync(out_host, c->d_rec.p, p->n_rays * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->stream));
   SART_HIP(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// Test entry (not in sart.h): HotA::shell0_miss_radius as the next launch would use it (-1: the shortcut is off for this setup).
+__attribute__((visibility("default"))) int sart_internal_shell0_miss_radius(sart_context* c, double* out) {
+  if (!c || !out) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  SART_HIP(hipSetDevice(c->device));
+  if (int rc = refresh_derived(c)) return rc;
+  if (int rc = sync_blob(c)) return rc;
+  *out = c->hot.shell0_miss_radius;
   return 0;
 }
 

@@ -95,6 +95,59 @@ def test_fixed64_is_bitwise_independent_of_placement_and_splitting(name):
     assert_bitwise(base, run(name, "fixed64", splits=(1, 999, 9_999_000, 10_000_000)), "four launches")
     # stage A0 off: other ring traffic, another wave -> ray assignment, other per-workgroup partial sums
     assert_bitwise(base, run(name, "fixed64", env={"SART_NO_EARLY_REJECT": "1"}), "stage A0 off")
+    # rays that provably miss the innermost shell's first mirror go through phase B instead of ending in phase A
+    assert_bitwise(base, run(name, "fixed64", env={"SART_NO_SURE_MISS": "1"}), "innermost-shell shortcut off")
+
+
+def _shell0_miss_radius(full, env=None):
+    import ctypes as C
+    env = env or {}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        with sa.RayTracer(full) as rt:
+            out = C.c_double()
+            fn = rt.lib.sart_internal_shell0_miss_radius
+            fn.argtypes, fn.restype = [C.c_void_p, C.POINTER(C.c_double)], C.c_int
+            L.check(fn(rt.handle, C.byref(out)))
+            return out.value
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_innermost_shell_shortcut_where_it_is_proved_and_only_there():
+    """Phase A ends rays that select the innermost shell from so far inside that neither root of findPosParabolic (:677-682)
+    can lie in the mirror: r3 of that shell minus the largest drift over the mirror's length.  On for Wolter telescopes with
+    the solar source (tilted or not), off (-1) everywhere else; exactness: the parametrised test above (bitwise) and the
+    record path, which does not take the shortcut, against the histogram."""
+    full = full_setup("babyiaxo_xmm")
+    rho = _shell0_miss_radius(full)
+    s = full.setup
+    beta = np.deg2rad(s.all_angles_deg[0])
+    tl = np.tan(beta) * s.l_mirror
+    r3 = -tl + np.sqrt(tl * tl + s.all_r1[0] ** 2)
+    assert 148.0 < rho < r3 - 1.0 and r3 < s.all_r1[0]                 # 151.6 - 4.6e-3 x 300 mm - margin
+    assert _shell0_miss_radius(full_setup("babyiaxo_xmm_gas")) == rho  # the stage does not enter
+    assert _shell0_miss_radius(full, env={"SART_NO_SURE_MISS": "1"}) == -1.0
+    assert _shell0_miss_radius(full, env={"SART_NO_EARLY_REJECT": "1"}) == -1.0   # the slope bound is built with the zones
+    for name in ("cast_llnl_gold", "babyiaxo_xmm_xray"):                          # cones (nothing to gain); slopes unbounded
+        assert _shell0_miss_radius(full_setup(name)) == -1.0, name
+    rot = _shell0_miss_radius(full_setup("babyiaxo_xmm_rot"))                     # tilted by acos(cos 0.02 deg cos 0.1 deg): 0.53 mm more drift
+    assert rho - 0.6 < rot < rho - 0.5
+    assert 30.0 < _shell0_miss_radius(full_setup("cast_abrixas_gas")) < full_setup("cast_abrixas_gas").setup.all_r1[0]   # the other Wolter telescope
+    # what it is worth and that it is exact where it counts most: the rays it ends are counted as "shell selected" and
+    # nothing else; records (no shortcut) binned on the host give the histogram's counters
+    with sa.RayTracer(full) as rt:
+        n = 2_000_000
+        rec = rt.traceAxionWrapper(n, seed=11)
+        img, summ = rt.trace_histogram(n, seed=11)
+    assert summ["N_PASSED"] == int(rec["passed"].sum()) and summ["N_HIT_NICKEL"] == int(rec["hitNickel"].sum())
+    assert summ["N_PASSED_TILL_WINDOW"] == int(rec["passedTillWindow"].sum())
+    assert summ["SUM_WEIGHTS"] == pytest.approx(float(rec["weights"][rec["passed"] != 0].sum()), rel=1e-12)
 
 
 @pytest.mark.parametrize("name", ["babyiaxo_xmm", "cast_llnl_gold", "babyiaxo_xmm_rot", "babyiaxo_xmm_xray"])
