@@ -573,27 +573,15 @@ HotA hot_of(const DevParams& P) {
   h.ring_lo = P.ring_lo; h.ring_hi = P.ring_hi;
   h.test_active = P.test_active; h.rotated = P.rotated; h.telescope_kind = P.telescope_kind; h.spoke_n = P.spoke_n;
   h.n_shells = P.n_shells; h.lut_n = P.lut_n; h.radius_span = P.radius_span; h.inner_blocks = P.inner_blocks;
-  h.shell0_miss_radius = -1.0;   // set by build_zones where it can be proved
   return h;
 }
 
-// Stage A0 zones (see HotA).  With r = R sqrt(u3) the distance of the point on the bore exit from the axis and
-// |slope| <= s_max for every ray from the Sun, the ray's distance from the axis at a plane dz further on lies in
-// [r - dz s_max, r + dz s_max].  From that: (a) r - dz_k s_max >= R_k for one of the three cuts behind the
-// magnetic field (cold-bore exit, two pipe cuts; raytracer.nim:1846-1868) => dead, not "reached";
-// (b) telescopes on the magnet axis (entrance offset 0, not rotated): r certainly inside bore + pipes and
-// certainly inside the inner disc / the XMM ring / beyond the outermost shell (:1653, :1674-1692, :1934) => dead,
-// "reached".  Every bound carries a safety margin far above f64 rounding, so the verdict equals the reference's.
-void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h) {
-  h.n_zones = 0;
-  h.zone_reached = 0;
-  h.shell0_miss_radius = -1.0;
-  for (int z = 0; z < kMaxZones; ++z) { h.zone_lo[z] = 1u; h.zone_hi[z] = 0u; }   // empty
-  if (P.test_active || n_radii < 1) return;   // the bound on |slope| holds for rays from the Sun only
+// DevParams::shell0_miss_radius, or -1 where the bound below is not available (X-ray test source: slopes unbounded; cones).
+double shell0_miss_radius_of(const sart_setup_t& s, const DevParams& P, int n_radii) {
+  if (P.test_active || n_radii < 1) return -1.0;   // the bound on |slope| holds for rays from the Sun only
   const double R = P.radius_cb;
   const double r_sun_max = (0.0015 + (n_radii - 1) * 0.0005) * P.sun_radius;
   const double s_max = (r_sun_max + R) / (P.sun_distance + P.length_b - r_sun_max) * (1.0 + 1e-6);
-  const double eps = 1e-6;  // mm
   // Innermost shell of a Wolter telescope (XMM, Abrixas: findPosParabolic, :1985-1988): its first mirror is the surface
   // rho(z)^2 = r3^2 + e (l - z), 0 < z < l cos(beta), never closer to the axis than r3 (:668-675).  In the telescope's frame
   // (where phase A measures the radial distance rho0 at the entrance plane z = 0, :1897-1905) the ray is a straight line whose
@@ -608,8 +596,27 @@ void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h
     const double beta = s.all_angles_deg[0] * (kPi / 180.0), l = s.l_mirror, r1 = s.all_r1[0];
     const double tl = std::tan(beta) * l;
     const double r3 = -tl + std::sqrt(tl * tl + r1 * r1);
-    h.shell0_miss_radius = std::max(-1.0, r3 - s_tel * l * std::cos(beta) - 1e-3);
+    return std::max(-1.0, r3 - s_tel * l * std::cos(beta) - 1e-3);
   }
+  return -1.0;
+}
+
+// Stage A0 zones (see HotA).  With r = R sqrt(u3) the distance of the point on the bore exit from the axis and
+// |slope| <= s_max for every ray from the Sun, the ray's distance from the axis at a plane dz further on lies in
+// [r - dz s_max, r + dz s_max].  From that: (a) r - dz_k s_max >= R_k for one of the three cuts behind the
+// magnetic field (cold-bore exit, two pipe cuts; raytracer.nim:1846-1868) => dead, not "reached";
+// (b) telescopes on the magnet axis (entrance offset 0, not rotated): r certainly inside bore + pipes and
+// certainly inside the inner disc / the XMM ring / beyond the outermost shell (:1653, :1674-1692, :1934) => dead,
+// "reached".  Every bound carries a safety margin far above f64 rounding, so the verdict equals the reference's.
+void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h) {
+  h.n_zones = 0;
+  h.zone_reached = 0;
+  for (int z = 0; z < kMaxZones; ++z) { h.zone_lo[z] = 1u; h.zone_hi[z] = 0u; }   // empty
+  if (P.test_active || n_radii < 1) return;   // the bound on |slope| holds for rays from the Sun only
+  const double R = P.radius_cb;
+  const double r_sun_max = (0.0015 + (n_radii - 1) * 0.0005) * P.sun_radius;
+  const double s_max = (r_sun_max + R) / (P.sun_distance + P.length_b - r_sun_max) * (1.0 + 1e-6);
+  const double eps = 1e-6;  // mm
   const double dz[3] = {h.dz1, h.dz2, h.dz3};
   const double Rk[3] = {R, std::sqrt(P.pipe1_radius_sq), std::sqrt(P.pipe1_radius_sq)};
   // (a) r >= K_dead => dead
@@ -671,6 +678,8 @@ DevTables tables_of(sart_context* c);
 int sync_blob(sart_context* c) {
   if (!c->blob_dirty) return 0;
   SART_HIP(hipStreamSynchronize(c->stream));
+  c->params.shell0_miss_radius =
+      (c->knobs.no_sure_miss || c->knobs.no_early_reject) ? -1.0 : shell0_miss_radius_of(c->setup, c->params, c->n_radii);
   DevBlob b;
   std::memset(&b, 0, sizeof b);
   b.P = c->params;
@@ -687,7 +696,6 @@ int sync_blob(sart_context* c) {
   c->hotb.cdf_stride = c->n_energies + kEnergyCdfPad;
   c->hotb._pad = 0;
   if (!c->knobs.no_early_reject) build_zones(c->setup, c->params, c->n_radii, c->hot);
-  if (c->knobs.no_sure_miss) c->hot.shell0_miss_radius = -1.0;
   c->path_const = path_is_constant(c->params, c->hot, c->n_radii);
   c->blob_dirty = false;
   if (c->spot_may_have_moved) c->tile.valid = false;   // a new axion mass alone (weights only) keeps the tile where it is
@@ -1117,13 +1125,13 @@ __attribute__((visibility("default"))) int sart_internal_trace_records_uniforms(
   return 0;
 }
 
-// Test entry (not in sart.h): HotA::shell0_miss_radius as the next launch would use it (-1: the shortcut is off for this setup).
+// Test entry (not in sart.h): DevParams::shell0_miss_radius as the next launch would use it (-1: the shortcut is off for this setup).
 __attribute__((visibility("default"))) int sart_internal_shell0_miss_radius(sart_context* c, double* out) {
   if (!c || !out) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
   SART_HIP(hipSetDevice(c->device));
   if (int rc = refresh_derived(c)) return rc;
   if (int rc = sync_blob(c)) return rc;
-  *out = c->hot.shell0_miss_radius;
+  *out = c->params.shell0_miss_radius;
   return 0;
 }
 

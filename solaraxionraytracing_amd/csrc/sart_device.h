@@ -108,6 +108,12 @@ struct DevParams {
   double r1_last;             // allR1[^1]
   double lut_inv_step;
   int32_t lut_n, _pad1;
+  // A ray that selects the innermost shell (none below it, so no nickel test, :1719) from a radial distance below this value
+  // provably stays inside that shell's first mirror over its whole length: neither root of findPosParabolic lies in the
+  // mirror (:677-682), the input point comes back and the ray ends at the no-hit test (:2055) with every counter untouched.
+  // Phase A counts it as "shell selected" and does not hand it to phase B.  -1: not proved for this setup (sart_api.hip:
+  // shell0_miss_radius_of).
+  double shell0_miss_radius;
   // ---- opaque structures (raytracer.nim:1635-1704) ----
   double spider_z;            // -85 (XMM) / -35 (Abrixas)
   double inner_radius;        // XMM: 64.7 (<=) ; Abrixas: 37.5 (<)
@@ -145,11 +151,6 @@ struct HotA {
   double entrance_x, entrance_y;
   double r1_last, lut_inv_step;
   double spider_z, spoke_cos_thr, inner_radius, ring_lo, ring_hi;
-  // A ray that selects the innermost shell (none below it, so no nickel test, :1719) from a radial distance below this value
-  // provably stays inside that shell's first mirror over its whole length: neither root of findPosParabolic lies in the
-  // mirror (:677-682), the input point comes back and the ray ends at the no-hit test (:2055) with every counter untouched.
-  // Phase A counts it as "shell selected" and does not hand it to phase B.  -1: not proved for this setup (sart_api.hip).
-  double shell0_miss_radius;
   int32_t test_active, rotated, telescope_kind, spoke_n;
   int32_t n_shells, lut_n, radius_span, inner_blocks;
   // Stage A0 (early rejection on the bore-exit radius alone): the hi word w of the uniform u3 that sets the

@@ -519,7 +519,7 @@ struct Uniforms { double u0, u1, u2, u3, u4, u5; };
 
 template <bool FAST, int ROT, bool ZEXT>
 __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, const LdsTables& L, const Uniforms& U, RayState& st,
-                                             bool& sampled, bool& reached, bool& sure_miss) {
+                                             bool& sampled, bool& reached, double& radial_out) {
   static_assert(!ZEXT || (FAST && ROT == 0), "the z-extent form needs the magnet-frame slopes in phase B");
   const bool cfg_test = FAST ? false : (H.test_active != 0);
   const bool cfg_rotated = (ROT < 0) ? (H.rotated != 0) : (ROT != 0);
@@ -728,9 +728,7 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
   const double g_r1 = step ? c_r1 : b_r1, g_ro = step ? c_ro : b_ro;
   ok = ok & !((j > 0) & (radial > g_r1) & (radial < g_ro));
   st.shell = min(j, nS - 1);
-  // innermost shell, far enough below its first mirror: phase B would find no root inside the mirror and stop at the no-hit
-  // test without touching a counter (HotA::shell0_miss_radius; -1 when the host could not prove it)
-  sure_miss = (j == 0) & (radial < H.shell0_miss_radius);
+  radial_out = radial;
   return ok;
 }
 
@@ -741,7 +739,7 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
 template <bool FAST, int ROT, bool ZEXT>
 __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const LdsTables& L, uint32_t seed_lo,
                                         uint32_t seed_hi, uint64_t ray_id, uint32_t u3_hi, RayState& st, bool& sampled,
-                                        bool& reached, bool& sure_miss) {
+                                        bool& reached, double& radial) {
   const uint32_t id_lo = (uint32_t)ray_id, id_hi = (uint32_t)(ray_id >> 32);
   const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, seed_lo, seed_hi);
   const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, seed_lo, seed_hi);
@@ -752,7 +750,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   U.u1 = u52(b1.y, b0.w << 20);
   U.u4 = u52(b1.z, b1.w);
   U.u3 = u52(u3_hi, b1.w << 20);
-  return phase_a_core<FAST, ROT, ZEXT>(H, P, L, U, st, sampled, reached, sure_miss);
+  return phase_a_core<FAST, ROT, ZEXT>(H, P, L, U, st, sampled, reached, radial);
 }
 
 // Results of phase B for one ray (record mode needs all of them; histogram mode a few).
@@ -1206,19 +1204,24 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   auto run_phase_a = [&](uint32_t rel, bool valid, uint32_t u3_hi) {
     SART_STAGE_MARK("A1");
     RayState st;
-    bool sampled = false, reached = false, sure_miss = false;
+    bool sampled = false, reached = false;
+    double radial;
     HotA Hl;
     reload_hot(Hl);
     constexpr bool ZEXT = FAST && !ROT && GAS == 0;
-    const bool ok = phase_a<FAST, ROT ? 1 : 0, ZEXT>(Hl, Pb, L, A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi, st, sampled, reached, sure_miss);
+    const bool ok = phase_a<FAST, ROT ? 1 : 0, ZEXT>(Hl, Pb, L, A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi, st, sampled, reached, radial);
     n_reached += (uint32_t)__popcll(ballot64(valid && reached));
     const uint64_t selected = ballot64(valid && ok);
     n_shell += (uint32_t)__popcll(selected);
-    // rays that provably miss the first mirror of the innermost shell are counted above and end here (lane masks: scalar)
+    // Innermost shell, far enough below its first mirror (DevParams::shell0_miss_radius; -1 when the host could not prove it): phase
+    // B would find no root inside the mirror and stop at the no-hit test without touching a counter.  Such a ray is counted
+    // above and ends here.  Below the bound the selected shell is shell 0 (the bound lies below R1[0]): ONE compare against a
+    // broadcast read of the parameter block in LDS, whose lane mask is combined with `selected` in scalar registers (the
+    // ballot of a direct compare is the compare itself; a ballot of `a && b` costs a select and a second compare).
 #ifdef SART_DEBUG_KNOBS
-    const uint64_t mask = (A.flags & 0x10000000u) ? 0ull : (selected & ~ballot64(sure_miss));   // experiment: nothing reaches phase B
+    const uint64_t mask = (A.flags & 0x10000000u) ? 0ull : (selected & ~ballot64(radial < Pb.shell0_miss_radius));   // experiment: nothing reaches phase B
 #else
-    const uint64_t mask = selected & ~ballot64(sure_miss);
+    const uint64_t mask = selected & ~ballot64(radial < Pb.shell0_miss_radius);
 #endif
     const bool alive = __builtin_amdgcn_inverse_ballot_w64(mask);
     const uint32_t cnt = (uint32_t)__popcll(mask);
@@ -1640,16 +1643,16 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
     sart_axion_t rec = {};   // newSeq[Axion] zero-initialises (:2760)
     RayState st;
     bool sampled, reached;
-    bool sure_miss;   // not used here: the record path lets phase B find the miss itself (and so checks the shortcut of the histogram path)
+    double radial;    // not used here: the record path lets phase B find every miss itself (and so checks the shortcut of the histogram path)
     const uint64_t ray_id = A.ray_id_offset + i;
     bool alive;
     if (uniforms) {   // wave-uniform
       const double* u = uniforms + 6 * i;
       const Uniforms U{u[0], u[1], u[2], u[3], u[4], u[5]};
-      alive = phase_a_core<false, -1, false>(H, P, L, U, st, sampled, reached, sure_miss);
+      alive = phase_a_core<false, -1, false>(H, P, L, U, st, sampled, reached, radial);
     } else {
       const uint32_t u3_hi = word_of(stream_block(ray_id >> 2, A.seed_lo, A.seed_hi), (uint32_t)ray_id & 3u);
-      alive = phase_a<false, -1, false>(H, P, L, A.seed_lo, A.seed_hi, ray_id, u3_hi, st, sampled, reached, sure_miss);
+      alive = phase_a<false, -1, false>(H, P, L, A.seed_lo, A.seed_hi, ray_id, u3_hi, st, sampled, reached, radial);
     }
     int e_idx = -1;
     if (sampled) {
