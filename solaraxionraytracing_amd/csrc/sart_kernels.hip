@@ -48,8 +48,10 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-    const uint32_t n0 = hi1 ^ c1 ^ k0;
-    const uint32_t n2 = hi0 ^ c3 ^ k1;
+    // a ^ b ^ c in ONE instruction: gfx950's v_bitop3_b32 with the truth table of the three-input xor (0x96); the compiler
+    // does not form it from two `^` by itself (it emits two v_xor_b32)
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96);
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;

@@ -47,7 +47,7 @@ INT = re.compile(r"v_(mad_u64_u32|mad_i64_i32|mul_lo_u32|mul_hi_u32|mul_u32_u24|
                  r"subrev_co_u32|subbrev_co_u32|add_u32|sub_u32|subrev_u32|add_nc_u32|lshlrev_b32|lshrrev_b32|ashrrev_i32|lshlrev_b64|lshrrev_b64|"
                  r"ashrrev_i64|and_b32|or_b32|xor_b32|not_b32|bfe_u32|bfe_i32|bfi_b32|alignbit_b32|perm_b32|min_u32|max_u32|min_i32|max_i32|"
                  r"mbcnt_lo_u32_b32|mbcnt_hi_u32_b32|lshl_add_u32|add_lshl_u32|lshl_or_b32|and_or_b32|or3_b32|add3_u32|xad_u32|bcnt_u32_b32|"
-                 r"lshl_add_u64|add_i32|sub_i32|med3_i32|med3_u32|xnor_b32|ffbh_u32|ffbl_b32)")
+                 r"lshl_add_u64|add_i32|sub_i32|med3_i32|med3_u32|xnor_b32|ffbh_u32|ffbl_b32|bitop3_b32|bitop3_b16)")
 
 
 def classify(mn: str) -> str:
