@@ -519,10 +519,11 @@ __device__ __forceinline__ double spoke_measure(int n, double c) {
 // (:433-434), u2 -> radius CDF (:436), u3 -> disc radius (:418), u4 -> disc angle (:419), u5 -> energy CDF (:464).
 struct Uniforms { double u0, u1, u2, u3, u4, u5; };
 
-template <bool FAST, int ROT, bool ZEXT>
+template <bool FAST, int ROT, bool ZEXT, bool NOWALL = false>
 __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, const LdsTables& L, const Uniforms& U, RayState& st,
                                              bool& sampled, bool& reached, double& radial_out) {
   static_assert(!ZEXT || (FAST && ROT == 0), "the z-extent form needs the magnet-frame slopes in phase B");
+  static_assert(!NOWALL || ZEXT, "the constant-path form is a specialisation of the vacuum, unrotated one");
   const bool cfg_test = FAST ? false : (H.test_active != 0);
   const bool cfg_rotated = (ROT < 0) ? (H.rotated != 0) : (ROT != 0);
   const bool cfg_holes = FAST ? false : (H.telescope_kind == SART_TK_XMM && H.inner_blocks < 0);
@@ -598,10 +599,16 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
   const double A2 = fma(sx, sx, sy * sy);     // slope^2
   const double norm = ZEXT ? 1.0 : fsqrt_pos(1.0 + A2);   // ZEXT: phase B applies the factor (1 + A2) to pathCB^2 itself
   // entrance plane z = 0
-  const double x0 = fma(-H.length_b, sx, ex), y0 = fma(-H.length_b, sy, ey);
-  const bool hits_entrance = fma(x0, x0, y0 * y0) < H.radius_cb_sq;
   double path_cb = H.length_b * norm;          // |exit point - entrance-plane point| (:1836-1843); FAST: its z extent
-  if (ok & !hits_entrance) {                   // divergent, skipped when no lane needs it: the ray entered through the bore wall
+  // NOWALL (constant-path variant): the host has proved that no ray that passes the three cuts below entered through the bore
+  // wall (sart_api.hip: path_is_constant), so a wall entry changes neither `ok` after those cuts nor `reached`, and nobody
+  // reads the path: the entrance-plane test and the wall branch are not compiled.
+  bool hits_entrance = true;
+  if (!NOWALL) {
+    const double x0 = fma(-H.length_b, sx, ex), y0 = fma(-H.length_b, sy, ey);
+    hits_entrance = fma(x0, x0, y0 * y0) < H.radius_cb_sq;
+  }
+  if (!NOWALL && (ok & !hits_entrance)) {      // divergent, skipped when no lane needs it: the ray entered through the bore wall
     // lineIntersectsCylinderOnce (:591-604): intersections of the line with the bore wall,
     // t = z - lengthB:  A2 t^2 + 2 Dm t + (Qm - R^2) = 0.  inter1 = larger z, inter2 = smaller z.
     const double Dm = fma(ex, sx, ey * sy);
@@ -738,7 +745,7 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
 // shared stream (sart_oracle_uniforms): the two CDF draws (u2, u5) and the disc angle (u4) have 52 random mantissa bits, the
 // two angles of the solar point (u0, u1) and the disc radius (u3) 44: a high word of their own + the 12 bits the 52-bit fills
 // leave over in a word.  u3_hi = word ray_id of the shared stream.
-template <bool FAST, int ROT, bool ZEXT>
+template <bool FAST, int ROT, bool ZEXT, bool NOWALL = false>
 __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const LdsTables& L, uint32_t seed_lo,
                                         uint32_t seed_hi, uint64_t ray_id, uint32_t u3_hi, RayState& st, bool& sampled,
                                         bool& reached, double& radial) {
@@ -752,7 +759,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   U.u1 = u52(b1.y, b0.w << 20);
   U.u4 = u52(b1.z, b1.w);
   U.u3 = u52(u3_hi, b1.w << 20);
-  return phase_a_core<FAST, ROT, ZEXT>(H, P, L, U, st, sampled, reached, radial);
+  return phase_a_core<FAST, ROT, ZEXT, NOWALL>(H, P, L, U, st, sampled, reached, radial);
 }
 
 // Results of phase B for one ray (record mode needs all of them; histogram mode a few).
@@ -1211,7 +1218,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     HotA Hl;
     reload_hot(Hl);
     constexpr bool ZEXT = FAST && !ROT && GAS == 0;
-    const bool ok = phase_a<FAST, ROT ? 1 : 0, ZEXT>(Hl, Pb, L, A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi, st, sampled, reached, radial);
+    const bool ok = phase_a<FAST, ROT ? 1 : 0, ZEXT, PATHC>(Hl, Pb, L, A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi, st, sampled, reached, radial);
     n_reached += (uint32_t)__popcll(ballot64(valid && reached));
     const uint64_t selected = ballot64(valid && ok);
     n_shell += (uint32_t)__popcll(selected);
