@@ -166,7 +166,9 @@ int parse_file(const std::string& path, const std::set<int>* want, OpcdFile& out
   const std::string name = base_name(path);
   // fname[2 .. 3] = element, fname[5 .. ^1] = temperature index (:238-242)
   long z = 0, t = 0;
-  if (name.size() < 6 || !parse_int(name.data() + 2, name.data() + 4, z) || !parse_int(name.data() + 5, name.data() + name.size(), t)) {
+  const char *rz = nullptr, *rt = nullptr;
+  if (name.size() < 6 || name[0] != 'f' || name[1] != 'm' || name[4] != '.' || !parse_int(name.data() + 2, name.data() + 4, z, &rz) ||
+      rz != name.data() + 4 || !parse_int(name.data() + 5, name.data() + name.size(), t, &rt) || rt != name.data() + name.size() || z < 0 || t < 0) {
     err = "cannot read element and temperature from the file name `" + name + "` (expected fmZZ.TTT)";
     return SART_ERR_INVALID_ARGUMENT;
   }

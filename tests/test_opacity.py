@@ -126,8 +126,11 @@ def test_file_reader_errors(tmp_path):
             op.read_table(q, 74)
     with pytest.raises(_lib.SartError, match="Could not open file"):                                      # IOError :266
         op.read_table(str(tmp_path / "fm06.299"), 74)
-    with pytest.raises(_lib.SartError, match="expected fmZZ.TTT"):
-        op.read_table(str(tmp_path / "opacity.dat"), 74)
+    for bad in ("opacity.dat", "fm6.250", "fm06_250", "fm06.25a"):                                          # parseInt raises on these (:238-242)
+        with open(tmp_path / bad, "w") as f:
+            f.write(text)
+        with pytest.raises(_lib.SartError, match="expected fmZZ.TTT"):
+            op.read_table(str(tmp_path / bad), 74)
 
 
 def test_mesh_reader(tmp_path):
