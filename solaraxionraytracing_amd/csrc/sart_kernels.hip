@@ -292,7 +292,7 @@ __device__ __forceinline__ int lower_bound_bracket(Ptr a, int lo, int hi, double
 // Roots of a z^2 + 2 hb z + c = 0 in the reference's naming:
 //   root1 = (-hb - sqrt(hb^2 - a c)) / a,  root2 = (-hb + sqrt(hb^2 - a c)) / a     (:649-650)
 // evaluated without cancellation (q-form); root1 is preferred, then root2, else miss (:651-656).
-__device__ __forceinline__ bool pick_root(double a, double hb, double c, double zlo, double zhi, double& z) {
+__device__ __forceinline__ bool pick_root(double a, double hb, double c, double zlo, double zhi, double& z, uint64_t& hit_m) {
   const double disc = fma(hb, hb, -a * c);
   const double sq = fsqrt_pos(disc);  // NaN for disc <= 0 -> every comparison below is false -> miss (disc == 0: tangent ray, measure zero)
   // q = -(hb + sign(hb) sq); the two roots are q / a and c / q.  With hb >= 0 (sign bit clear) q / a is the reference's
@@ -300,7 +300,9 @@ __device__ __forceinline__ bool pick_root(double a, double hb, double c, double 
   const double q = -hb - copysign(sq, hb);
   const double raq = frcp(a * q);            // one reciprocal: 1/a = q raq, 1/q = a raq
   const double ra = q * q * raq, rb = c * a * raq;
-  const bool in_a = (ra > zlo) & (ra < zhi), in_b = (rb > zlo) & (rb < zhi);
+  const bool a_lo = ra > zlo, a_hi = ra < zhi, b_lo = rb > zlo, b_hi = rb < zhi;
+  const bool in_a = a_lo & a_hi, in_b = b_lo & b_hi;
+  hit_m = (ballot64(a_lo) & ballot64(a_hi)) | (ballot64(b_lo) & ballot64(b_hi));   // the verdict as a lane mask (see phase_a_core)
   // root1 if it lies in the mirror's z range, else root2, else miss (:651-656): only when both roots are in range does
   // the order matter, and then root1 is q / a exactly when the sign bit of hb is clear
   const bool a_first = __double2hiint(hb) >= 0;
@@ -518,10 +520,11 @@ __device__ __forceinline__ double spoke_measure(int n, double c) {
 // The six uniforms of a ray in the reference's draw order: solar source u0, u1 -> angles of the solar point
 // (:433-434), u2 -> radius CDF (:436), u3 -> disc radius (:418), u4 -> disc angle (:419), u5 -> energy CDF (:464).
 struct Uniforms { double u0, u1, u2, u3, u4, u5; };
+struct LaneMasks { uint64_t ok, reached; };   // phase A's verdicts as wave-wide lane masks (see phase_a_core)
 
 template <bool FAST, int ROT, bool ZEXT, bool NOWALL = false>
 __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, const LdsTables& L, const Uniforms& U, RayState& st,
-                                             bool& sampled, bool& reached, double& radial_out) {
+                                             bool& sampled, bool& reached, double& radial_out, LaneMasks& M) {
   static_assert(!ZEXT || (FAST && ROT == 0), "the z-extent form needs the magnet-frame slopes in phase B");
   static_assert(!NOWALL || ZEXT, "the constant-path form is a specialisation of the vacuum, unrotated one");
   const bool cfg_test = FAST ? false : (H.test_active != 0);
@@ -594,6 +597,10 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
     ok = fma(cx, cx, cy * cy) < P.test_radius_sq;
   }
   sampled = ok;
+  // The same verdicts as lane masks, combined on the scalar unit from the ballots of the single compares (the ballot of a
+  // direct compare is the compare's own result; a ballot of `a & b & c` costs a select and a second compare): what the
+  // histogram kernel counts and compacts with.  The bools stay for the divergent regions and for the record kernel.
+  uint64_t okm = cfg_test ? ballot64(ok) : ~0ull;
 
   // ---- bore (:1813-1848) ----
   const double A2 = fma(sx, sx, sy * sy);     // slope^2
@@ -624,6 +631,7 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
     ok = (v1 != v2);                           // exactly one valid intersection (:598-600, :1825)
     path_cb = fabs(t) * norm;
   }
+  if (!NOWALL) okm = ballot64(ok);             // `ok` may come out of the divergent region above
   st.path_cb = path_cb;
   // exit of the cold bore (:1846), pipe CB -> VT3 (:1856), VT3 -> XRT (:1866; same radius — sic)
   const double x1 = fma(H.dz1, sx, ex), y1 = fma(H.dz1, sy, ey);
@@ -631,9 +639,12 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
   const double x3 = fma(H.dz3, sx, ex), y3 = fma(H.dz3, sy, ey);
   // bitwise on purpose: `&&` keeps the short-circuit as three nested divergent regions (exec-mask bookkeeping around eight
   // f64 operations that nearly every lane needs anyway)
-  ok = ok & (fma(x1, x1, y1 * y1) < H.radius_cb_sq) & (fma(x2, x2, y2 * y2) < H.pipe1_radius_sq) &
-       (fma(x3, x3, y3 * y3) < H.pipe1_radius_sq);
+  const bool in1 = fma(x1, x1, y1 * y1) < H.radius_cb_sq, in2 = fma(x2, x2, y2 * y2) < H.pipe1_radius_sq,
+             in3 = fma(x3, x3, y3 * y3) < H.pipe1_radius_sq;
+  ok = ok & in1 & in2 & in3;
+  okm &= ballot64(in1) & ballot64(in2) & ballot64(in3);
   reached = ok;
+  M.reached = okm;
 
   // ---- telescope frame (:1878-1899) ----
   // pointExitCB' (z = -Lp before rotation) and pointExitPipeVT3XRT' (z = 0 before rotation)
@@ -674,17 +685,23 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
 
   // ---- opaque structures (:1635-1704) ----
   if (H.telescope_kind != SART_TK_LLNL) {      // LLNL: the graphite block never blocks (:1646)
-    const bool inner = (H.telescope_kind == SART_TK_XMM) ? (radial <= H.inner_radius) : (radial < H.inner_radius);
+    const bool inner_le = radial <= H.inner_radius, inner_lt = radial < H.inner_radius;
+    const bool inner = (H.telescope_kind == SART_TK_XMM) ? inner_le : inner_lt;
     // htNone: the hole test is always false => inner disc blocked (:1683-1688, :527); Abrixas :1653;
     // XMM ring :1691; spider spokes tested on phi = acos(x / r) at the entrance plane and at
     // z = spider_z (:1695-1701): every 360/n degrees, |phi - k 360/n| <= w  <=>  cos(n phi) >= cos(n w)
-    const bool ring = (H.telescope_kind == SART_TK_XMM) && (radial < H.ring_hi) && (radial > H.ring_lo);
+    const bool ring_a = radial < H.ring_hi, ring_b = radial > H.ring_lo;
+    const bool ring = (H.telescope_kind == SART_TK_XMM) & ring_a & ring_b;
     const double c_ent = X0 * inv_radial;
     const double xs = fma(H.spider_z, tsx, X0), ys = fma(H.spider_z, tsy, Y0);
     const double c_sp = xs * frsq(fma(xs, xs, ys * ys));
     // (bitwise: the second test is needed by every lane the first one does not block - no divergent region around it)
-    const bool spoke = (spoke_measure(H.spoke_n, c_ent) >= H.spoke_cos_thr) | (spoke_measure(H.spoke_n, c_sp) >= H.spoke_cos_thr);
+    const bool spoke_a = spoke_measure(H.spoke_n, c_ent) >= H.spoke_cos_thr, spoke_b = spoke_measure(H.spoke_n, c_sp) >= H.spoke_cos_thr;
+    const bool spoke = spoke_a | spoke_b;
     bool blocked = inner | ring | spoke;
+    const bool xmm = H.telescope_kind == SART_TK_XMM;   // wave-uniform
+    uint64_t blocked_m = (xmm ? ballot64(inner_le) : ballot64(inner_lt)) | (xmm ? (ballot64(ring_a) & ballot64(ring_b)) : 0ull) |
+                         ballot64(spoke_a) | ballot64(spoke_b);
     if (cfg_holes) {
       // hole loop (:1675-1688) with lineIntersectsObject (:494-527) on the entrance plane; replaces the
       // verdict for rays inside the inner disc
@@ -715,12 +732,16 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
         if (!done) { res = !through; done = through; }   // `break` at the first hole the ray passes through
       }
       if (inner) blocked = res;
+      blocked_m = ballot64(blocked);
     }
     ok = ok & !blocked;
+    okm &= ~blocked_m;
   }
 
   // ---- shell selection (:1932-1957) ----
-  ok = ok & !(radial > H.r1_last);
+  const bool beyond = radial > H.r1_last;
+  ok = ok & !beyond;
+  okm &= ~ballot64(beyond);
   // R1 ascending: the nearest shell above is the first j with R1[j] > radial; the look-up cell (narrower
   // than any shell spacing) gives it up to one step
   const int nS = H.n_shells;
@@ -731,11 +752,20 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
   const double b_r1 = L.shells[jb].r1, b_ro = L.shells[jb].r1_outer;
   const bool step = (j0 < nS) & !(c_r1 > radial);
   const int j = j0 + (step ? 1 : 0);
-  ok = ok & (j < nS);    // radial == R1[last] exactly (measure zero; the reference then uses a zero shell)
+  const bool has_shell = j < nS;
+  ok = ok & has_shell;   // radial == R1[last] exactly (measure zero; the reference then uses a zero shell)
+  okm &= ballot64(has_shell);
   // glass front (:1942-1944): only the shell just below the selected one can contain radial (thickness < spacing, checked on
   // the host): the cell's shell after a step, the one below it otherwise
   const double g_r1 = step ? c_r1 : b_r1, g_ro = step ? c_ro : b_ro;
-  ok = ok & !((j > 0) & (radial > g_r1) & (radial < g_ro));
+  const bool gf_a = j > 0, gf_b = radial > g_r1, gf_c = radial < g_ro;
+  ok = ok & !(gf_a & gf_b & gf_c);
+  // (mask form: both candidates compared, the choice between them made on the masks - four compares instead of four selects
+  // and two compares)
+  const uint64_t step_m = ballot64(j0 < nS) & ~ballot64(c_r1 > radial);
+  const uint64_t in_c = ballot64(radial > c_r1) & ballot64(radial < c_ro), in_b = ballot64(radial > b_r1) & ballot64(radial < b_ro);
+  okm &= ~(ballot64(gf_a) & ((step_m & in_c) | (~step_m & in_b)));
+  M.ok = okm;
   st.shell = min(j, nS - 1);
   radial_out = radial;
   return ok;
@@ -748,7 +778,7 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
 template <bool FAST, int ROT, bool ZEXT, bool NOWALL = false>
 __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const LdsTables& L, uint32_t seed_lo,
                                         uint32_t seed_hi, uint64_t ray_id, uint32_t u3_hi, RayState& st, bool& sampled,
-                                        bool& reached, double& radial) {
+                                        bool& reached, double& radial, LaneMasks& M) {
   const uint32_t id_lo = (uint32_t)ray_id, id_hi = (uint32_t)(ray_id >> 32);
   const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, seed_lo, seed_hi);
   const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, seed_lo, seed_hi);
@@ -759,7 +789,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   U.u1 = u52(b1.y, b0.w << 20);
   U.u4 = u52(b1.z, b1.w);
   U.u3 = u52(u3_hi, b1.w << 20);
-  return phase_a_core<FAST, ROT, ZEXT, NOWALL>(H, P, L, U, st, sampled, reached, radial);
+  return phase_a_core<FAST, ROT, ZEXT, NOWALL>(H, P, L, U, st, sampled, reached, radial, M);
 }
 
 // Results of phase B for one ray (record mode needs all of them; histogram mode a few).
@@ -818,7 +848,8 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const double A0 = fma(tsx, tsx, tsy * tsy);
   const double L0 = 1.0 + A0;                 // |w|^2 of the un-normalised direction w = (tsx, tsy, 1)
   double z1;
-  const bool hit1 = pick_root(A0 - sh.m1_k, D0 + sh.m1_hb, Q0 - sh.m1_cc, 0.0, sh.m1_zhi, z1);
+  uint64_t live_m = ballot64(live), hit1_m, hit2_m;   // `live` and the cuts below as lane masks, combined on the scalar unit
+  const bool hit1 = pick_root(A0 - sh.m1_k, D0 + sh.m1_hb, Q0 - sh.m1_cc, 0.0, sh.m1_zhi, z1, hit1_m);
   if (!hit1) z1 = zcb;                        // the reference returns its input point (:656-658)
   const double m1x = fma(z1, tsx, X0), m1y = fma(z1, tsy, Y0);
   // on the surface the normal's z-component is closed-form: cone tan(b) rho(z); paraboloid r3 tan(b)
@@ -836,13 +867,17 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   {
     const double lz = P.l_mirror - z1, num = sh.nickel_num;
     bool nick = sin2_a1 * fma(lz, lz, num * num) > num * num;
+    uint64_t nick_m = ballot64(nick);
     if (ballot64(!(lz > 0.0))) {               // wave-uniform; only for a missed mirror with z1 >= l (never in practice)
       if (!(lz > 0.0)) nick = fsqrt(sin2_a1 / (1.0 - sin2_a1)) > num / lz;
+      nick_m = ballot64(nick);
     }
-    const bool hit_nickel = live & (st.shell > 0) & nick;
-    out.m_nickel = ballot64(hit_nickel);
+    const bool upper = st.shell > 0;
+    const bool hit_nickel = live & upper & nick;
+    out.m_nickel = live_m & ballot64(upper) & nick_m;
     if (RECORDS && hit_nickel) rec->hitNickel = 1;
     live = live & !hit_nickel & hit1;         // nickel (:2045), almostEqual(z1, z0) (:2055)
+    live_m = live_m & ~out.m_nickel & hit1_m;
   }
 
   SART_B_STAMP(1, wz);
@@ -854,8 +889,9 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   const double D1 = fma(X1, s2x, Y1 * s2y);
   const double Q1 = fma(X1, X1, Y1 * Y1);
   double z2;
-  const bool hit2 = pick_root(A1 - sh.m2_k, D1 + sh.m2_hb, Q1 - sh.m2_cc, sh.m2_zlo, sh.m2_zhi, z2);
+  const bool hit2 = pick_root(A1 - sh.m2_k, D1 + sh.m2_hb, Q1 - sh.m2_cc, sh.m2_zlo, sh.m2_zhi, z2, hit2_m);
   live = live & hit2;                         // almostEqual(z1, z2) (:2055)
+  live_m &= hit2_m;
   if (!hit2) z2 = sh.m2_zlo;
   const double m2x = fma(z2, s2x, X1), m2y = fma(z2, s2y, Y1);
   const double n2z = wolter ? sh.n2_r3t * fma(2.0 * (P.l_mirror - z2), sh.n2_invF, 1.0)
@@ -939,8 +975,9 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   // ---- geometry of the detector window / chip (:2138-2147) and of the window strips (:2149-2187: rotateAroundZ by theta,
   // strips along x): none of it needs the gathers, so it runs before they are consumed ----
   const double rdet2 = fma(pdx, pdx, pdy * pdy);
-  const bool on_chip = !((!(flags & SART_CF_IGNORE_DET_WINDOW)) & (rdet2 > P.radius_window_sq)) &
-                       !((fabs(pdx) > P.chip_cx) | (fabs(pdy) > P.chip_cy));
+  const bool off_window = rdet2 > P.radius_window_sq, off_x = fabs(pdx) > P.chip_cx, off_y = fabs(pdy) > P.chip_cy;
+  const bool on_chip = !((!(flags & SART_CF_IGNORE_DET_WINDOW)) & off_window) & !(off_x | off_y);
+  const uint64_t on_chip_m = ~(((flags & SART_CF_IGNORE_DET_WINDOW) ? 0ull : ballot64(off_window)) | ballot64(off_x) | ballot64(off_y));
   const double yt = fabs(fma(pdy, P.theta_c, -pdx * P.theta_s));
   bool in_strip = false;
   for (int i = 0; i < n_half_strips; ++i) in_strip = in_strip | ((yt > P.strip_lo[i]) & (yt < P.strip_hi[i]));
@@ -980,10 +1017,12 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
     rec->reflect = reflectv;
   }
 
-  const bool till_window = live & (weight != 0.0);
-  out.m_till = ballot64(till_window);
+  const bool has_weight = weight != 0.0;
+  const bool till_window = live & has_weight;
+  out.m_till = live_m & ballot64(has_weight);
   if (RECORDS && till_window) rec->passedTillWindow = 1;
   live = live & on_chip;
+  live_m &= on_chip_m;
 
   const double trans_window = (n_half_strips > 0) ? (in_strip ? en.t_strongback : en.t_window) : 0.0;
   const uint8_t kind_w = in_strip ? SART_MK_SI : SART_MK_SI3N4;
@@ -994,8 +1033,9 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   if (!(flags & SART_CF_XRAY_TEST)) { asm volatile(""); weight *= P.exposure; }           // :2207-2212
 
   SART_B_STAMP(5, weight);
-  out.passed = live & (weight != 0.0);
-  out.m_passed = ballot64(out.passed);
+  const bool final_weight = weight != 0.0;
+  out.m_passed = live_m & ballot64(final_weight);
+  out.passed = RECORDS ? (live & final_weight) : __builtin_amdgcn_inverse_ballot_w64(out.m_passed);
   out.reflect = reflectv;
   out.e_idx = e_idx;
   out.rdet = fsqrt_pos(rdet2 + 1e-300);       // + 1e-300: exact no-op unless the ray hits the chip centre to the last bit
@@ -1218,9 +1258,11 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     HotA Hl;
     reload_hot(Hl);
     constexpr bool ZEXT = FAST && !ROT && GAS == 0;
-    const bool ok = phase_a<FAST, ROT ? 1 : 0, ZEXT, PATHC>(Hl, Pb, L, A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi, st, sampled, reached, radial);
-    n_reached += (uint32_t)__popcll(ballot64(valid && reached));
-    const uint64_t selected = ballot64(valid && ok);
+    LaneMasks M;
+    (void)phase_a<FAST, ROT ? 1 : 0, ZEXT, PATHC>(Hl, Pb, L, A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi, st, sampled, reached, radial, M);
+    const uint64_t valid_m = ballot64(valid);
+    n_reached += (uint32_t)__popcll(valid_m & M.reached);
+    const uint64_t selected = valid_m & M.ok;
     n_shell += (uint32_t)__popcll(selected);
     // Innermost shell, far enough below its first mirror (DevParams::shell0_miss_radius; -1 when the host could not prove it): phase
     // B would find no root inside the mirror and stop at the no-hit test without touching a counter.  Such a ray is counted
@@ -1311,8 +1353,10 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       const double fx = (out.px - Al.image_x_min) * Al.image_inv_step_x;
       const double fy = (out.py - Al.image_y_min) * Al.image_inv_step_y;
       const int nx = Al.image_nx, ny = Al.image_ny;
-      const bool inside = (fx >= 0.0) & (fx < (double)nx) & (fy >= 0.0) & (fy < (double)ny);
-      n_outside += (uint32_t)__popcll(ballot64(!inside));
+      // (lane masks of the four compares combined on the scalar unit; ballots in here see the passed lanes only)
+      const uint64_t inside_m = ballot64(fx >= 0.0) & ballot64(fx < (double)nx) & ballot64(fy >= 0.0) & ballot64(fy < (double)ny);
+      n_outside += (uint32_t)__popcll(out.m_passed & ~inside_m);
+      const bool inside = __builtin_amdgcn_inverse_ballot_w64(inside_m);
       // this wave's replica of the image; the pixel's byte offset is 32-bit (image < 2^29 pixels, checked on the host)
 #ifdef SART_DEBUG_KNOBS
       const uint32_t rep_key = (Al.flags & 0x08000000u) ? blockIdx.x : (uint32_t)wave_global;   // experiment: replica per XCD
@@ -1653,15 +1697,16 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
     RayState st;
     bool sampled, reached;
     double radial;    // not used here: the record path lets phase B find every miss itself (and so checks the shortcut of the histogram path)
+    LaneMasks masks;  // not used here either: this kernel branches per lane on the bools
     const uint64_t ray_id = A.ray_id_offset + i;
     bool alive;
     if (uniforms) {   // wave-uniform
       const double* u = uniforms + 6 * i;
       const Uniforms U{u[0], u[1], u[2], u[3], u[4], u[5]};
-      alive = phase_a_core<false, -1, false>(H, P, L, U, st, sampled, reached, radial);
+      alive = phase_a_core<false, -1, false>(H, P, L, U, st, sampled, reached, radial, masks);
     } else {
       const uint32_t u3_hi = word_of(stream_block(ray_id >> 2, A.seed_lo, A.seed_hi), (uint32_t)ray_id & 3u);
-      alive = phase_a<false, -1, false>(H, P, L, A.seed_lo, A.seed_hi, ray_id, u3_hi, st, sampled, reached, radial);
+      alive = phase_a<false, -1, false>(H, P, L, A.seed_lo, A.seed_hi, ray_id, u3_hi, st, sampled, reached, radial, masks);
     }
     int e_idx = -1;
     if (sampled) {
