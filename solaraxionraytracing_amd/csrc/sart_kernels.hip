@@ -1186,8 +1186,18 @@ __device__ __forceinline__ void reload_kernarg(T& dst, size_t byte_offset) {
 template <int BLOCK, bool FAST, bool ROT, int GAS, bool PATHC, bool FIXED>
 __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
                                                                 double* __restrict__ acc, HotB HBarg) {
-  __shared__ TablesLds S;
-  __shared__ QueueLds<BLOCK / 64> Q;
+  // One LDS object with the tables FIRST: their addresses then fit the 16-bit offset field of the ds_ instructions, and a
+  // lookup is `ds_read v, v_index_scaled offset:TABLE` instead of a literal moved into a register and added to the index
+  // (the rings are addressed from a per-wave scalar base anyway).
+  struct LdsLayout {
+    TablesLds S;
+    DevBlob B;
+    TraceArgs Ab;
+    QueueLds<BLOCK / 64> Q;
+  };
+  __shared__ LdsLayout lds;
+  TablesLds& S = lds.S;
+  QueueLds<BLOCK / 64>& Q = lds.Q;
   static_assert(!PATHC || (FAST && !ROT && GAS == 0), "the constant-path form belongs to the vacuum, unrotated specialisation");
   static_assert(kImageTileMax * kImageTileMax <= (BLOCK / 64) * kQueue,
                 "the LDS image tile (host: kImageTileMax) lives in 128 doubles per wave of this workgroup's rings");
@@ -1198,8 +1208,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   // Only the ~20 scalars phase A needs for every ray travel in the kernel arguments (SGPRs); everything
   // else is read from an LDS copy of the parameter blob (broadcast ds_read).  All of them together do not
   // fit the 102 SGPRs of a wave and would be spilled through VGPR lanes (v_readlane = VALU slots).
-  __shared__ DevBlob B;
-  __shared__ TraceArgs Ab;
+  DevBlob& B = lds.B;
+  TraceArgs& Ab = lds.Ab;
   {
     const uint64_t* src = reinterpret_cast<const uint64_t*>(blob);
     uint64_t* dst = reinterpret_cast<uint64_t*>(&B);
