@@ -67,6 +67,42 @@ def test_kernel_argument_layout_matches_the_code_object(tmp_path):
     assert seen == 12  # {specialised (vacuum with and without the constant path, gas, rotated), generic, generic rotated} x {f64, FIXED64}
 
 
+def test_code_object_keeps_what_the_design_counts_on(tmp_path):
+    """Properties of the compiled ray kernels that DESIGN.md 3.1 / 3.3 rest on, read from the gfx950 code object: no scratch
+    (nothing spills to memory), at most 128 VGPRs (four waves per SIMD at 1024 threads), the LDS budget, and the Philox
+    rounds' three-input xors as v_bitop3_b32 (the compiler does not form them by itself: a toolchain that stops accepting the
+    builtin, or starts splitting it, shows up here and not as a silent 6 % of instructions)."""
+    import shutil
+    import subprocess
+    obj = tmp_path / "sart_kernels.o"
+    shutil.copy(os.path.join(ROOT, "solaraxionraytracing_amd", "csrc", "build", "sart_kernels.o"), obj)
+    llvm = "/opt/rocm/lib/llvm/bin"
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(obj)], check=True, capture_output=True, cwd=tmp_path)
+    dev = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert len(dev) == 1, dev
+    notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / dev[0])], capture_output=True, text=True,
+                           check=True).stdout
+    seen = 0
+    for k in re.split(r"\n  - \.a", notes):
+        m = re.search(r"\.name:\s+(\S+)", k)
+        if not m or "trace_" not in m.group(1):
+            continue
+        g = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, k).group(1))
+        assert g("private_segment_fixed_size") == 0 and g("vgpr_spill_count") == 0, m.group(1)
+        assert g("vgpr_count") <= 128, (m.group(1), g("vgpr_count"))
+        if "trace_histogram_kernel" in m.group(1):
+            assert 160 * 1024 - 2048 < g("group_segment_fixed_size") <= 160 * 1024, g("group_segment_fixed_size")
+        seen += 1
+    assert seen == 13   # twelve histogram instantiations + the record kernel
+    asm = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", str(tmp_path / dev[0])], capture_output=True,
+                         text=True, check=True).stdout
+    body = asm.split("<_ZN4sart22trace_histogram_kernelILi1024ELb1ELb0ELi0ELb1ELb0EEEvNS_4HotAEPKNS_7DevBlobENS_9TraceArgsEPdNS_4HotBE>:")
+    assert len(body) == 2, "headline instantiation not found in the disassembly"
+    head = body[1].split("s_endpgm")[0]
+    # 2 per Philox round: two full blocks per phase-A copy (less the shared first round) x 2 copies + the quarter block of stage A0
+    assert head.count("v_bitop3_b32") >= 70 and head.count("v_xor_b32") <= 8, (head.count("v_bitop3_b32"), head.count("v_xor_b32"))
+
+
 def test_nim_binding_declares_every_header_field():
     """integration/sart_ffi.nim (the binding a maintainer of the reference adds) names every field of the three structs and
     every entry point of include/sart.h, and assigns every sart_setup_t field in toSartSetup.  (No Nim compiler in the image:
