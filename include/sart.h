@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SART_ABI_VERSION 1
+#define SART_ABI_VERSION 2   /* 2: SART_ACC_COUNT 16 -> 24 (SUM_WEIGHTS_SQ_HI), fused mass scan, FIXED64 status */
 #define SART_MAX_SHELLS 64
 #define SART_MAX_COATINGS 8
 
@@ -231,12 +231,14 @@ enum {
   SART_ACC_N_SHELL_SELECTED = 10,   /* survived opaque structures + shell selection (:1910-1957) */
   SART_ACC_N_OUTSIDE_IMAGE = 11,    /* passed rays whose (x,y) fall outside the image range */
   /* SART_ACCUM_FIXED64 only (raw accumulators; 0 in every f64 accumulator): high limbs of the four sums that every
-   * passed ray adds to, in units of 2^40 quanta - see "accumulation mode" below */
+   * passed ray adds to (and, slot 16, of the sum of squared weights), in units of 2^40 quanta - see "accumulation mode" below */
   SART_ACC_SUM_WEIGHTS_HI = 12,
   SART_ACC_SUM_X_HI = 13,
   SART_ACC_SUM_Y_HI = 14,
   SART_ACC_SUM_R_HI = 15,
-  SART_ACC_COUNT = 16
+  SART_ACC_SUM_WEIGHTS_SQ_HI = 16,   /* FIXED64 raw accumulators only, like 12 .. 15 */
+  /* 17 .. 23: reserved, 0 */
+  SART_ACC_COUNT = 24
 };
 
 static inline size_t sart_accumulator_len(int32_t nx, int32_t ny) {
@@ -401,6 +403,46 @@ int sart_get_fixed_quanta(sart_context* ctx, sart_fixed_quanta_t* out);
  */
 int sart_finalize_accumulator_device(sart_context* ctx, const sart_trace_params_t* params, const void* acc_fixed_device,
                                      double* out_f64_device);
+
+/* ---- fused axion-mass scan (BASELINE configs[4]) -------------------------- */
+/*
+ * The reference has ONE constant axion mass (`mAxion`, raytracer.nim:255); a mass scan on it is a host loop that re-runs
+ * calculateFluxFractions per mass.  In the gas stage the mass enters a ray's weight through the conversion probability
+ * alone (computeMagnetTransmission :1599-1625 -> axionConversionProb2, axionMassforMagnet.nim:75-98): sampling, cuts,
+ * mirrors, reflectivities, window and absorption do not depend on it.  These entry points trace every ray ONCE and
+ * evaluate the conversion probability for n_masses masses in the last stage of the kernel (per mass and surviving ray:
+ * q = |m_gamma^2 - m_a^2| / 2E, one reciprocal, one cosine; Gamma(E), exp(-Gamma L / 2) and the rest of the weight are
+ * shared), accumulating per mass the flux, its sum of squares and the number of passed rays - the same ray ids for every
+ * mass (common random numbers: the curve's point-to-point noise is the noise of the weights' ratio, not of two samples).
+ * Per mass the results equal a sart_trace_histogram launch with sart_set_axion_mass(m) on the same ray ids: bit for bit
+ * in SART_ACCUM_FIXED64, up to the summation order in SART_ACCUM_F64.
+ *
+ * Scan accumulator: (n_masses + 1) rows of SART_SCAN_ROW 8-byte slots (f64, or int64 when raw SART_ACCUM_FIXED64):
+ *   row k < n_masses   SART_SCAN_SUM_WEIGHTS, SART_SCAN_SUM_WEIGHTS_SQ, SART_SCAN_N_PASSED of masses_ev[k]
+ *                      (raw FIXED64: + the high limbs SART_SCAN_SUM_WEIGHTS_HI / _SQ_HI, value = (hi 2^40 + lo) quantum)
+ *   row n_masses       mass-independent counters SART_SCAN_N_* below
+ * Only params->n_rays, seed, ray_id_offset, flags and accumulate are read (no image is accumulated).
+ * SART_ERR_INVALID_ARGUMENT unless the setup's stage is SART_SK_GAS (the vacuum probability :363-365 has no m_a in it).
+ * Masses are processed in groups of 16 per kernel launch (the per-mass accumulators of a workgroup live in LDS).
+ * FIXED64: the quanta of mass k are a function of (setup, tables, flags, headroom, masses_ev[k]) alone - every rank of a
+ * multi-GPU job computes the same ones; a reduce is an int64 sum of the raw scan accumulators;
+ * sart_finalize_mass_scan_device (same masses) converts to doubles.
+ */
+enum { SART_SCAN_SUM_WEIGHTS = 0, SART_SCAN_SUM_WEIGHTS_SQ = 1, SART_SCAN_N_PASSED = 2,
+       SART_SCAN_SUM_WEIGHTS_HI = 4, SART_SCAN_SUM_WEIGHTS_SQ_HI = 5, SART_SCAN_ROW = 8 };
+enum { SART_SCAN_N_RAYS = 0, SART_SCAN_N_REACHED_TELESCOPE = 1, SART_SCAN_N_SHELL_SELECTED = 2, SART_SCAN_N_HIT_NICKEL = 3,
+       SART_SCAN_N_ON_DETECTOR = 4 /* rays on the chip whose mass-independent weight factor is non-zero */ };
+static inline size_t sart_mass_scan_len(int32_t n_masses) { return ((size_t)n_masses + 1u) * (size_t)SART_SCAN_ROW; }
+/* scan_acc_device: DEVICE memory of sart_mass_scan_len(n_masses) 8-byte slots; asynchronous on the context's stream. */
+int sart_trace_mass_scan_device(sart_context* ctx, const sart_trace_params_t* params, const double* masses_ev,
+                                int32_t n_masses, double* scan_acc_device);
+/* Blocking form with a HOST output of sart_mass_scan_len(n_masses) doubles (finalized in FIXED64 mode). */
+int sart_trace_mass_scan(sart_context* ctx, const sart_trace_params_t* params, const double* masses_ev, int32_t n_masses,
+                         double* scan_out_host);
+/* Raw FIXED64 scan accumulator -> doubles (device pointers; in place allowed); asynchronous.  Resolution / overflow
+ * problems are reported by the next sart_synchronize (see "accumulation mode"). */
+int sart_finalize_mass_scan_device(sart_context* ctx, const sart_trace_params_t* params, const double* masses_ev,
+                                   int32_t n_masses, const void* scan_fixed_device, double* out_f64_device);
 
 /* ---- multi-GPU ---------------------------------------------------------- */
 /*

@@ -73,9 +73,16 @@ int sart_host_perform_angular_scan(sart_context* ctx, const double* angles_deg, 
                                    uint64_t n_rays_per_angle, uint64_t seed, uint64_t ray_id_offset,
                                    uint32_t flags, double* fluxes_out, double* rel_fluxes_out);
 
-/* Axion-mass scan in the gas stage (BASELINE config 5; the reference only has the constant mAxion, raytracer.nim:255):
- * for each m_a set the mass, trace n_rays_per_mass rays, fluxes_out[i] = sum of weights of the passed rays.
- * Mass i uses ray ids [ray_id_offset + i*n_rays_per_mass, ...). */
+/* Axion-mass scan (BASELINE configs[4]; the reference only has the constant mAxion, raytracer.nim:255).
+ * Gas stage: ONE pass over the ray ids [ray_id_offset, ray_id_offset + n_rays) through the fused scan kernel
+ * (sart_trace_mass_scan, include/sart.h): every ray is traced once and weighed for every mass - the same rays for all masses
+ * (common random numbers).  Vacuum stage: the conversion probability (:363-365) has no m_a in it - one launch, the same flux
+ * for every mass.  fluxes_out[i] = sum of the weights of the passed rays for masses_ev[i]; flux_sq_out[i] (may be NULL) the sum
+ * of their squares (Monte-Carlo error of the flux: sqrt(flux_sq)); n_passed_out[i] (may be NULL) the number of passed rays. */
+int sart_host_axion_mass_scan(sart_context* ctx, const double* masses_ev, int32_t n_masses, uint64_t n_rays, uint64_t seed,
+                              uint64_t ray_id_offset, uint32_t flags, double* fluxes_out, double* flux_sq_out,
+                              double* n_passed_out);
+/* The same with the argument list of rounds 1-3 (n_rays_per_mass = the rays every mass is evaluated on). */
 int sart_host_perform_axion_mass_scan(sart_context* ctx, const double* masses_ev, int32_t n_masses,
                                       uint64_t n_rays_per_mass, uint64_t seed, uint64_t ray_id_offset,
                                       uint32_t flags, double* fluxes_out);

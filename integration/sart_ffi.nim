@@ -15,7 +15,8 @@ const
   sartH = "sart.h"
   SartMaxShells = 64    # SART_MAX_SHELLS
   SartMaxCoatings = 8   # SART_MAX_COATINGS
-  SartAccCount = 16     # SART_ACC_COUNT
+  SartAccCount = 24     # SART_ACC_COUNT (ABI version 2)
+  SartScanRow = 8       # SART_SCAN_ROW: 8-byte slots per row of a mass-scan accumulator
 
 type
   SartContext* {.importc: "sart_context", header: sartH, incompleteStruct.} = object
@@ -121,6 +122,13 @@ proc sart_get_accumulation_mode*(ctx: ptr SartContext, modeOut: ptr cint): cint 
 proc sart_get_fixed_quanta*(ctx: ptr SartContext, quanta: ptr SartFixedQuanta): cint {.importc, header: sartH.}
 proc sart_finalize_accumulator_device*(ctx: ptr SartContext, p: ptr SartTraceParams, accFixedDevice: pointer,
                                        outF64Device: ptr cdouble): cint {.importc, header: sartH.}
+## fused axion-mass scan (gas stage): every ray traced once, weighed for nMasses masses; (nMasses + 1) rows of SartScanRow slots
+proc sart_trace_mass_scan_device*(ctx: ptr SartContext, p: ptr SartTraceParams, massesEv: ptr cdouble, nMasses: int32,
+                                  scanAccDevice: ptr cdouble): cint {.importc, header: sartH.}
+proc sart_trace_mass_scan*(ctx: ptr SartContext, p: ptr SartTraceParams, massesEv: ptr cdouble, nMasses: int32,
+                           scanOutHost: ptr cdouble): cint {.importc, header: sartH.}
+proc sart_finalize_mass_scan_device*(ctx: ptr SartContext, p: ptr SartTraceParams, massesEv: ptr cdouble, nMasses: int32,
+                                     scanFixedDevice: pointer, outF64Device: ptr cdouble): cint {.importc, header: sartH.}
 proc sart_reduce_across_devices*(contexts: ptr ptr SartContext, accumulatorsDevice: ptr ptr cdouble, n: int32, nDoubles: csize_t,
                                  root: int32): cint {.importc, header: sartH.}
 proc sart_enable_kernel_timing*(ctx: ptr SartContext, enable: cint): cint {.importc, header: sartH.}

@@ -6,7 +6,9 @@ libsart_host.so (C++ host mirror of the reference's setup/driver layer).
 """
 from . import _lib, tables  # noqa: F401
 from .raytracer import (FullRaytraceSetup, RayTracer, accumulator_len, calculateFluxFractions, initFullSetup,  # noqa: F401
-                        newFullSetup, performAngularScan, performAxionMassScan)
+                        mass_scan_len, newFullSetup, performAngularScan, performAxionMassScan, performAxionMassScanHostLoop,
+                        split_mass_scan)
 
-__all__ = ["FullRaytraceSetup", "RayTracer", "accumulator_len", "calculateFluxFractions", "initFullSetup",
-           "newFullSetup", "performAngularScan", "performAxionMassScan", "tables"]
+__all__ = ["FullRaytraceSetup", "RayTracer", "accumulator_len", "calculateFluxFractions", "initFullSetup", "mass_scan_len",
+           "newFullSetup", "performAngularScan", "performAxionMassScan", "performAxionMassScanHostLoop", "split_mass_scan",
+           "tables"]

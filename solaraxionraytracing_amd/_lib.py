@@ -15,7 +15,8 @@ LIBSART_HOST_PATH = os.path.join(_PKG_DIR, "libsart_host.so")
 
 SART_MAX_SHELLS = 64
 SART_MAX_COATINGS = 8
-SART_ACC_COUNT = 16
+SART_ACC_COUNT = 24
+SART_ABI_VERSION = 2
 
 # enums (values of include/sart.h)
 ES_CAST, ES_BABYIAXO = 0, 1
@@ -34,7 +35,12 @@ CF_READ_DET_INSTALL_CONFIG = 1 << 6
 
 ENERGY_GUIDE_ENTRIES = 2594   # csrc/sart_device.h: kEnergyGuideEntries (992 uniform + 1600 logarithmic buckets, bracketed)
 ACCUM_F64, ACCUM_FIXED64 = 0, 1
-ACC_HI = dict(SUM_WEIGHTS=12, SUM_X=13, SUM_Y=14, SUM_R=15)   # SART_ACC_SUM_*_HI: high limbs of the raw FIXED64 accumulator
+ACC_HI = dict(SUM_WEIGHTS=12, SUM_X=13, SUM_Y=14, SUM_R=15, SUM_WEIGHTS_SQ=16)   # SART_ACC_SUM_*_HI: high limbs of the raw FIXED64 accumulator
+# fused mass scan (include/sart.h: SART_SCAN_*): (n_masses + 1) rows of SCAN_ROW slots; the last row holds the counters of SCAN_SHARED
+SCAN_ROW = 8
+SCAN = dict(SUM_WEIGHTS=0, SUM_WEIGHTS_SQ=1, N_PASSED=2)
+SCAN_HI = dict(SUM_WEIGHTS=4, SUM_WEIGHTS_SQ=5)
+SCAN_SHARED = dict(N_RAYS=0, N_REACHED_TELESCOPE=1, N_SHELL_SELECTED=2, N_HIT_NICKEL=3, N_ON_DETECTOR=4)
 FIXED_LIMB_BITS = 40
 
 ACC = dict(SUM_WEIGHTS=0, N_PASSED=1, N_PASSED_TILL_WINDOW=2, N_HIT_NICKEL=3, SUM_X=4, SUM_Y=5, SUM_R=6,
@@ -188,6 +194,9 @@ SART_SYMBOLS = {
     "sart_get_accumulation_mode": (C.c_int, [C.c_void_p, _P(C.c_int)]),
     "sart_get_fixed_quanta": (C.c_int, [C.c_void_p, _P(FixedQuanta)]),
     "sart_finalize_accumulator_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p, C.c_void_p]),
+    "sart_trace_mass_scan_device": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _i, C.c_void_p]),
+    "sart_trace_mass_scan": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _i, _dp]),
+    "sart_finalize_mass_scan_device": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _i, C.c_void_p, C.c_void_p]),
     "sart_reduce_across_devices": (C.c_int, [_P(C.c_void_p), _P(C.c_void_p), _i, C.c_size_t, _i]),
     "sart_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "sart_get_kernel_timing": (C.c_int, [C.c_void_p, _dp, _P(C.c_int64)]),
@@ -216,6 +225,7 @@ SART_HOST_SYMBOLS = {
     "sart_host_build_cdfs": (C.c_int, [_dp, _dp, _dp, _i, _i, _dp, _dp]),
     "sart_host_detector_tables": (C.c_int, [_dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _dp, _dp, _dp]),
     "sart_host_perform_axion_mass_scan": (C.c_int, [C.c_void_p, _dp, _i, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _dp]),
+    "sart_host_axion_mass_scan": (C.c_int, [C.c_void_p, _dp, _i, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _dp, _dp, _dp]),
     "sart_host_h5_reflectivity_info": (C.c_int, [C.c_char_p, _P(_i), _P(_i), _P(_i), _dp, _dp, _dp, _dp]),
     "sart_host_h5_read_reflectivity": (C.c_int, [C.c_char_p, _dp]),
     "sart_host_h5_write_reflectivity": (C.c_int, [C.c_char_p, _i, _i, _i, _dp, _dp, _dp]),

@@ -457,33 +457,44 @@ int sart_host_perform_angular_scan(sart_context* ctx, const double* angles_deg, 
   return 0;
 }
 
-int sart_host_perform_axion_mass_scan(sart_context* ctx, const double* masses_ev, int32_t n_masses, uint64_t n_rays_per_mass,
-                                      uint64_t seed, uint64_t ray_id_offset, uint32_t flags, double* fluxes_out) {
+int sart_host_axion_mass_scan(sart_context* ctx, const double* masses_ev, int32_t n_masses, uint64_t n_rays, uint64_t seed,
+                              uint64_t ray_id_offset, uint32_t flags, double* fluxes_out, double* flux_sq_out, double* n_passed_out) {
   if (!ctx || !masses_ev || n_masses < 1 || !fluxes_out)
-    return fail(SART_ERR_INVALID_ARGUMENT, "sart_host_perform_axion_mass_scan: bad argument");
+    return fail(SART_ERR_INVALID_ARGUMENT, "sart_host_axion_mass_scan: bad argument");
   sart_setup_t setup;
   if (int rc = sart_get_setup(ctx, &setup)) { g_err = sart_last_error(); return rc; }
   sart_trace_params_t p;
   std::memset(&p, 0, sizeof p);
-  p.n_rays = n_rays_per_mass;
+  p.n_rays = n_rays;
   p.seed = seed;
+  p.ray_id_offset = ray_id_offset;
   p.flags = flags;
   p.image_nx = 256; p.image_ny = 256;
   p.image_x_min = 0.0; p.image_x_max = setup.chip_x_max; p.image_y_min = 0.0; p.image_y_max = setup.chip_y_max;
-  int rc_scan = 0;   // the context's axion mass is put back on every way out (the scan works on a copy in spirit)
-  for (int32_t i = 0; i < n_masses && rc_scan == 0; ++i) {
-    rc_scan = sart_set_axion_mass(ctx, masses_ev[i]);
-    if (rc_scan) { g_err = sart_last_error(); break; }
-    p.ray_id_offset = ray_id_offset + static_cast<uint64_t>(i) * n_rays_per_mass;
+  if (setup.stage != SART_SK_GAS) {   // conversionProb (raytracer.nim:363-365) does not depend on m_a: one launch serves every mass
     sart_summary_t sum;
-    rc_scan = sart_trace_histogram(ctx, &p, nullptr, &sum);
-    if (rc_scan) { g_err = sart_last_error(); break; }
-    fluxes_out[i] = sum.v[SART_ACC_SUM_WEIGHTS];
+    if (int rc = sart_trace_histogram(ctx, &p, nullptr, &sum)) { g_err = sart_last_error(); return rc; }
+    for (int32_t i = 0; i < n_masses; ++i) {
+      fluxes_out[i] = sum.v[SART_ACC_SUM_WEIGHTS];
+      if (flux_sq_out) flux_sq_out[i] = sum.v[SART_ACC_SUM_WEIGHTS_SQ];
+      if (n_passed_out) n_passed_out[i] = sum.v[SART_ACC_N_PASSED];
+    }
+    return 0;
   }
-  if (int rc = sart_set_axion_mass(ctx, setup.m_axion)) {
-    if (!rc_scan) { g_err = sart_last_error(); rc_scan = rc; }
+  std::vector<double> rows(sart_mass_scan_len(n_masses));
+  if (int rc = sart_trace_mass_scan(ctx, &p, masses_ev, n_masses, rows.data())) { g_err = sart_last_error(); return rc; }
+  for (int32_t i = 0; i < n_masses; ++i) {
+    const double* r = rows.data() + static_cast<size_t>(i) * SART_SCAN_ROW;
+    fluxes_out[i] = r[SART_SCAN_SUM_WEIGHTS];
+    if (flux_sq_out) flux_sq_out[i] = r[SART_SCAN_SUM_WEIGHTS_SQ];
+    if (n_passed_out) n_passed_out[i] = r[SART_SCAN_N_PASSED];
   }
-  return rc_scan;
+  return 0;
+}
+
+int sart_host_perform_axion_mass_scan(sart_context* ctx, const double* masses_ev, int32_t n_masses, uint64_t n_rays_per_mass,
+                                      uint64_t seed, uint64_t ray_id_offset, uint32_t flags, double* fluxes_out) {
+  return sart_host_axion_mass_scan(ctx, masses_ev, n_masses, n_rays_per_mass, seed, ray_id_offset, flags, fluxes_out, nullptr, nullptr);
 }
 
 int sart_host_h5_reflectivity_info(const char* path, int32_t* n_coatings, int32_t* n_angles, int32_t* n_energies,

@@ -28,7 +28,11 @@ namespace sart {
 void launch_trace_histogram(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
                             hipStream_t stream, int variant, bool fixed);
 void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectra, int n_radial_bins, int n_energies1, double q_w,
-                           double q_w2, double q_pos, double q_refl, hipStream_t stream);
+                           double q_w2, double q_pos, double q_refl, uint32_t* status_dev, hipStream_t stream);
+bool launch_trace_mass_scan(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, const ScanArgs& SC, double* rows,
+                            double* shared_row, int n_blocks, hipStream_t stream, int variant, bool fixed);
+void launch_finalize_scan(const void* in, double* out, int n_masses, const double* q_w, const double* q_w2, int shared_row,
+                          uint32_t* status_dev, hipStream_t stream);
 int histogram_block_of(int variant);
 void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream, const double* uniforms_dev);
@@ -138,7 +142,7 @@ size_t lower_bound_idx(const double* a, size_t n, double key) {
 struct sart_context {
   int device = 0;
   int n_cu = 0;
-  int blocks_per_cu_hist[6] = {0, 0, 0, 0, 0, 0}, blocks_per_cu_rec = 0;
+  int blocks_per_cu_hist[7] = {0, 0, 0, 0, 0, 0, 0}, blocks_per_cu_rec = 0;
   // tuning / experiment knobs, read from the environment once when the context is created
   struct Knobs {
 #ifdef SART_DEBUG_KNOBS              // experiment builds only (make DEBUG_KNOBS=1); compiled out of the shipped library
@@ -151,6 +155,7 @@ struct sart_context {
     bool no_path_const = false;      // SART_NO_PATH_CONST: never use the constant-path kernel variant (5)
     bool no_host_prefault = false;   // SART_NO_HOST_PREFAULT: sart_trace_records leaves the caller's buffer as it finds it
     int records_chunk = 0;           // SART_RECORDS_CHUNK: records per chunk of sart_trace_records (0 = 1 Mi)
+    int records_fail_chunk = 0;      // SART_RECORDS_FAIL_CHUNK=k: test hook - the k-th chunk of sart_trace_records fails instead of being traced
     int prefault_threads = 0;        // SART_PREFAULT_THREADS: host threads that fault the caller's record buffer in (0 = 8)
     bool force_generic = false;      // SART_FORCE_GENERIC: never use the specialised kernel variant
     int image_replicas = 0;          // SART_IMAGE_REPLICAS: 0 = chosen from the plate scale
@@ -216,7 +221,15 @@ struct sart_context {
   int weight_sq_exp = 0;             // q_w2 = 2^weight_sq_exp
   double weight_bound = 0.0;         // the bound the frozen quantum was derived from
   std::vector<double> etab_max;      // max t_window / t_strongback / a_gas over the energy table, max reflectivity (hoist_*)
+  std::vector<EnergyDev> etab_host;  // host copy of the per-energy-index table (the gas-stage weight bound follows the axion mass)
   DevBuf<double> d_fin;              // f64 image of d_acc for the blocking host-output calls in FIXED64 mode
+  // What the finalize kernels found wrong with a raw FIXED64 accumulator (sart_kernels.hip: kFixedStatus*): OR-ed into d_status,
+  // copied to the pinned h_status behind every finalize, read - and turned into an error - by the next synchronising call.
+  DevBuf<uint32_t> d_status;
+  uint32_t* h_status = nullptr;
+  bool status_pending = false;
+  // fused mass scan: per-workgroup per-mass partial sums, scratch accumulators of the blocking call
+  DevBuf<double> d_scan_partials, d_scan, d_scan_fin;
 
   // timing
   bool timing = false;
@@ -321,6 +334,7 @@ int hoist_setup(sart_context* c) {
     P.gas_term1 = std::pow(g_ev * beV / 2.0, 2);
     P.gas_inv_hbarc_m = 1e-3 / 1.97e-7;
     P.m_axion_sq = s.m_axion * s.m_axion;
+    P.gas_dm2_abs = std::fabs(P.gas_m_gamma_sq - P.m_axion_sq);
   }
   // reflectivity
   P.n_coatings = c->refl_nc;
@@ -431,7 +445,7 @@ int hoist_energy_tables(sart_context* c) {
     e.a_gas = linear1d(c->gas_x, c->gas_y, E);
     const double massAtt = std::exp(-1.5832 + 5.9195 * std::exp(-0.353808 * E) + 4.03598 * std::exp(-0.970557 * E));  // :70-73
     e.gamma = 1.97e-7 * 100.0 * density(pGas, s.magnet_tGas) * massAtt;  // :84
-    e.two_e_ev = 2 * (E * 1000.0);                                         // :68
+    e.inv_two_e_ev = 1.0 / (2 * (E * 1000.0));                             // :68 (the kernel multiplies)
     e.mu_pipe = massAtt * density(pGas, s.room_temp) * 100;                // :109-113
     e.mu_magnet = massAtt * density(pGas, s.magnet_tGas) * 100;
   }
@@ -447,6 +461,7 @@ int hoist_energy_tables(sart_context* c) {
   c->etab_max[4] = std::fabs(tab[nE].t_window);
   c->etab_max[5] = std::fabs(tab[nE].t_strongback);
   c->etab_max[6] = std::fabs(tab[nE].a_gas);
+  c->etab_host = tab;
   return c->d_etab.upload(tab.data(), tab.size());
 }
 
@@ -722,16 +737,33 @@ DevTables tables_of(sart_context* c) {
 // from it.  It is the scale of the largest weights, not a guarantee: the factor 1 + slope^2 of the path length (< 1.00003 for
 // rays from the Sun) and reflectivities extrapolated beyond the edge of their grid are left out, which is harmless - the
 // conversion of a weight to quanta stays exact up to 2^(51 - 63 + headroom) >= 2^4 times the bound, it only uses up headroom.
-double weight_bound_of(const sart_context* c, uint32_t flags) {
+// Gas stage: bound of the conversion probability (axionMassforMagnet.nim:75-98) for |m_gamma^2 - m_a^2| = dm2_abs,
+//   P / (g B / 2)^2 = |integral_0^L exp((i q - Gamma / 2) z) dz|^2 <= min(L^2, 4 / (q^2 + Gamma^2 / 4)),   q = dm2_abs / (2 E),
+// maximised over the energies a ray can have (the table rows of the solar source, or the test source's one row).  Off resonance
+// P falls like 4 / (q L)^2: a bound that ignored the mass (L^2 alone) would leave the weights of a far-off-resonance scan point
+// 1e-6 .. 1e-7 of it, at or below what the integer quanta resolve.
+double gas_prob_bound(const sart_context* c, double dm2_abs) {
+  const DevParams& P = c->params;
+  const double l_nat = P.length_b * P.gas_inv_hbarc_m;
+  const size_t nE = static_cast<size_t>(c->n_energies);
+  const size_t lo = P.test_active ? nE : 0, hi = P.test_active ? nE + 1 : nE;
+  double best = 0.0;
+  for (size_t i = lo; i < hi && i < c->etab_host.size(); ++i) {
+    const EnergyDev& e = c->etab_host[i];
+    const double q = dm2_abs * e.inv_two_e_ev;
+    best = std::max(best, std::min(l_nat * l_nat, 4.0 / (q * q + 0.25 * e.gamma * e.gamma)));
+  }
+  return P.gas_term1 * best;
+}
+
+double weight_bound_of(const sart_context* c, uint32_t flags, double dm2_abs) {
   const DevParams& P = c->params;
   const double* m = c->etab_max.data() + (P.test_active ? 4 : 0);   // the test source has ONE energy: its row, not the maxima
   double b = 1.0;
   if (!(flags & SART_CF_IGNORE_REFLECTION)) b *= m[3] * m[3];
   if (!(flags & SART_CF_IGNORE_CONV_PROB)) {
-    // vacuum: conv_k pathCB^2, pathCB ~ lengthB (:363-365); gas: |integral of exp((iq - Gamma/2) z)|^2 <= L^2 in natural
-    // units (axionMassforMagnet.nim:75-98)
-    const double l_nat = P.length_b * P.gas_inv_hbarc_m;
-    b *= P.stage_gas ? P.gas_term1 * l_nat * l_nat : P.conv_k * P.length_b * P.length_b;
+    // vacuum: conv_k pathCB^2, pathCB ~ lengthB (:363-365); gas: see gas_prob_bound
+    b *= P.stage_gas ? gas_prob_bound(c, dm2_abs) : P.conv_k * P.length_b * P.length_b;
   }
   if (!(flags & SART_CF_IGNORE_DET_WINDOW)) b *= std::max(m[0], m[1]);
   if (!(flags & SART_CF_IGNORE_GAS_ABS)) b *= m[2];
@@ -739,22 +771,51 @@ double weight_bound_of(const sart_context* c, uint32_t flags) {
   return b;
 }
 
-// Freezes the FIXED64 quanta from the bound `b` (or checks that `b` still fits the frozen ones).
-int freeze_quanta(sart_context* c, double b, bool refreeze) {
+// The exponents of the FIXED64 quanta for a weight bound b < 2^e: weights (pixels, SUM_WEIGHTS, weight spectra) in units of
+// 2^(e - 63 + headroom); squared weights in units of 2^(2 e - 39) - SUM_WEIGHTS_SQ has a high limb, so its quantum only has to
+// leave room for the rays of one workgroup of one launch (< 2^23) in an int64.
+struct QuantaExp { int w, w2; };
+int quanta_exp_of(const sart_context* c, double b, QuantaExp& q, int* bound_exp = nullptr) {
   if (!std::isfinite(b) || b < 0.0) return fail(SART_ERR_INVALID_ARGUMENT, "FIXED64: the weight bound of this setup is not finite");
   int e = 0;
   if (b > 0.0) (void)std::frexp(b, &e);   // b < 2^e
+  q.w = e - (63 - c->headroom_bits);
+  q.w2 = 2 * e - 39;
+  if (bound_exp) *bound_exp = e;
+  return 0;
+}
+
+// Freezes the FIXED64 quanta from the bound `b` (or checks that `b` still fits the frozen ones).
+int freeze_quanta(sart_context* c, double b, bool refreeze) {
+  QuantaExp q;
+  int e = 0;
+  if (int rc = quanta_exp_of(c, b, q, &e)) return rc;
   if (c->quanta_frozen && !refreeze) {
     if (e > c->weight_exp + (63 - c->headroom_bits))
       return fail(SART_ERR_INVALID_ARGUMENT, "FIXED64: this launch's weights do not fit the quantum frozen for the accumulator "
                                              "(flags or setup changed between accumulate == 1 launches)");
     return 0;
   }
-  c->weight_exp = e - (63 - c->headroom_bits);
-  c->weight_sq_exp = 2 * e - (63 - 44);
+  c->weight_exp = q.w;
+  c->weight_sq_exp = q.w2;
   c->weight_bound = b;
   c->quanta_frozen = true;
   return 0;
+}
+
+// Kernel variant of the accumulating kernels for the context's current setup (sart_kernels.hip: SART_HIST_VARIANTS).
+// 0 / 3 / 4: compile-time specialisations for the solar source without the hole loop (vacuum; gas stage; rotated telescope =
+// the angular scan); 1 / 2: everything else with the switches read at run time (1 not rotated, 2 rotated); 5 / 6: variants
+// 0 / 3 when no surviving ray entered through the bore wall (constant path in the magnetic field: ring 1 does not carry it
+// and the LDS image tile - or the mass scan's accumulators - use its space beside stage A0).
+int hist_variant_of(const sart_context* c) {
+  const DevParams& P = c->params;
+  const bool fast = !P.test_active && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) && !c->knobs.force_generic;
+  int variant = P.rotated ? 2 : 1;
+  if (fast && !P.rotated) variant = P.stage_gas ? 3 : 0;
+  if (fast && P.rotated && !P.stage_gas) variant = 4;
+  if ((variant == 0 || variant == 3) && c->path_const && !c->knobs.no_path_const) variant = variant == 0 ? 5 : 6;
+  return variant;
 }
 
 int grid_for(uint64_t n_rays, int n_cu, int blocks_per_cu, int block) {
@@ -782,6 +843,40 @@ struct TimedLaunch {
 };
 
 }  // namespace
+
+// FIXED64 status word (sart_kernels.hip: kFixedStatus*).  ensure: allocates it; enqueue_copy: behind a finalize kernel, the
+// cumulative device word -> pinned host memory on the same stream; take: after a stream synchronisation, turns what the
+// finalize kernels found into an error (once) and clears it.
+int status_ensure(sart_context* c) {
+  if (!c->d_status.p) {
+    if (int rc = c->d_status.resize(4)) return rc;
+    SART_HIP(hipMemset(c->d_status.p, 0, 4 * sizeof(uint32_t)));
+  }
+  if (!c->h_status) {
+    SART_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_status), 4 * sizeof(uint32_t), hipHostMallocDefault));
+    std::memset(c->h_status, 0, 4 * sizeof(uint32_t));
+  }
+  return 0;
+}
+int status_enqueue_copy(sart_context* c) {
+  SART_HIP(hipMemcpyAsync(c->h_status, c->d_status.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  c->status_pending = true;
+  return 0;
+}
+int status_take(sart_context* c) {   // the stream has been synchronised
+  if (!c->status_pending) return 0;
+  c->status_pending = false;
+  const uint32_t st = c->h_status[0];
+  if (st == 0) return 0;
+  c->h_status[0] = 0;
+  SART_HIP(hipMemsetAsync(c->d_status.p, 0, sizeof(uint32_t), c->stream));
+  std::string msg = "FIXED64:";
+  if (st & 1u) msg += " a slot of the accumulator is negative or >= 2^62 - it wrapped, or is about to (more bound-weight rays on one pixel "
+                      "/ bin than 2^headroom_bits: use a larger headroom, or finalize and start a new accumulator earlier);";
+  if (st & 2u) msg += " the accumulated weights average below 2^12 quanta per passed ray (bound " + std::to_string(c->weight_bound) +
+                      ": an outlier in a table inflated it) - choose a smaller headroom or SART_ACCUM_F64;";
+  return fail(SART_ERR_INVALID_ARGUMENT, msg);
+}
 
 // Used by the other translation units of libsart.so (sart_emission.hip); not part of the C-ABI.
 namespace sart {
@@ -838,6 +933,7 @@ int sart_create(int device_ordinal, sart_context** out) {
     c->knobs.no_path_const = flag("SART_NO_PATH_CONST");
     c->knobs.no_host_prefault = flag("SART_NO_HOST_PREFAULT");
     c->knobs.records_chunk = number("SART_RECORDS_CHUNK");
+    c->knobs.records_fail_chunk = number("SART_RECORDS_FAIL_CHUNK");
     c->knobs.prefault_threads = number("SART_PREFAULT_THREADS");
     c->knobs.force_generic = flag("SART_FORCE_GENERIC");
     c->knobs.image_replicas = number("SART_IMAGE_REPLICAS");
@@ -858,6 +954,7 @@ int sart_destroy(sart_context* c) {
   }
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  if (c->h_status) (void)hipHostFree(c->h_status);
   delete c;
   return 0;
 }
@@ -879,7 +976,7 @@ int sart_synchronize(sart_context* c) {
   if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
   SART_HIP(hipSetDevice(c->device));
   SART_HIP(hipStreamSynchronize(c->stream));
-  return 0;
+  return status_take(c);   // what the FIXED64 finalize kernels queued before this call found (include/sart.h "accumulation mode")
 }
 
 int sart_set_setup(sart_context* c, const sart_setup_t* s) {
@@ -931,9 +1028,14 @@ int sart_set_telescope_angles(sart_context* c, double tx, double ty) {
 int sart_set_axion_mass(sart_context* c, double m) {
   if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (!c->have_setup) return fail(SART_ERR_NOT_READY, "no setup");
+  const bool changed = c->setup.m_axion != m;
   c->setup.m_axion = m;
+  // gas stage: the weight bound follows the mass (gas_prob_bound), so the FIXED64 quanta of the next launch do, too - a new
+  // mass starts a new accumulator
+  if (changed && c->setup.stage == SART_SK_GAS) c->quanta_frozen = false;
   if (c->derived_dirty) return 0;
   c->params.m_axion_sq = m * m;
+  c->params.gas_dm2_abs = std::fabs(c->params.gas_m_gamma_sq - c->params.m_axion_sq);
   c->blob_dirty = true;
   return 0;
 }
@@ -1231,25 +1333,37 @@ int sart_trace_records(sart_context* c, const sart_trace_params_t* p, sart_axion
                         static_cast<unsigned>(c->knobs.prefault_threads));
   sart_trace_params_t q = *p;
   int rc = 0;
-  for (uint64_t k = 0; k <= n_chunks && rc == 0; ++k) {
+  // A failure inside the pipeline must not leave through an early return: kernels and copies into the CALLER's buffer are queued
+  // on two streams, and the caller may free or reuse that buffer the moment this call returns.  Every step records its error
+  // and breaks; both streams are synchronised on every way out (the HostPrefault destructor joins the pre-fault threads).
+  hipError_t he = hipSuccess;
+  const char* what = "";
+  auto step = [&](hipError_t e, const char* name) {
+    if (e != hipSuccess && he == hipSuccess) { he = e; what = name; }
+    return e == hipSuccess;
+  };
+  for (uint64_t k = 0; k <= n_chunks && rc == 0 && he == hipSuccess; ++k) {
     if (k < n_chunks) {   // trace chunk k into buffer k & 1 once the copy of chunk k - 2 has left it
-      if (k >= 2) SART_HIP(hipStreamWaitEvent(c->stream, c->rec_copied[k & 1], 0));
+      if (k >= 2 && !step(hipStreamWaitEvent(c->stream, c->rec_copied[k & 1], 0), "hipStreamWaitEvent(stream)")) break;
       q.n_rays = std::min(chunk, n - k * chunk);
       q.ray_id_offset = p->ray_id_offset + k * chunk;
-      rc = sart_trace_records_device(c, &q, bufs[k & 1]);
+      rc = (c->knobs.records_fail_chunk > 0 && k + 1 == static_cast<uint64_t>(c->knobs.records_fail_chunk))
+               ? fail(SART_ERR_INTERNAL, "sart_trace_records: failure injected by SART_RECORDS_FAIL_CHUNK (test hook)")
+               : sart_trace_records_device(c, &q, bufs[k & 1]);
       if (rc) break;
-      SART_HIP(hipEventRecord(c->rec_traced[k & 1], c->stream));
+      if (!step(hipEventRecord(c->rec_traced[k & 1], c->stream), "hipEventRecord(traced)")) break;
     }
     if (k > 0) {          // chunk k - 1 crosses PCIe while chunk k is traced (the call may block the host: pageable destination)
       const uint64_t j = k - 1, cnt = std::min(chunk, n - j * chunk);
       prefault.wait(j);
-      SART_HIP(hipStreamWaitEvent(c->copy_stream, c->rec_traced[j & 1], 0));
-      SART_HIP(hipMemcpyAsync(out + j * chunk, bufs[j & 1], cnt * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->copy_stream));
-      SART_HIP(hipEventRecord(c->rec_copied[j & 1], c->copy_stream));
+      if (!step(hipStreamWaitEvent(c->copy_stream, c->rec_traced[j & 1], 0), "hipStreamWaitEvent(copy_stream)")) break;
+      if (!step(hipMemcpyAsync(out + j * chunk, bufs[j & 1], cnt * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->copy_stream), "hipMemcpyAsync(records)")) break;
+      if (!step(hipEventRecord(c->rec_copied[j & 1], c->copy_stream), "hipEventRecord(copied)")) break;
     }
   }
   const hipError_t e1 = hipStreamSynchronize(c->copy_stream), e2 = hipStreamSynchronize(c->stream);
   if (rc) return rc;
+  if (he != hipSuccess) return fail(SART_ERR_NO_DEVICE, std::string("sart_trace_records: ") + what + ": " + hipGetErrorString(he));
   if (e1 != hipSuccess || e2 != hipSuccess) return fail(SART_ERR_NO_DEVICE, std::string("sart_trace_records: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
   return 0;
 }
@@ -1265,7 +1379,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
   const bool fixed = c->accum_mode == SART_ACCUM_FIXED64 && !c->tile.in_pilot;
   a.fx_scale_w = a.fx_scale_w2 = 0.0;
   if (fixed) {
-    if (int rc = freeze_quanta(c, weight_bound_of(c, p->flags), !p->accumulate)) return rc;
+    if (int rc = freeze_quanta(c, weight_bound_of(c, p->flags, c->params.gas_dm2_abs), !p->accumulate)) return rc;
     a.fx_scale_w = std::ldexp(1.0, -c->weight_exp);
     a.fx_scale_w2 = std::ldexp(1.0, -c->weight_sq_exp);
   }
@@ -1283,17 +1397,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
     }
     return 0;
   }
-  // kernel variant: 0 = specialised for the common configuration (solar source, telescope not rotated, vacuum, no
-  // hole loop); 1 = generic, not rotated; 2 = generic, rotated
-  const DevParams& P = c->params;
-  // 0 / 3 / 4: compile-time specialisations for the solar source without the hole loop (vacuum; gas stage = the m_a scan;
-  // rotated telescope = the angular scan); 1 / 2: everything else with the switches read at run time; 5: variant 0 when no
-  // surviving ray entered through the bore wall (constant path in the magnetic field, LDS image tile beside stage A0)
-  const bool fast = !P.test_active && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) && !c->knobs.force_generic;
-  int variant = P.rotated ? 2 : 1;
-  if (fast && !P.rotated) variant = P.stage_gas ? 3 : 0;
-  if (fast && P.rotated && !P.stage_gas) variant = 4;
-  if (variant == 0 && c->path_const && !c->knobs.no_path_const) variant = 5;
+  const int variant = hist_variant_of(c);
   {
     // Replication factor from the expected size of the solar image in pixels: plate scale (distance XRT -> detector)
     // times the angular radius of the emitting core (~0.25 R_sun).  Scattered f64 atomics execute at the memory side
@@ -1331,7 +1435,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
       // accumulate the centre of the spot in a per-workgroup LDS tile (CAST / LLNL: 65 % of the hits, BabyIAXO / XMM: 29 %).
       // The tile is centred on the spot's centroid, measured once per setup and image binning by a pilot launch of 2e5 rays
       // into a one-pixel image (only SUM_X / SUM_Y / N_PASSED are read).
-      if ((c->hot.n_zones == 0 || variant == 5) && !c->knobs.no_image_tile && !c->tile.in_pilot) {
+      if ((c->hot.n_zones == 0 || variant == 5 || variant == 6) && !c->knobs.no_image_tile && !c->tile.in_pilot) {
         sart_context::TileCache& t = c->tile;
         const bool same = t.valid && t.nx == p->image_nx && t.ny == p->image_ny && t.x_min == p->image_x_min &&
                           t.x_max == p->image_x_max && t.y_min == p->image_y_min && t.y_max == p->image_y_max;
@@ -1422,19 +1526,10 @@ int sart_trace_histogram_spectra(sart_context* c, const sart_trace_params_t* p, 
   if (spectra_out && p->spectra)
     SART_HIP(hipMemcpyAsync(spectra_out, src + nimg + SART_ACC_COUNT, (len - nimg - SART_ACC_COUNT) * sizeof(double),
                             hipMemcpyDeviceToHost, c->stream));
-  double check[SART_ACC_COUNT];
-  const bool fixed = c->accum_mode == SART_ACCUM_FIXED64;
-  if (fixed) SART_HIP(hipMemcpyAsync(check, src + nimg, sizeof check, hipMemcpyDeviceToHost, c->stream));
   SART_HIP(hipStreamSynchronize(c->stream));
-  if (fixed && check[SART_ACC_N_PASSED] > 0.0) {
-    // The quantum is derived from a BOUND of the weights.  If what was accumulated averages below 2^12 quanta per ray (tables
-    // or flags the bound does not see through), the integers no longer resolve the weights: say so instead of returning noise.
-    const double mean_quanta = std::ldexp(check[SART_ACC_SUM_WEIGHTS], -c->weight_exp) / check[SART_ACC_N_PASSED];
-    if (mean_quanta < 4096.0)
-      return fail(SART_ERR_INVALID_ARGUMENT, "FIXED64: the accumulated weights average below 2^12 quanta per ray (bound " +
-                                             std::to_string(c->weight_bound) + "): choose a smaller headroom or SART_ACCUM_F64");
-  }
-  return 0;
+  // FIXED64: the quantum is derived from a BOUND of the weights.  If what was accumulated averages below 2^12 quanta per ray
+  // (tables or flags the bound does not see through), or a slot wrapped, the finalize kernel has said so: an error, not noise.
+  return status_take(c);
 }
 
 int sart_set_accumulation_mode(sart_context* c, int mode, int headroom_bits) {
@@ -1444,9 +1539,11 @@ int sart_set_accumulation_mode(sart_context* c, int mode, int headroom_bits) {
     return fail(SART_ERR_INVALID_ARGUMENT, "headroom_bits must be 0 (default 27) or in [16, 44]");
   SART_HIP(hipSetDevice(c->device));
   SART_HIP(hipStreamSynchronize(c->stream));
-  if (mode != c->accum_mode) c->d_acc_stale = true;
+  const int headroom = headroom_bits ? headroom_bits : 27;
+  if (mode == c->accum_mode && headroom == c->headroom_bits) return 0;   // nothing changes: the frozen quanta stay (an accumulator may hold data in them)
+  c->d_acc_stale = true;   // the scratch accumulator of the blocking calls holds data of the old mode / quanta
   c->accum_mode = mode;
-  c->headroom_bits = headroom_bits ? headroom_bits : 27;
+  c->headroom_bits = headroom;
   c->quanta_frozen = false;
   return 0;
 }
@@ -1473,11 +1570,147 @@ int sart_finalize_accumulator_device(sart_context* c, const sart_trace_params_t*
     return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
   if (!c->quanta_frozen) return fail(SART_ERR_NOT_READY, "no FIXED64 launch has fixed the quanta yet");
   SART_HIP(hipSetDevice(c->device));
+  if (int rc = status_ensure(c)) return rc;
   launch_finalize_fixed(acc_fixed_dev, out_dev, static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny), p->spectra ? 1 : 0,
                         p->spectra ? p->n_radial_bins : 0, c->n_energies + 1, std::ldexp(1.0, c->weight_exp),
-                        std::ldexp(1.0, c->weight_sq_exp), 1.0 / kFixedPositionScale, 1.0 / kFixedReflectScale, c->stream);
+                        std::ldexp(1.0, c->weight_sq_exp), 1.0 / kFixedPositionScale, 1.0 / kFixedReflectScale, c->d_status.p, c->stream);
   SART_HIP(hipGetLastError());
+  return status_enqueue_copy(c);
+}
+
+// ---- fused axion-mass scan (include/sart.h) -----------------------------------------------------------------------------------
+namespace {
+
+int scan_check(sart_context* c, const sart_trace_params_t* p, const double* masses, int32_t n) {
+  if (!c || !p || !masses) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (n < 1 || n > 65536) return fail(SART_ERR_INVALID_ARGUMENT, "n_masses must be in [1, 65536]");
+  for (int32_t k = 0; k < n; ++k)
+    if (!std::isfinite(masses[k]) || masses[k] < 0.0) return fail(SART_ERR_INVALID_ARGUMENT, "axion masses must be finite and >= 0");
   return 0;
+}
+
+// |m_gamma^2 - m_a^2| exactly as hoist_setup / sart_set_axion_mass compute it for the single-mass kernels
+double dm2_abs_of(const sart_context* c, double m_axion) { return std::fabs(c->params.gas_m_gamma_sq - m_axion * m_axion); }
+
+}  // namespace
+
+int sart_trace_mass_scan_device(sart_context* c, const sart_trace_params_t* p, const double* masses, int32_t n_masses, double* scan_dev) {
+  if (int rc = scan_check(c, p, masses, n_masses)) return rc;
+  if (!scan_dev) return fail(SART_ERR_INVALID_ARGUMENT, "scan accumulator is NULL");
+  SART_HIP(hipSetDevice(c->device));
+  if (int rc = refresh_derived(c)) return rc;
+  if (int rc = sync_blob(c)) return rc;
+  if (!c->params.stage_gas)
+    return fail(SART_ERR_INVALID_ARGUMENT, "sart_trace_mass_scan: the setup's stage is vacuum, whose conversion probability "
+                                           "(raytracer.nim:363-365) does not depend on the axion mass");
+  sart_trace_params_t q = *p;   // a scan accumulates no image: whatever the caller left in the image fields is not read
+  q.image_nx = q.image_ny = 1;
+  q.image_x_min = q.image_y_min = 0.0;
+  q.image_x_max = q.image_y_max = 1.0;
+  q.spectra = 0;
+  TraceArgs a;
+  if (int rc = make_args(c, &q, a)) return rc;
+  a.fx_scale_w = a.fx_scale_w2 = 0.0;
+  const bool fixed = c->accum_mode == SART_ACCUM_FIXED64;
+  if (!p->accumulate) SART_HIP(hipMemsetAsync(scan_dev, 0, sart_mass_scan_len(n_masses) * sizeof(double), c->stream));
+  if (p->n_rays == 0) return 0;
+  const int variant = hist_variant_of(c);
+  if (variant != 1 && variant != 2 && variant != 3 && variant != 6) return fail(SART_ERR_INTERNAL, "no scan kernel for this variant");
+  if (c->blocks_per_cu_hist[variant] == 0) {
+    c->blocks_per_cu_hist[variant] = std::max(1, histogram_blocks_per_cu(variant));
+    if (c->knobs.hist_blocks_per_cu > 0) c->blocks_per_cu_hist[variant] = c->knobs.hist_blocks_per_cu;
+  }
+  // ray indices inside one launch are 32-bit: pieces of at most 2^31 rays; every piece runs once per group of masses
+  for (uint64_t done = 0; done < p->n_rays;) {
+    const uint64_t n = std::min<uint64_t>(p->n_rays - done, 1ull << 31);
+    a.n_rays = n;
+    a.ray_id_offset = p->ray_id_offset + done;
+    const int n_blocks = grid_for(n, c->n_cu, c->blocks_per_cu_hist[variant], histogram_block_of(variant));
+    if (c->d_partials.n < static_cast<size_t>(n_blocks) * SART_ACC_COUNT) {
+      SART_HIP(hipStreamSynchronize(c->stream));
+      const size_t rows = std::max<size_t>(static_cast<size_t>(n_blocks), static_cast<size_t>(c->n_cu) * 4);
+      if (int rc = c->d_partials.resize(rows * SART_ACC_COUNT)) return rc;
+    }
+    const size_t scan_partials = static_cast<size_t>(n_blocks) * kScanMaxMasses * kScanPartialSlots;
+    if (c->d_scan_partials.n < scan_partials) {
+      SART_HIP(hipStreamSynchronize(c->stream));
+      const size_t rows = std::max<size_t>(static_cast<size_t>(n_blocks), static_cast<size_t>(c->n_cu) * 4);
+      if (int rc = c->d_scan_partials.resize(rows * kScanMaxMasses * kScanPartialSlots)) return rc;
+    }
+    a.partials = c->d_partials.p;
+    for (int32_t k0 = 0; k0 < n_masses; k0 += kScanMaxMasses) {
+      ScanArgs sc;
+      std::memset(&sc, 0, sizeof sc);
+      sc.n_masses = std::min<int32_t>(kScanMaxMasses, n_masses - k0);
+      sc.partials = c->d_scan_partials.p;
+      for (int k = 0; k < sc.n_masses; ++k) {
+        ScanMass& m = sc.m[k];
+        m.dm2_abs = dm2_abs_of(c, masses[k0 + k]);
+        m.fx_scale_w = m.fx_scale_w2 = 0.0;
+        if (fixed) {
+          QuantaExp qe;
+          if (int rc = quanta_exp_of(c, weight_bound_of(c, p->flags, m.dm2_abs), qe)) return rc;
+          m.fx_scale_w = std::ldexp(1.0, -qe.w);
+          m.fx_scale_w2 = std::ldexp(1.0, -qe.w2);
+        }
+      }
+      double* const rows = scan_dev + static_cast<size_t>(k0) * SART_SCAN_ROW;
+      double* const shared = (k0 == 0) ? scan_dev + static_cast<size_t>(n_masses) * SART_SCAN_ROW : nullptr;   // counters: once per piece
+      {
+        TimedLaunch tl(c);
+        if (!launch_trace_mass_scan(c->hot, c->hotb, c->d_blob.p, a, sc, rows, shared, n_blocks, c->stream, variant, fixed))
+          return fail(SART_ERR_INTERNAL, "no scan kernel for this variant");
+      }
+      SART_HIP(hipGetLastError());
+    }
+    done += n;
+  }
+  return 0;
+}
+
+int sart_finalize_mass_scan_device(sart_context* c, const sart_trace_params_t* p, const double* masses, int32_t n_masses,
+                                   const void* raw_dev, double* out_dev) {
+  if (int rc = scan_check(c, p, masses, n_masses)) return rc;
+  if (!raw_dev || !out_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  SART_HIP(hipSetDevice(c->device));
+  if (int rc = refresh_derived(c)) return rc;
+  if (int rc = sync_blob(c)) return rc;
+  if (int rc = status_ensure(c)) return rc;
+  for (int32_t k0 = 0; k0 < n_masses; k0 += kScanMaxMasses) {
+    const int n = std::min<int32_t>(kScanMaxMasses, n_masses - k0);
+    double q_w[kScanMaxMasses], q_w2[kScanMaxMasses];
+    for (int k = 0; k < n; ++k) {
+      QuantaExp qe;
+      if (int rc = quanta_exp_of(c, weight_bound_of(c, p->flags, dm2_abs_of(c, masses[k0 + k])), qe)) return rc;
+      q_w[k] = std::ldexp(1.0, qe.w);
+      q_w2[k] = std::ldexp(1.0, qe.w2);
+    }
+    const size_t off = static_cast<size_t>(k0) * SART_SCAN_ROW;
+    launch_finalize_scan(static_cast<const long long*>(raw_dev) + off, out_dev + off, n, q_w, q_w2,
+                         (k0 + n == n_masses) ? n : -1, c->d_status.p, c->stream);   // the counter row sits behind the last group
+    SART_HIP(hipGetLastError());
+  }
+  return status_enqueue_copy(c);
+}
+
+int sart_trace_mass_scan(sart_context* c, const sart_trace_params_t* p, const double* masses, int32_t n_masses, double* out_host) {
+  if (int rc = scan_check(c, p, masses, n_masses)) return rc;
+  if (!out_host) return fail(SART_ERR_INVALID_ARGUMENT, "output is NULL");
+  SART_HIP(hipSetDevice(c->device));
+  const size_t len = sart_mass_scan_len(n_masses);
+  if (int rc = c->d_scan.resize(len)) return rc;
+  sart_trace_params_t q = *p;
+  q.accumulate = 0;   // the blocking form has no accumulator the caller could add into
+  if (int rc = sart_trace_mass_scan_device(c, &q, masses, n_masses, c->d_scan.p)) return rc;
+  const double* src = c->d_scan.p;
+  if (c->accum_mode == SART_ACCUM_FIXED64) {
+    if (int rc = c->d_scan_fin.resize(len)) return rc;
+    if (int rc = sart_finalize_mass_scan_device(c, p, masses, n_masses, c->d_scan.p, c->d_scan_fin.p)) return rc;
+    src = c->d_scan_fin.p;
+  }
+  SART_HIP(hipMemcpyAsync(out_host, src, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  return status_take(c);
 }
 
 // RCCL through dlopen (the library is only needed by hosts that drive several GPUs from one process)

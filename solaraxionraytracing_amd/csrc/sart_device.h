@@ -80,7 +80,7 @@ struct EnergyDev {
   double a_gas;        // gasAbsorption.eval(E)           (:2190)
   // gas stage (axionMassforMagnet.nim:75-113)
   double gamma;        // Gamma(E) in eV
-  double two_e_ev;     // 2 * E[eV]  (momentumTransfer denominator)
+  double inv_two_e_ev; // 1 / (2 * E[eV])  (momentumTransfer, :68: q = |m_gamma^2 - m_a^2| / (2 E), as a multiplication)
   double mu_pipe;      // massAtt * rhoPipe   * 100   [1/m]
   double mu_magnet;    // massAtt * rhoMagnet * 100   [1/m]
 };
@@ -136,6 +136,7 @@ struct DevParams {
   double exposure;            // 3.585e3*3600*1.5*90 | 9.5e6*3600*12*90
   double gas_m_gamma_sq, gas_term1, gas_inv_hbarc_m;   // m_gamma^2, (g B / 2)^2, 1e-3 / 1.97e-7 (mm -> 1/eV)
   double m_axion_sq;
+  double gas_dm2_abs;         // |m_gamma^2 - m_a^2| (one IEEE subtraction; the mass scan's table holds the same expression per mass)
   // ---- reflectivity (raytracer.nim:1533-1580) ----
   int32_t refl_n_angles, n_coatings;
   double refl_angle_min, refl_inv_dangle, refl_dangle;
@@ -230,6 +231,24 @@ struct TraceArgs {
   // of two); positions use kFixedPositionScale, the reflectivity spectrum kFixedReflectScale.  Unused by the f64 kernels.
   double fx_scale_w, fx_scale_w2;
 };
+// Fused axion-mass scan (include/sart.h: sart_trace_mass_scan): phase B evaluates the gas-stage conversion probability of every
+// surviving ray for the masses of this table and accumulates per mass.  One launch takes up to kScanMaxMasses masses: their per-lane
+// accumulators ([mass][sum of w, sum of w^2][64 lanes] f64 or int64 = 1 KB per mass) live in the 16 KB of LDS that the image tile uses
+// in the histogram kernels (a scan accumulates no image).
+constexpr int kScanMaxMasses = 16;
+struct ScanMass {
+  double dm2_abs;                 // |m_gamma^2 - m_a^2| in eV^2 (host: the same IEEE subtraction the single-mass kernel performs)
+  double fx_scale_w, fx_scale_w2; // SART_ACCUM_FIXED64: 1 / quantum of the weights and of the squared weights of THIS mass
+  double _pad;
+};
+struct ScanArgs {
+  int32_t n_masses, _pad;         // masses of this launch (<= kScanMaxMasses); 0 in every launch that is not a scan
+  double* partials;               // [n_blocks][kScanMaxMasses][4] per-workgroup {sum w, sum w^2, rays whose weight vanishes for this mass only, 0}
+  ScanMass m[kScanMaxMasses];
+};
+static_assert(sizeof(ScanMass) == 32 && sizeof(ScanArgs) == 16 + 32 * kScanMaxMasses, "the kernel re-reads ScanArgs with scalar loads at these offsets");
+constexpr int kScanPartialSlots = 4;
+
 constexpr double kFixedPositionScale = 4294967296.0;        // 2^32 per mm
 constexpr double kFixedReflectScale = 1099511627776.0;      // 2^40
 constexpr int kFixedLimbBits = 40;                          // two-limb sums: value = hi * 2^40 + lo

@@ -26,6 +26,7 @@
 // Lines cited as ":NNNN" refer to src/raytracer.nim of the reference.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -255,6 +256,27 @@ __device__ __forceinline__ double cos_any(double y, const double* __restrict__ t
     cs = cos(y);
   }
   return cs;
+}
+
+// Gas-stage conversion probability axionConversionProb2 (axionMassforMagnet.nim:75-98) of one ray for one axion mass:
+//   P = (g B / 2)^2 / (q^2 + Gamma^2 / 4) (1 + exp(-Gamma L) - 2 exp(-Gamma L / 2) cos(q L)),   q = |m_gamma^2 - m_a^2| / (2 E)
+// split into what depends on the ray alone (GasRay: built once per ray in phase B) and the mass (dm2_abs).  The histogram
+// kernels apply it as the LAST factor of the weight, and the fused mass scan calls it once per mass on the same GasRay: every
+// operation below is an explicit multiplication or FMA (nothing for the compiler to contract differently in different
+// surroundings), so a scan's weight for mass k is bit for bit the weight of a single-mass launch with that mass.
+struct GasRay {
+  double inv_two_e;   // 1 / (2 E[eV])
+  double g2q;         // Gamma^2 / 4
+  double m2eh;        // -2 exp(-Gamma L / 2)
+  double eh2p1;       // 1 + exp(-Gamma L)
+  double Lnat;        // L in 1 / eV
+};
+__device__ __forceinline__ double gas_conversion_prob(double dm2_abs, const GasRay& G, double term1, const double* __restrict__ table,
+                                                      const SinCosCoef& K) {
+  const double q = dm2_abs * G.inv_two_e;
+  const double term2 = frcp(fma(q, q, G.g2q));
+  const double term3 = fma(G.m2eh, cos_any(q * G.Lnat, table, K), G.eh2p1);
+  return (term1 * term2) * term3;
 }
 
 // The table pointers of a launch are read from the LDS copy of the parameter blob, where the compiler cannot see
@@ -803,6 +825,7 @@ struct RayOut {
 #endif
   double px = 0.0, py = 0.0, rdet = 0.0, weight = 0.0, reflect = 0.0;
   int e_idx = 0;
+  GasRay gas = {0.0, 0.0, 0.0, 0.0, 0.0};   // SCAN: what the per-mass conversion probability needs of this ray
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -811,7 +834,10 @@ struct RayOut {
 // every table access stays in range); only record fields and the final outputs look at `live`.
 // ------------------------------------------------------------------------------------------------
 // GAS: stage known at compile time (0 vacuum / 1 gas) or read at run time (-1).  ZEXT: see phase_a.
-template <bool RECORDS, bool FAST, int GAS, bool ZEXT>
+// SCAN (fused mass scan): the gas-stage conversion probability is left out - out.weight is the mass-independent factor of the
+// weight, out.gas what gas_conversion_prob() needs of this ray, out.m_passed the rays on the chip for which that factor is not
+// zero; the caller applies the probability per mass.
+template <bool RECORDS, bool FAST, int GAS, bool ZEXT, bool SCAN = false>
 __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, const HotB& HB, const TraceArgs& A,
                                         const RayState& st, int e_idx_in, bool live, RayOut& out, sart_axion_t* rec) {
 #ifdef SART_STAGE_TIMING
@@ -835,7 +861,8 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   // P / A may live in LDS: branch conditions are made wave-uniform (scalar branches) explicitly.
   // FAST: vacuum stage, solar source (known at compile time).
   const int wolter = __builtin_amdgcn_readfirstlane(P.telescope_wolter);
-  static_assert(!ZEXT || GAS == 0, "the z-extent form is the vacuum conversion probability");
+  static_assert(!ZEXT || GAS >= 0, "the z-extent form needs the stage at compile time");
+  static_assert(!SCAN || !RECORDS, "the mass scan accumulates, it writes no records");
   const int stage_gas = (GAS >= 0) ? GAS : __builtin_amdgcn_readfirstlane(P.stage_gas);
   const int test_active = FAST ? 0 : __builtin_amdgcn_readfirstlane(P.test_active);
   const int n_half_strips = __builtin_amdgcn_readfirstlane(P.n_half_strips);
@@ -985,6 +1012,9 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   // ---- weights (:2116-2128) ----
   const double path_cb = st.path_cb;
   double trans_magnet;
+  // Gas stage, accumulating kernels: the conversion probability is the one factor that depends on the axion mass; it is
+  // applied LAST (below; per mass by the caller when SCAN), trans_magnet goes without it.  Wave-uniform.
+  bool prob_deferred = false;
   {
     double prob = 1.0;
     double absorb = 1.0;
@@ -993,17 +1023,17 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
       if (!(flags & SART_CF_IGNORE_CONV_PROB)) prob = ZEXT ? (P.conv_k * L0) * (path_cb * path_cb) : P.conv_k * path_cb * path_cb;
     } else {
       // axionConversionProb2 / intensitySuppression2 (axionMassforMagnet.nim:75-113) with pathCB as length
-      const double Lnat = path_cb * P.gas_inv_hbarc_m;               // length / 1.97e-7, length in m
+      const double path_len = ZEXT ? path_cb * fsqrt_pos(L0) : path_cb;   // ZEXT: the ring carries the z extent of the path
+      const double Lnat = path_len * P.gas_inv_hbarc_m;              // length / 1.97e-7, length in m
       if (!(flags & SART_CF_IGNORE_CONV_PROB)) {
-        const double q = fabs((P.gas_m_gamma_sq - P.m_axion_sq) / en.two_e_ev);
         const double g = en.gamma;
-        const double term2 = frcp(fma(q, q, g * g * 0.25));
         const double eh = exp_neg(-g * Lnat * 0.5);                    // exp(-Gamma L) = eh^2: one exp for both terms
-        const double term3 = fma(eh, eh, 1.0) - 2.0 * eh * cos_any(q * Lnat, L.sincos, sincos_coef());
-        prob = P.gas_term1 * term2 * term3;
+        out.gas = GasRay{en.inv_two_e_ev, g * g * 0.25, -2.0 * eh, fma(eh, eh, 1.0), Lnat};
+        if (RECORDS) prob = gas_conversion_prob(P.gas_dm2_abs, out.gas, P.gas_term1, L.sincos, sincos_coef());
+        else prob_deferred = true;
       }
       // intensitySuppression2 (axionMassforMagnet.nim:100-113): exp(-mu_pipe d) exp(-mu_magnet L) as one exponential
-      absorb = exp_neg(-fma(en.mu_pipe, distance_pipe_m, en.mu_magnet * (path_cb * 1e-3)));
+      absorb = exp_neg(-fma(en.mu_pipe, distance_pipe_m, en.mu_magnet * (path_len * 1e-3)));
     }
     trans_magnet = cos_ya * prob * absorb;          // cos of a degree value taken as radians — sic (:1598)
   }
@@ -1019,7 +1049,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
 
   const bool has_weight = weight != 0.0;
   const bool till_window = live & has_weight;
-  out.m_till = live_m & ballot64(has_weight);
+  out.m_till = live_m & ballot64(has_weight);   // (a deferred conversion probability of exactly zero is taken out below)
   if (RECORDS && till_window) rec->passedTillWindow = 1;
   live = live & on_chip;
   live_m &= on_chip_m;
@@ -1031,6 +1061,11 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   if (!(flags & SART_CF_IGNORE_DET_WINDOW)) { asm volatile(""); weight *= trans_window; }
   if (!(flags & SART_CF_IGNORE_GAS_ABS)) { asm volatile(""); weight *= en.a_gas; }        // :2190-2192
   if (!(flags & SART_CF_XRAY_TEST)) { asm volatile(""); weight *= P.exposure; }           // :2207-2212
+  if (!SCAN && prob_deferred) {
+    const double prob = gas_conversion_prob(P.gas_dm2_abs, out.gas, P.gas_term1, L.sincos, sincos_coef());
+    weight *= prob;
+    out.m_till &= ballot64(prob != 0.0);
+  }
 
   SART_B_STAMP(5, weight);
   const bool final_weight = weight != 0.0;
@@ -1157,11 +1192,14 @@ struct HistKernArgs {
   TraceArgs A;
   double* acc;
   HotB HB;
+  ScanArgs SC;
 };
 static_assert(offsetof(HistKernArgs, H) == 0 && offsetof(HistKernArgs, blob) == (sizeof(HotA) + 7) / 8 * 8 &&
                   offsetof(HistKernArgs, A) == offsetof(HistKernArgs, blob) + 8 &&
                   offsetof(HistKernArgs, acc) == offsetof(HistKernArgs, A) + sizeof(TraceArgs) &&
-                  offsetof(HistKernArgs, HB) == offsetof(HistKernArgs, acc) + 8 && sizeof(HotA) % 4 == 0 && sizeof(TraceArgs) % 8 == 0,
+                  offsetof(HistKernArgs, HB) == offsetof(HistKernArgs, acc) + 8 &&
+                  offsetof(HistKernArgs, SC) == offsetof(HistKernArgs, HB) + sizeof(HotB) && sizeof(HotA) % 4 == 0 &&
+                  sizeof(TraceArgs) % 8 == 0 && sizeof(HotB) % 8 == 0,
               "reload_hot / reload_zones / reload_kernarg read the arguments at these offsets");
 // Re-reads one argument (or a leading part of it) from the kernel-argument segment with scalar loads at the place of use.
 template <typename T>
@@ -1183,9 +1221,14 @@ __device__ __forceinline__ void reload_kernarg(T& dst, size_t byte_offset) {
 // does not carry it, and its 128 doubles per wave hold the LDS image tile instead (with stage A0 running beside it).
 // FIXED: SART_ACCUM_FIXED64 - every sum is accumulated as an integer multiple of its quantum (to_fixed), with integer
 // atomics in LDS and global memory; the slots of the replicas, of the partials and of the accumulator then hold int64.
-template <int BLOCK, bool FAST, bool ROT, int GAS, bool PATHC, bool FIXED>
+// SCAN: fused axion-mass scan (sart_trace_mass_scan).  Stage B leaves the gas-stage conversion probability out of the weight and
+// a loop over the launch's masses (ScanArgs: kernel arguments, read with scalar loads) applies it per mass:
+// sum of w and of w^2 go to per-lane accumulators [mass][2][64] in the 16 KB of LDS that hold the image tile otherwise (ds_add_f64 /
+// ds_add_u64 across the 16 waves of the workgroup); no image, no position sums.  Without PATHC that space is ring 0, so stage
+// A0 stays off for such a launch whatever zones the host built.
+template <int BLOCK, bool FAST, bool ROT, int GAS, bool PATHC, bool FIXED, bool SCAN = false>
 __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
-                                                                double* __restrict__ acc, HotB HBarg) {
+                                                                double* __restrict__ acc, HotB HBarg, ScanArgs SCarg) {
   // One LDS object with the tables FIRST: their addresses then fit the 16-bit offset field of the ds_ instructions, and a
   // lookup is `ds_read v, v_index_scaled offset:TABLE` instead of a literal moved into a register and added to the index
   // (the rings are addressed from a per-wave scalar base anyway).
@@ -1198,7 +1241,10 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   __shared__ LdsLayout lds;
   TablesLds& S = lds.S;
   QueueLds<BLOCK / 64>& Q = lds.Q;
-  static_assert(!PATHC || (FAST && !ROT && GAS == 0), "the constant-path form belongs to the vacuum, unrotated specialisation");
+  static_assert(!PATHC || (FAST && !ROT && GAS >= 0), "the constant-path form belongs to the unrotated specialisations");
+  static_assert(!SCAN || GAS != 0, "a mass scan needs the gas stage");
+  static_assert(!SCAN || kScanMaxMasses * 2 * 64 <= (BLOCK / 64) * kQueue, "the scan accumulators live in the image tile's 128 doubles per wave");
+  __shared__ uint32_t scan_zero[kScanMaxMasses];   // SCAN: rays whose weight vanishes for one mass only (conversion probability exactly 0)
   static_assert(kImageTileMax * kImageTileMax <= (BLOCK / 64) * kQueue,
                 "the LDS image tile (host: kImageTileMax) lives in 128 doubles per wave of this workgroup's rings");
   // cell t of the LDS image tile: 128 doubles per wave, in the space of ring 0 (stage A0 off) or of ring 1's path column (PATHC)
@@ -1223,6 +1269,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     // zeroed rings: a slot that was never written reads as ray 0 / shell 0 / radius 0 / u = 0 instead of arbitrary bits
     uint64_t* q = reinterpret_cast<uint64_t*>(&Q);
     for (int i = threadIdx.x; i < (int)(sizeof(Q) / 8); i += BLOCK) q[i] = 0ull;
+    if (SCAN && threadIdx.x < kScanMaxMasses) scan_zero[threadIdx.x] = 0u;   // (the barrier of stage_tables orders both before their first use)
   }
   stage_tables<BLOCK>(S, Pb, Tb);
   const LdsTables L{S.sincos, S.rcdf, S.rguide, S.shells, S.lut};
@@ -1231,7 +1278,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: scalar addressing of the rings
   const uint64_t waves_total = (uint64_t)gridDim.x * (BLOCK / 64);
   const uint64_t wave_global = (uint64_t)blockIdx.x * (BLOCK / 64) + wave;
-  const bool early_reject = H.n_zones > 0;   // wave-uniform; the host builds no zones for the X-ray test source
+  // wave-uniform; the host builds no zones for the X-ray test source.  (SCAN without PATHC: ring 0 holds the scan accumulators.)
+  const bool early_reject = (SCAN && !PATHC) ? false : H.n_zones > 0;
   // chunks of 256 ids aligned in global-id space; `rel` = id - id_base (fits 32 bits: n_rays < 2^31)
   const uint64_t first_chunk = A.ray_id_offset >> 8;
   const uint64_t id_base = first_chunk << 8;
@@ -1267,7 +1315,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     double radial;
     HotA Hl;
     reload_hot(Hl);
-    constexpr bool ZEXT = FAST && !ROT && GAS == 0;
+    constexpr bool ZEXT = FAST && !ROT && GAS >= 0;
     LaneMasks M;
     (void)phase_a<FAST, ROT ? 1 : 0, ZEXT, PATHC>(Hl, Pb, L, A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi, st, sampled, reached, radial, M);
     const uint64_t valid_m = ballot64(valid);
@@ -1328,9 +1376,47 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       const DevBlob& Bo = lds_opaque(B);
       HotB HB;
       reload_kernarg(HB, offsetof(HistKernArgs, HB));
-      phase_b<false, FAST, GAS, FAST && !ROT && GAS == 0>(Bo.P, L, HB, lds_opaque(Ab), st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
+      phase_b<false, FAST, GAS, FAST && !ROT && GAS >= 0, SCAN>(Bo.P, L, HB, lds_opaque(Ab), st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
+      if constexpr (SCAN) {
+        SART_STAGE_MARK("SCAN");
+        // out.m_passed: rays on the chip whose mass-independent weight factor out.weight is not zero.  Per mass: weight =
+        // out.weight x conversion probability (the single-mass kernels multiply in the same order), accumulated per lane.
+        n_passed += (uint32_t)__popcll(out.m_passed);
+        struct { int32_t n_masses, pad; } hdr;
+        reload_kernarg(hdr, offsetof(HistKernArgs, SC));
+        const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)Ab.flags);
+        const bool use_prob = !(fl & SART_CF_IGNORE_CONV_PROB) & ((GAS >= 0) ? (GAS == 1) : (__builtin_amdgcn_readfirstlane(Bo.P.stage_gas) != 0));
+        const double term1 = Bo.P.gas_term1;
+        for (int k = 0; k < hdr.n_masses; ++k) {   // wave-uniform
+          ScanMass M;
+          reload_kernarg(M, offsetof(HistKernArgs, SC) + offsetof(ScanArgs, m) + (size_t)k * sizeof(ScanMass));
+          double w = out.weight;
+          if (use_prob) w *= gas_conversion_prob(M.dm2_abs, out.gas, term1, L.sincos, sincos_coef());
+          const uint64_t nz = out.m_passed & ballot64(w != 0.0);
+          if (nz != out.m_passed) {
+            asm volatile("; rare: a conversion probability of exactly zero");
+            if (lane == 0) atomicAdd(&scan_zero[k], (uint32_t)__popcll(out.m_passed & ~nz));
+          }
+          if (__builtin_amdgcn_inverse_ballot_w64(nz)) {
+            const uint32_t t = ((uint32_t)k << 7) + (uint32_t)lane;   // cell [k][0][lane]; [k][1][lane] is 64 further on
+            if constexpr (FIXED) {
+              __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell(t)), (unsigned long long)to_fixed(w, M.fx_scale_w),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell(t + 64u)), (unsigned long long)to_fixed(w * w, M.fx_scale_w2),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              __hip_atomic_fetch_add(tile_cell(t), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_add(tile_cell(t + 64u), w * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+        }
+      }
     }
     h1 += n_valid;
+    if constexpr (SCAN) {
+      n_nickel += (uint32_t)__popcll(out.m_nickel);
+      return;
+    }
 #ifdef SART_STAGE_TIMING
     for (int k = 0; k < 5; ++k) cyc_bs[k] += out.tb[k + 1] - out.tb[k];
     cyc_bs[5] += out.tb[0];     // entry stamps, to place the sub-stages inside the B span
@@ -1516,8 +1602,27 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   }
 
   SART_STAGE_MARK("EPILOGUE");
+  if constexpr (SCAN) {
+    // per-mass sums of this workgroup: wave k adds up the 64 per-lane accumulators of mass k (fixed order: the result does not
+    // depend on which wave added what when) -> one plain store per mass and quantity, folded by fold_scan_kernel
+    __syncthreads();   // every wave of the workgroup has left the loop
+    if (wave < SCarg.n_masses) {
+      using Sum = std::conditional_t<FIXED, long long, double>;
+      Sum* const dst = reinterpret_cast<Sum*>(SCarg.partials) + ((size_t)blockIdx.x * kScanMaxMasses + (size_t)wave) * kScanPartialSlots;
+      const uint32_t t = ((uint32_t)wave << 7) + (uint32_t)lane;
+      Sum a, b;
+      if constexpr (FIXED) {
+        a = wave_sum_i64(__double_as_longlong(*tile_cell(t)));
+        b = wave_sum_i64(__double_as_longlong(*tile_cell(t + 64u)));
+      } else {
+        a = wave_sum(*tile_cell(t));
+        b = wave_sum(*tile_cell(t + 64u));
+      }
+      if (lane == 0) { dst[0] = a; dst[1] = b; dst[2] = (Sum)scan_zero[wave]; dst[3] = 0; }
+    }
+  }
   // flush of the LDS image tile: one global atomic per non-empty tile pixel and workgroup
-  if (A.tile_n > 0) {
+  if (!SCAN && A.tile_n > 0) {
     __syncthreads();   // every wave of the workgroup has left the loop (uniform condition: kernel argument)
     const uint32_t tn = (uint32_t)A.tile_n, n_tile = tn * tn;
     double* const img = A.replicas + (size_t)((uint32_t)wave_global & A.replica_mask) * (size_t)A.replica_stride;
@@ -1534,7 +1639,12 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
 
   // scalars: wave reduction -> LDS -> one plain store per workgroup and quantity (folded by fold_scalars_kernel)
   // (FIXED: the slots hold int64 - sums in quanta, counters as integers - and are added as integers all the way)
-  __shared__ Sum red[BLOCK / 64][SART_ACC_COUNT];
+  // (the staging area is the head of wave 0's rings - X0, Y0, tsx: dead once every wave has left the loop, and apart from the
+  // image tile / the scan accumulators, which live in the path or the ring-0 columns)
+  static_assert(sizeof(Sum) * (BLOCK / 64) * SART_ACC_COUNT <= 3 * kQueue * sizeof(double) && offsetof(WaveRings, Y0) == kQueue * sizeof(double) &&
+                    offsetof(WaveRings, tsx) == 2 * kQueue * sizeof(double), "the scalar staging area fits the first three ring columns of wave 0");
+  __syncthreads();
+  Sum (*const red)[SART_ACC_COUNT] = reinterpret_cast<Sum (*)[SART_ACC_COUNT]>(&Q.w[0].X0[0]);
   Sum sw, sw2, sxx, syy, srr;
   if constexpr (FIXED) {
     sw = wave_sum_i64(sum_w); sw2 = wave_sum_i64(sum_w2); sxx = wave_sum_i64(sum_x); syy = wave_sum_i64(sum_y); srr = wave_sum_i64(sum_r);
@@ -1572,49 +1682,55 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   }
 }
 
-// acc scalars += sum over workgroups of the partials; N_RAYS += n_rays.  256 threads: 16 groups x 16 quantities.
+// acc scalars += sum over workgroups of the partials; N_RAYS += n_rays.  256 threads: 8 groups x 32 quantity slots (24 used).
 __global__ __launch_bounds__(256) void fold_scalars_kernel(double* __restrict__ scalars, const double* __restrict__ partials,
                                                            int n_blocks, double n_rays) {
-  static_assert(SART_ACC_COUNT == 16, "layout of the reduction below");
-  __shared__ double red[16][16];
-  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
+  static_assert(SART_ACC_COUNT <= 32, "layout of the reduction below");
+  __shared__ double red[8][32];
+  const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
   double t = 0.0;
-  for (int b = g; b < n_blocks; b += 16) t += partials[(size_t)b * SART_ACC_COUNT + k];
+  if (k < SART_ACC_COUNT)
+    for (int b = g; b < n_blocks; b += 8) t += partials[(size_t)b * SART_ACC_COUNT + k];
   red[g][k] = t;
   __syncthreads();
-  if (threadIdx.x < 16) {
+  if (threadIdx.x < SART_ACC_COUNT) {
     double s = (k == SART_ACC_N_RAYS) ? n_rays : 0.0;
-    for (int i = 0; i < 16; ++i) s += red[i][k];
+    for (int i = 0; i < 8; ++i) s += red[i][k];
     scalars[k] += s;
   }
 }
 
-// SART_ACCUM_FIXED64 form of the same fold, in integers.  The four sums every passed ray of every launch adds to are kept in
-// two limbs, value = hi * 2^40 + lo (include/sart.h): the workgroup partials (each < 2^57) are split before they are added,
+// SART_ACCUM_FIXED64 form of the same fold, in integers.  The five sums every passed ray of every launch adds to are kept in
+// two limbs, value = hi * 2^40 + lo (include/sart.h): the workgroup partials (each < 2^62) are split before they are added,
 // so nothing can wrap, and lo is left in [0, 2^40).  Slot k's thread owns slot k and, for a two-limb sum, its *_HI slot; the
-// threads of the *_HI slots (12 .. 15, whose partials are zero) write nothing.
+// threads of the *_HI slots (whose partials are zero) write nothing.
 __device__ __forceinline__ int fixed_hi_slot(int k) {
   return k == SART_ACC_SUM_WEIGHTS ? SART_ACC_SUM_WEIGHTS_HI : k == SART_ACC_SUM_X ? SART_ACC_SUM_X_HI
-         : k == SART_ACC_SUM_Y ? SART_ACC_SUM_Y_HI : k == SART_ACC_SUM_R ? SART_ACC_SUM_R_HI : -1;
+         : k == SART_ACC_SUM_Y ? SART_ACC_SUM_Y_HI : k == SART_ACC_SUM_R ? SART_ACC_SUM_R_HI
+         : k == SART_ACC_SUM_WEIGHTS_SQ ? SART_ACC_SUM_WEIGHTS_SQ_HI : -1;
+}
+__device__ __forceinline__ bool fixed_is_hi_slot(int k) {
+  return (k >= SART_ACC_SUM_WEIGHTS_HI && k <= SART_ACC_SUM_R_HI) || k == SART_ACC_SUM_WEIGHTS_SQ_HI;
 }
 __global__ __launch_bounds__(256) void fold_scalars_fixed_kernel(long long* __restrict__ scalars, const long long* __restrict__ partials,
                                                                  int n_blocks, long long n_rays) {
-  static_assert(SART_ACC_COUNT == 16, "layout of the reduction below");
+  static_assert(SART_ACC_COUNT <= 32, "layout of the reduction below");
   constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
-  __shared__ long long red_lo[16][16], red_hi[16][16];
-  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
+  __shared__ long long red_lo[8][32], red_hi[8][32];
+  const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
   long long lo = 0, hi = 0;
-  for (int b = g; b < n_blocks; b += 16) {
-    const long long p = partials[(size_t)b * SART_ACC_COUNT + k];
-    lo += p & kMask;                 // arithmetic shift + mask: p = (p >> 40) * 2^40 + (p & mask) for negative p as well
-    hi += p >> kFixedLimbBits;
-  }
+  if (k < SART_ACC_COUNT)
+    for (int b = g; b < n_blocks; b += 8) {
+      const long long p = partials[(size_t)b * SART_ACC_COUNT + k];
+      lo += p & kMask;                 // arithmetic shift + mask: p = (p >> 40) * 2^40 + (p & mask) for negative p as well
+      hi += p >> kFixedLimbBits;
+    }
   red_lo[g][k] = lo;
   red_hi[g][k] = hi;
   __syncthreads();
-  if (threadIdx.x < 16 && k < SART_ACC_SUM_WEIGHTS_HI) {
+  if (threadIdx.x < SART_ACC_COUNT && !fixed_is_hi_slot(k)) {
     lo = 0; hi = 0;
-    for (int i = 0; i < 16; ++i) { lo += red_lo[i][k]; hi += red_hi[i][k]; }
+    for (int i = 0; i < 8; ++i) { lo += red_lo[i][k]; hi += red_hi[i][k]; }
     const int kh = fixed_hi_slot(k);
     if (kh >= 0) {
       lo += scalars[k];              // < 2^40 + 2^14 * 2^40
@@ -1640,34 +1756,108 @@ __global__ __launch_bounds__(256) void fold_replicas_kernel(T* __restrict__ acc,
   acc[i] += s;
 }
 
+// Fused mass scan: rows of the scan accumulator (include/sart.h: SART_SCAN_*) += the per-workgroup sums of one launch.
+// One thread per (mass, quantity); thread (k, 2) turns the counts into N_PASSED of mass k = rays with a non-zero
+// mass-independent weight factor minus those whose conversion probability for this mass is exactly zero.  `shared_row` (first
+// group of masses of a scan only, else nullptr): the mass-independent counters.  Summation order = workgroup order: fixed
+// for a given grid.  FIXED: integers, the two sums in two limbs like fold_scalars_fixed_kernel.
+template <bool FIXED>
+__global__ __launch_bounds__(64) void fold_scan_kernel(double* __restrict__ rows_, double* __restrict__ shared_row_, const double* __restrict__ scal_partials_,
+                                                       const double* __restrict__ scan_partials_, int n_blocks, int n_masses, double n_rays) {
+  using Sum = std::conditional_t<FIXED, long long, double>;
+  constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
+  Sum* const rows = reinterpret_cast<Sum*>(rows_);
+  Sum* const shared_row = reinterpret_cast<Sum*>(shared_row_);
+  const Sum* const scal = reinterpret_cast<const Sum*>(scal_partials_);
+  const Sum* const scan = reinterpret_cast<const Sum*>(scan_partials_);
+  static_assert(kScanMaxMasses * kScanPartialSlots == 64, "one thread per (mass, partial slot)");
+  const int k = threadIdx.x >> 2, j = threadIdx.x & 3;
+  if (k < n_masses && j < 3) {
+    Sum* const row = rows + (size_t)k * SART_SCAN_ROW;
+    if constexpr (FIXED) {
+      long long lo = 0, hi = 0;
+      for (int b = 0; b < n_blocks; ++b) {
+        long long p = scan[((size_t)b * kScanMaxMasses + k) * kScanPartialSlots + j];
+        if (j == 2) p = scal[(size_t)b * SART_ACC_COUNT + SART_ACC_N_PASSED] - p;
+        lo += p & kMask;
+        hi += p >> kFixedLimbBits;
+      }
+      if (j == 2) {
+        row[SART_SCAN_N_PASSED] += (hi << kFixedLimbBits) + lo;
+      } else {
+        const int s = j == 0 ? SART_SCAN_SUM_WEIGHTS : SART_SCAN_SUM_WEIGHTS_SQ, sh = j == 0 ? SART_SCAN_SUM_WEIGHTS_HI : SART_SCAN_SUM_WEIGHTS_SQ_HI;
+        lo += row[s];
+        row[s] = lo & kMask;
+        row[sh] += hi + (lo >> kFixedLimbBits);
+      }
+    } else {
+      double t = 0.0;
+      for (int b = 0; b < n_blocks; ++b) {
+        double p = scan[((size_t)b * kScanMaxMasses + k) * kScanPartialSlots + j];
+        if (j == 2) p = scal[(size_t)b * SART_ACC_COUNT + SART_ACC_N_PASSED] - p;
+        t += p;
+      }
+      row[j == 0 ? SART_SCAN_SUM_WEIGHTS : j == 1 ? SART_SCAN_SUM_WEIGHTS_SQ : SART_SCAN_N_PASSED] += t;
+    }
+  }
+  if (shared_row && threadIdx.x >= 60) {   // threads (15, 0..3): the four counters that come from the workgroup partials
+    const int c = threadIdx.x - 60;
+    const int src = c == 0 ? SART_ACC_N_REACHED_TELESCOPE : c == 1 ? SART_ACC_N_SHELL_SELECTED : c == 2 ? SART_ACC_N_HIT_NICKEL : SART_ACC_N_PASSED;
+    const int dst = c == 0 ? SART_SCAN_N_REACHED_TELESCOPE : c == 1 ? SART_SCAN_N_SHELL_SELECTED : c == 2 ? SART_SCAN_N_HIT_NICKEL : SART_SCAN_N_ON_DETECTOR;
+    Sum t = 0;
+    for (int b = 0; b < n_blocks; ++b) t += scal[(size_t)b * SART_ACC_COUNT + src];
+    shared_row[dst] += t;
+    if (c == 0) shared_row[SART_SCAN_N_RAYS] += (Sum)n_rays;
+  }
+}
+
+// What the finalize kernels report about a raw SART_ACCUM_FIXED64 accumulator (OR-ed into a word of the context that the next
+// sart_synchronize reads): integers that no longer mean what they should.
+constexpr uint32_t kFixedStatusWrapped = 1u;       // a slot is negative or >= 2^62: wrapped, or about to (weights and counts are >= 0)
+constexpr uint32_t kFixedStatusUnresolved = 2u;    // the accumulated weights average below 2^12 quanta per passed ray
+__device__ __forceinline__ void fixed_status_check_slot(long long v, uint32_t* status) {
+  if (v < 0 || v >= (1ll << 62)) atomicOr(status, kFixedStatusWrapped);
+}
+// Returns false if the squared weights average below 2^6 quanta per passed ray: the integers do not resolve them (their quantum
+// 2^-39 of the squared weight bound is as fine as an int64 per workgroup allows); SUM_WEIGHTS_SQ - an error estimate, nothing
+// else depends on it - then reads NaN in the f64 output instead of a number that looks like one.
+__device__ __forceinline__ bool fixed_status_check_means(double quanta_w, double quanta_w2, double n_passed, uint32_t* status) {
+  if (!(n_passed > 0.0)) return true;
+  if (quanta_w < 4096.0 * n_passed) atomicOr(status, kFixedStatusUnresolved);
+  return quanta_w2 >= 64.0 * n_passed;
+}
+
 // Raw SART_ACCUM_FIXED64 accumulator -> the f64 layout of include/sart.h (sart_finalize_accumulator_device).  Element-wise, so
-// `out` may alias `in`; the 16 scalars are converted by one thread, which reads all of them before it writes.
+// `out` may alias `in`; the scalars are converted by one thread, which reads all of them before it writes.
 struct FinalizeArgs {
   long long n_img;
   int32_t spectra, n_radial_bins, n_energies1, _pad;
   double q_w, q_w2, q_pos, q_refl;
 };
-__global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in, double* out, FinalizeArgs F) {
+__global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in, double* out, FinalizeArgs F, uint32_t* status) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long n_scalar0 = F.n_img, n_spec0 = F.n_img + SART_ACC_COUNT;
   if (i < n_scalar0) {
-    out[i] = (double)in[i] * F.q_w;                        // power-of-two quantum: the product is exact
+    const long long v = in[i];
+    fixed_status_check_slot(v, status);
+    out[i] = (double)v * F.q_w;                            // power-of-two quantum: the product is exact
   } else if (i == n_scalar0) {
     long long v[SART_ACC_COUNT];
-    for (int k = 0; k < SART_ACC_COUNT; ++k) v[k] = in[n_scalar0 + k];
-    auto two_limb = [&](int k, int kh, double q) {         // hi * 2^40 and lo are exact doubles: one rounding in the sum
-      return ((double)v[kh] * (double)(1ll << kFixedLimbBits) + (double)v[k]) * q;
+    for (int k = 0; k < SART_ACC_COUNT; ++k) { v[k] = in[n_scalar0 + k]; fixed_status_check_slot(v[k], status); }
+    auto limbs = [&](int k, int kh) {                      // hi * 2^40 and lo are exact doubles: one rounding in the sum
+      return (double)v[kh] * (double)(1ll << kFixedLimbBits) + (double)v[k];
     };
+    const bool sq_ok = fixed_status_check_means(limbs(SART_ACC_SUM_WEIGHTS, SART_ACC_SUM_WEIGHTS_HI),
+                                                limbs(SART_ACC_SUM_WEIGHTS_SQ, SART_ACC_SUM_WEIGHTS_SQ_HI), (double)v[SART_ACC_N_PASSED], status);
     for (int k = 0; k < SART_ACC_COUNT; ++k) {
       double r;
       switch (k) {
-        case SART_ACC_SUM_WEIGHTS: r = two_limb(k, SART_ACC_SUM_WEIGHTS_HI, F.q_w); break;
-        case SART_ACC_SUM_X: r = two_limb(k, SART_ACC_SUM_X_HI, F.q_pos); break;
-        case SART_ACC_SUM_Y: r = two_limb(k, SART_ACC_SUM_Y_HI, F.q_pos); break;
-        case SART_ACC_SUM_R: r = two_limb(k, SART_ACC_SUM_R_HI, F.q_pos); break;
-        case SART_ACC_SUM_WEIGHTS_SQ: r = (double)v[k] * F.q_w2; break;
-        case SART_ACC_SUM_WEIGHTS_HI: case SART_ACC_SUM_X_HI: case SART_ACC_SUM_Y_HI: case SART_ACC_SUM_R_HI: r = 0.0; break;
-        default: r = (double)v[k]; break;                  // counters
+        case SART_ACC_SUM_WEIGHTS: r = limbs(k, SART_ACC_SUM_WEIGHTS_HI) * F.q_w; break;
+        case SART_ACC_SUM_X: r = limbs(k, SART_ACC_SUM_X_HI) * F.q_pos; break;
+        case SART_ACC_SUM_Y: r = limbs(k, SART_ACC_SUM_Y_HI) * F.q_pos; break;
+        case SART_ACC_SUM_R: r = limbs(k, SART_ACC_SUM_R_HI) * F.q_pos; break;
+        case SART_ACC_SUM_WEIGHTS_SQ: r = sq_ok ? limbs(k, SART_ACC_SUM_WEIGHTS_SQ_HI) * F.q_w2 : __builtin_nan(""); break;
+        default: r = fixed_is_hi_slot(k) ? 0.0 : (double)v[k]; break;   // counters (the reserved slots hold 0)
       }
       out[n_scalar0 + k] = r;
     }
@@ -1676,8 +1866,36 @@ __global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in
     const long long j = i - n_spec0, nr = F.n_radial_bins, ne = F.n_energies1;
     if (j < 2 * nr + 3 * ne) {
       const double q = j < nr ? 1.0 : j < 2 * nr ? F.q_w : j < 2 * nr + ne ? 1.0 : j < 2 * nr + 2 * ne ? F.q_w : F.q_refl;
-      out[i] = (double)in[i] * q;
+      const long long v = in[i];
+      fixed_status_check_slot(v, status);
+      out[i] = (double)v * q;
     }
+  }
+}
+
+// Raw FIXED64 scan accumulator -> doubles: rows [0, n) of `in` / `out` (a group of up to kScanMaxMasses masses, whose quanta
+// travel in the kernel arguments) and, if `shared_row`, the counter row behind the whole scan.  One thread per row.
+struct FinalizeScanArgs {
+  int32_t n_masses, shared_row;    // shared_row: row index of the counters relative to `in`, or -1
+  double q_w[kScanMaxMasses], q_w2[kScanMaxMasses];
+};
+__global__ __launch_bounds__(64) void finalize_scan_kernel(const long long* in, double* out, FinalizeScanArgs F, uint32_t* status) {
+  const int k = threadIdx.x;
+  long long v[SART_SCAN_ROW];
+  if (k < F.n_masses) {
+    for (int j = 0; j < SART_SCAN_ROW; ++j) { v[j] = in[(size_t)k * SART_SCAN_ROW + j]; fixed_status_check_slot(v[j], status); }
+    const double two40 = (double)(1ll << kFixedLimbBits);
+    const double sw = (double)v[SART_SCAN_SUM_WEIGHTS_HI] * two40 + (double)v[SART_SCAN_SUM_WEIGHTS];
+    const double sw2 = (double)v[SART_SCAN_SUM_WEIGHTS_SQ_HI] * two40 + (double)v[SART_SCAN_SUM_WEIGHTS_SQ];
+    const bool sq_ok = fixed_status_check_means(sw, sw2, (double)v[SART_SCAN_N_PASSED], status);
+    double* const o = out + (size_t)k * SART_SCAN_ROW;
+    for (int j = 0; j < SART_SCAN_ROW; ++j) o[j] = 0.0;
+    o[SART_SCAN_SUM_WEIGHTS] = sw * F.q_w[k];
+    o[SART_SCAN_SUM_WEIGHTS_SQ] = sq_ok ? sw2 * F.q_w2[k] : __builtin_nan("");
+    o[SART_SCAN_N_PASSED] = (double)v[SART_SCAN_N_PASSED];
+  } else if (k == 63 && F.shared_row >= 0) {
+    for (int j = 0; j < SART_SCAN_ROW; ++j) { v[j] = in[(size_t)F.shared_row * SART_SCAN_ROW + j]; fixed_status_check_slot(v[j], status); }
+    for (int j = 0; j < SART_SCAN_ROW; ++j) out[(size_t)F.shared_row * SART_SCAN_ROW + j] = (double)v[j];
   }
 }
 
@@ -1737,13 +1955,14 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
 // (reload_hot / reload_zones / reload_kernarg).  Not part of the C-ABI: tests/test_host_and_abi.py compares them with the
 // argument offsets in the code object's metadata, so that a compiler that lays arguments out differently fails a CPU test
 // instead of faulting on the GPU.
-extern "C" __attribute__((visibility("default"))) void sart_internal_kernarg_layout(int32_t out[6]) {
+extern "C" __attribute__((visibility("default"))) void sart_internal_kernarg_layout(int32_t out[7]) {
   out[0] = (int32_t)offsetof(HistKernArgs, H);
   out[1] = (int32_t)offsetof(HistKernArgs, blob);
   out[2] = (int32_t)offsetof(HistKernArgs, A);
   out[3] = (int32_t)offsetof(HistKernArgs, acc);
   out[4] = (int32_t)offsetof(HistKernArgs, HB);
-  out[5] = (int32_t)sizeof(HistKernArgs);
+  out[5] = (int32_t)offsetof(HistKernArgs, SC);
+  out[6] = (int32_t)sizeof(HistKernArgs);
 }
 
 // ---- device math under test (tests/test_gpu_math.py): evaluates one helper on an array, not part of the C-ABI ----
@@ -1793,15 +2012,17 @@ extern "C" __attribute__((visibility("default"))) int sart_internal_math_eval(in
 // ---- launch wrappers (called from sart_api.hip) ----
 int records_block() { return kRecBlock; }
 // Variants: 0 = specialised (solar source, no hole loop) vacuum, not rotated; 1 = generic, not rotated; 2 = generic, rotated;
-// 3 = specialised, gas stage; 4 = specialised, rotated; 5 = variant 0 with the constant path in the magnetic field (PATHC).  All with 1024 threads = 4 waves / SIMD (measured fastest of 256 / 512 /
-// 768 / 1024).
+// 3 = specialised, gas stage; 4 = specialised, rotated; 5 = variant 0 with the constant path in the magnetic field (PATHC);
+// 6 = variant 3 with the constant path.  All with 1024 threads = 4 waves / SIMD (measured fastest of 256 / 512 / 768 / 1024).
+// The fused mass scan exists for the variants that can run the gas stage: 1, 2, 3, 6.
 int histogram_block_of(int) { return 1024; }
 
 #define SART_HIST_VARIANTS(X) \
   X(0, true, false, 0, false) X(1, false, false, -1, false) X(2, false, true, -1, false) X(3, true, false, 1, false) \
-  X(4, true, true, 0, false) X(5, true, false, 0, true)
+  X(4, true, true, 0, false) X(5, true, false, 0, true) X(6, true, false, 1, true)
+#define SART_SCAN_VARIANTS(X) X(1, false, false, -1, false) X(2, false, true, -1, false) X(3, true, false, 1, false) X(6, true, false, 1, true)
 
-int histogram_blocks_per_cu(int variant) {   // the FIXED64 instantiations use the same LDS and launch bounds
+int histogram_blocks_per_cu(int variant) {   // the FIXED64 and SCAN instantiations use the same LDS and launch bounds
   int n = 0;
   hipError_t e = hipErrorInvalidValue;
   switch (variant) {
@@ -1815,10 +2036,12 @@ int histogram_blocks_per_cu(int variant) {   // the FIXED64 instantiations use t
 
 void launch_trace_histogram(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
                             hipStream_t stream, int variant, bool fixed) {
+  ScanArgs SC;
+  memset(&SC, 0, sizeof SC);   // n_masses = 0: not a scan
   switch (variant + (fixed ? 100 : 0)) {
 #define X(ID, F, R, G, PC) \
-    case ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G, PC, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB); break; \
-    case 100 + ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G, PC, true>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB); break;
+    case ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G, PC, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB, SC); break; \
+    case 100 + ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G, PC, true>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, acc, HB, SC); break;
     SART_HIST_VARIANTS(X)
 #undef X
     default: return;
@@ -1839,12 +2062,42 @@ void launch_trace_histogram(const HotA& H, const HotB& HB, const DevBlob* blob, 
                        (int)A.replica_mask + 1, A.replica_stride);
 }
 
+// One group of SC.n_masses <= kScanMaxMasses masses over the rays of A: trace + per-mass accumulation, then the fold into
+// `rows` (the group's first row of the scan accumulator) and, if `shared_row`, into the scan's counter row.
+bool launch_trace_mass_scan(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, const ScanArgs& SC, double* rows,
+                            double* shared_row, int n_blocks, hipStream_t stream, int variant, bool fixed) {
+  double* const no_acc = nullptr;   // a scan accumulates no image and no spectra
+  switch (variant + (fixed ? 100 : 0)) {
+#define X(ID, F, R, G, PC) \
+    case ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G, PC, false, true>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, no_acc, HB, SC); break; \
+    case 100 + ID: hipLaunchKernelGGL((trace_histogram_kernel<1024, F, R, G, PC, true, true>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, no_acc, HB, SC); break;
+    SART_SCAN_VARIANTS(X)
+#undef X
+    default: return false;
+  }
+  if (fixed)
+    hipLaunchKernelGGL(fold_scan_kernel<true>, dim3(1), dim3(64), 0, stream, rows, shared_row, A.partials, SC.partials, n_blocks, SC.n_masses, (double)A.n_rays);
+  else
+    hipLaunchKernelGGL(fold_scan_kernel<false>, dim3(1), dim3(64), 0, stream, rows, shared_row, A.partials, SC.partials, n_blocks, SC.n_masses, (double)A.n_rays);
+  return true;
+}
+
 void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectra, int n_radial_bins, int n_energies1, double q_w,
-                           double q_w2, double q_pos, double q_refl, hipStream_t stream) {
+                           double q_w2, double q_pos, double q_refl, uint32_t* status_dev, hipStream_t stream) {
   FinalizeArgs F{(long long)n_img, spectra, n_radial_bins, n_energies1, 0, q_w, q_w2, q_pos, q_refl};
   const size_t total = n_img + SART_ACC_COUNT + (spectra ? 2 * (size_t)n_radial_bins + 3 * (size_t)n_energies1 : 0);
   hipLaunchKernelGGL(finalize_fixed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                     reinterpret_cast<const long long*>(in), out, F);
+                     reinterpret_cast<const long long*>(in), out, F, status_dev);
+}
+// rows [0, n_masses) of in / out with the quanta q_w[k], q_w2[k]; shared_row >= 0: that row (relative to `in`) holds the counters
+void launch_finalize_scan(const void* in, double* out, int n_masses, const double* q_w, const double* q_w2, int shared_row,
+                          uint32_t* status_dev, hipStream_t stream) {
+  FinalizeScanArgs F;
+  memset(&F, 0, sizeof F);
+  F.n_masses = n_masses;
+  F.shared_row = shared_row;
+  for (int k = 0; k < n_masses; ++k) { F.q_w[k] = q_w[k]; F.q_w2[k] = q_w2[k]; }
+  hipLaunchKernelGGL(finalize_scan_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const long long*>(in), out, F, status_dev);
 }
 void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream, const double* uniforms_dev) {

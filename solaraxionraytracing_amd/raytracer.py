@@ -331,6 +331,29 @@ class RayTracer:
         """Asynchronous form: adds into a device accumulator (e.g. ``torch_tensor.data_ptr()``)."""
         _lib.check(self.lib.sart_trace_histogram_device(self.handle, C.byref(params), C.c_void_p(accumulator_ptr)))
 
+    # -- fused axion-mass scan (gas stage; include/sart.h "fused axion-mass scan") -------------
+    def trace_mass_scan(self, masses_ev, n_rays: int, seed: int = 299792458, ray_id_offset: int = 0, flags: int | None = None):
+        """Every ray of [ray_id_offset, ray_id_offset + n_rays) traced ONCE and weighed for every axion mass.  Returns
+        (per-mass dict of arrays SUM_WEIGHTS / SUM_WEIGHTS_SQ / N_PASSED, dict of the mass-independent counters)."""
+        masses = np.ascontiguousarray(masses_ev, dtype=np.float64)
+        p = self.trace_params(n_rays, seed, ray_id_offset, flags)
+        out = np.empty(mass_scan_len(masses.size))
+        _lib.check(self.lib.sart_trace_mass_scan(self.handle, C.byref(p), _lib.as_dp(masses), masses.size, _lib.as_dp(out)))
+        return split_mass_scan(out, masses.size)
+
+    def trace_mass_scan_device(self, params: TraceParams, masses_ev, scan_acc_ptr: int):
+        """Asynchronous form: adds into a device scan accumulator of mass_scan_len(n) 8-byte slots (raw int64 in fixed64 mode)."""
+        masses = np.ascontiguousarray(masses_ev, dtype=np.float64)
+        _lib.check(self.lib.sart_trace_mass_scan_device(self.handle, C.byref(params), _lib.as_dp(masses), masses.size,
+                                                        C.c_void_p(scan_acc_ptr)))
+
+    def finalize_mass_scan_device(self, params: TraceParams, masses_ev, raw_ptr: int, out_ptr: int | None = None):
+        """Raw FIXED64 scan accumulator (device) -> doubles (device; in place by default).  Asynchronous; what the conversion
+        finds wrong (unresolved weights, wrapped slots) is raised by the next ``synchronize()``."""
+        masses = np.ascontiguousarray(masses_ev, dtype=np.float64)
+        _lib.check(self.lib.sart_finalize_mass_scan_device(self.handle, C.byref(params), _lib.as_dp(masses), masses.size,
+                                                           C.c_void_p(raw_ptr), C.c_void_p(out_ptr if out_ptr is not None else raw_ptr)))
+
     # -- measurement --------------------------------------------------------------------------
     def enable_kernel_timing(self, enable: bool = True):
         _lib.check(self.lib.sart_enable_kernel_timing(self.handle, 1 if enable else 0))
@@ -383,6 +406,19 @@ def accumulator_len(image_n: int = 256) -> int:
     return image_n * image_n + _lib.SART_ACC_COUNT
 
 
+def mass_scan_len(n_masses: int) -> int:
+    """sart_mass_scan_len: 8-byte slots of a scan accumulator."""
+    return (int(n_masses) + 1) * _lib.SCAN_ROW
+
+
+def split_mass_scan(acc: np.ndarray, n_masses: int):
+    """(per-mass dict of arrays, shared-counter dict) from a finalized scan accumulator."""
+    rows = np.asarray(acc, dtype=np.float64).reshape(n_masses + 1, _lib.SCAN_ROW)
+    per_mass = {k: rows[:n_masses, i].copy() for k, i in _lib.SCAN.items()}
+    shared = {k: float(rows[n_masses, i]) for k, i in _lib.SCAN_SHARED.items()}
+    return per_mass, shared
+
+
 def calculateFluxFractions(tracer: RayTracer, n_rays: int = 1_000_000, seed: int = 299792458,
                            ray_id_offset: int = 0):
     """calculateFluxFractions (raytracer.nim:2755-2776) in histogram form: NumberOfPointsSun rays ->
@@ -391,15 +427,35 @@ def calculateFluxFractions(tracer: RayTracer, n_rays: int = 1_000_000, seed: int
 
 
 def performAxionMassScan(tracer: RayTracer, masses_ev, n_rays_per_mass: int = 1_000_000, seed: int = 299792458,
-                         flags: int | None = None, ray_id_offset: int = 0):
-    """Gas-stage m_a scan (BASELINE config 5) through the C++ host driver: flux (sum of weights) per axion mass."""
+                         flags: int | None = None, ray_id_offset: int = 0, errors: bool = False):
+    """m_a scan (BASELINE configs[4]) through the C++ host driver: flux (sum of weights) per axion mass.  Gas stage: the
+    fused scan kernel - every ray of [ray_id_offset, ray_id_offset + n_rays_per_mass) is traced once and weighed for every
+    mass (common random numbers).  ``errors``: also return sqrt(sum of squared weights) and the passed-ray counts."""
     host = _lib.load_host()
     masses = np.ascontiguousarray(masses_ev, dtype=np.float64)
-    fluxes = np.empty_like(masses)
+    fluxes, sq, n_pass = np.empty_like(masses), np.empty_like(masses), np.empty_like(masses)
     fl = tracer.full.flags if flags is None else flags
-    _lib.check(host.sart_host_perform_axion_mass_scan(tracer.handle, _lib.as_dp(masses), masses.size, n_rays_per_mass, seed,
-                                                      ray_id_offset, fl, _lib.as_dp(fluxes)), host=True)
-    return fluxes
+    _lib.check(host.sart_host_axion_mass_scan(tracer.handle, _lib.as_dp(masses), masses.size, n_rays_per_mass, seed,
+                                              ray_id_offset, fl, _lib.as_dp(fluxes), _lib.as_dp(sq), _lib.as_dp(n_pass)), host=True)
+    return (fluxes, np.sqrt(sq), n_pass) if errors else fluxes
+
+
+def performAxionMassScanHostLoop(tracer: RayTracer, masses_ev, n_rays_per_mass: int = 1_000_000, seed: int = 299792458,
+                                 flags: int | None = None, ray_id_offset: int = 0, same_rays: bool = True):
+    """The reference-shaped scan (a host loop: set the mass, re-trace, sum) - what the fused kernel replaces; kept as the
+    comparison of the parity tests and of bench.py.  ``same_rays``: every mass on the same ray ids (what the fused scan
+    computes), else mass i on its own block of ids."""
+    masses = np.ascontiguousarray(masses_ev, dtype=np.float64)
+    out = np.empty_like(masses)
+    m0 = tracer.full.setup.m_axion
+    try:
+        for i, m in enumerate(masses):
+            tracer.set_axion_mass(float(m))
+            off = ray_id_offset + (0 if same_rays else i * n_rays_per_mass)
+            out[i] = tracer.trace_histogram(n_rays_per_mass, seed, off, flags)[1]["SUM_WEIGHTS"]
+    finally:
+        tracer.set_axion_mass(m0)
+    return out
 
 
 def performAngularScan(tracer: RayTracer, angularScanMin: float, angularScanMax: float, numAngularScanPoints: int = 50,

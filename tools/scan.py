@@ -5,9 +5,11 @@
             effective-area style scan of telescope_turned_y, angle bins sharded over the ranks (BASELINE config 4).
             Writes a CSV (the reference only makes a PDF) and compares with the two curves the reference overlays
             (xmm_newton_angular_effective_area.csv, McXtrace_angular_xmm.csv; :2805-2813).
-  mass      gas-stage axion-mass scan on the full AGSS09 emission table (BASELINE configs[4]): masses sharded over the ranks,
-            or (--shard rays) the rays of every mass point sharded over the ranks with one reduce of the fused accumulator per
-            point ("1e10 rays across 8 MI355X with RCCL histogram reduce": --points 10 --rays 1e9 --shard rays on 8 ranks).
+  mass      gas-stage axion-mass scan on the full AGSS09 emission table (BASELINE configs[4]) through the FUSED scan kernel
+            (sart_trace_mass_scan): every rank traces its share of the ray ids ONCE and weighs each ray for every mass; one
+            reduce of the scan accumulator (8 (points + 1) slots) over the ranks closes the scan ("1e10 rays across 8 MI355X
+            with RCCL histogram reduce": --points 32 --rays 1e10 on 8 ranks).  All masses see the same rays (common random
+            numbers).  --host-loop: the reference-shaped scan instead (a re-trace per mass point; --shard bins | rays).
 
 Examples
   python tools/scan.py angular --angularScanMin 0 --angularScanMax 0.3 --numAngularScanPoints 16 --rays 1e7
@@ -34,8 +36,11 @@ def main():
     ap.add_argument("--rays", type=float, default=1e7, help="rays per scan point")
     ap.add_argument("--chip", type=float, default=100.0, help="chip size in mm for the angular scan (SURVEY App. C)")
     ap.add_argument("--shard", default="bins", choices=["bins", "rays"],
-                    help="bins: every scan point is a full run on one rank (BASELINE config 4); rays: every rank traces its "
-                         "share of the ray ids of every point and the accumulators are reduced once per point (config 5)")
+                    help="angular scan, mass --host-loop: bins = every scan point is a full run on one rank (BASELINE config 4); "
+                         "rays = every rank traces its share of the ray ids of every point and the accumulators are reduced once per "
+                         "point.  The fused mass scan always shards the rays")
+    ap.add_argument("--host-loop", action="store_true",
+                    help="mass: one re-trace per mass point (what the fused scan replaces; independent ray blocks per point)")
     ap.add_argument("--emission", default=None, choices=["agss09-device", "agss09", "primakoff", "legacy", "flat"],
                     help="solar emission table; default: agss09-device (all terms of readOpacityFile.nim on the AGSS09 model; emission "
                          "kernel -> CDFs -> guide tables without leaving the GPU, sart_emission_to_solar_tables) for the mass scan = "
@@ -73,7 +78,38 @@ def main():
         full = sa.initFullSetup(stage=L.SK_GAS, emission=emission)   # BASELINE configs[4]: full AGSS09 emission + m_a scan
         flags = 0
         xs = np.linspace(args.massMin, args.massMax, args.points)
-    if args.shard == "rays":
+    fused = args.mode == "mass" and not args.host_loop
+    errs = None
+    if fused:
+        # Fused scan: rank r traces ray ids [lo_r, hi_r) ONCE for all masses into a device scan accumulator; ONE reduce of
+        # 8 (points + 1) slots over the ranks (int64 when fixed64: the curve then does not depend on the number of ranks).
+        use_cuda = not (world > 1 and torch.distributed.get_backend() != "nccl")
+        fixed64 = args.accumulation == "fixed64"
+        acc = torch.zeros(sa.mass_scan_len(len(xs)), dtype=torch.float64, device=torch.device("cuda", local_rank))
+        lo, hi = D.shard_range(n_rays, rank, world)
+        with sa.RayTracer(full, device=local_rank) as rt:
+            stream = torch.cuda.Stream(device=acc.device)
+            torch.cuda.set_stream(stream)
+            rt.set_stream(stream.cuda_stream)
+            rt.set_accumulation_mode(args.accumulation)
+            p = rt.trace_params(hi - lo, ray_id_offset=lo, flags=flags, accumulate=True)
+            rt.trace_mass_scan_device(p, xs, acc.data_ptr())
+            red = acc if use_cuda else acc.cpu()
+            D.reduce_accumulator(red, dst=0, fixed64=fixed64)
+            if fixed64:      # raw integers -> doubles (the quanta are a function of the inputs: the same on every rank)
+                if not use_cuda:
+                    acc.copy_(red)
+                rt.finalize_mass_scan_device(p, xs, acc.data_ptr())
+                rt.synchronize()   # raises if the integers did not resolve the weights / a slot wrapped
+                red = acc
+            red = red.cpu()
+        per_mass, shared = sa.split_mass_scan(red.numpy(), len(xs))
+        curve = per_mass["SUM_WEIGHTS"]
+        errs = np.sqrt(per_mass["SUM_WEIGHTS_SQ"])
+        if rank == 0:
+            assert shared["N_RAYS"] == n_rays, (shared, n_rays)
+        mine = None
+    elif args.shard == "rays":
         # Every point: rank r traces ray ids [lo_r, hi_r) of the point's id block into a device accumulator, then ONE
         # reduce of the fused accumulator (image + scalars) over the ranks — the RCCL histogram reduce of config 5.
         use_cuda = not (world > 1 and torch.distributed.get_backend() != "nccl")
@@ -100,6 +136,7 @@ def main():
                     if not use_cuda:
                         acc.copy_(red)
                     rt.finalize_accumulator_device(p, acc.data_ptr())
+                    rt.synchronize()   # raises if the integers did not resolve the weights / a slot wrapped
                     red = acc if use_cuda else acc.cpu()
                 curve[i] = float(red[256 * 256 + L.ACC["SUM_WEIGHTS"]].item())
                 if rank == 0:
@@ -108,14 +145,14 @@ def main():
         mine = None
     else:
         mine = D.shard_angles(len(xs), rank, world)
-    with sa.RayTracer(full, device=local_rank) as rt:
+    with sa.RayTracer(full, device=local_rank) if mine is not None else _Null() as rt:
         if mine is None:
             pass
         elif args.mode == "angular":
             # every bin keeps its own ray-id block so that the result does not depend on the number of ranks
             vals = [sa.performAngularScan(rt, 0, 0, 1, n_rays, flags=flags, angles=[xs[i]], ray_id_offset=i * n_rays)[1][0] for i in mine]
         else:
-            vals = [sa.performAxionMassScan(rt, [xs[i]], n_rays, flags=flags, ray_id_offset=i * n_rays)[0] for i in mine]
+            vals = [sa.performAxionMassScanHostLoop(rt, [xs[i]], n_rays, flags=flags, ray_id_offset=i * n_rays)[0] for i in mine]
     if mine is not None:
         dev = torch.device("cuda", local_rank) if (world > 1 and torch.distributed.get_backend() == "nccl") else "cpu"
         curve = D.gather_scan(torch.tensor(vals, dtype=torch.float64, device=dev), mine, len(xs)).cpu().numpy()
@@ -136,15 +173,23 @@ def main():
                 print("XMM theory          :", np.round(xmm, 4).tolist())
                 print("McXtrace            :", np.round(mcx, 4).tolist())
             else:
-                f.write("m_a [eV],flux,relative flux\n")
-                for a, c, r in zip(xs, curve, rel):
-                    f.write("%.8g,%.10g,%.8f\n" % (a, c, r))
+                f.write("m_a [eV],flux,relative flux,flux error\n")
+                for i, (a, c, r) in enumerate(zip(xs, curve, rel)):
+                    f.write("%.8g,%.17g,%.8f,%s\n" % (a, c, r, "%.6g" % errs[i] if errs is not None else ""))
                 print("mass scan: m_a", np.round(xs, 5).tolist())
                 print("relative flux", np.round(rel, 4).tolist())
         print("wrote", args.out)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+class _Null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
 
 
 if __name__ == "__main__":
