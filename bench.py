@@ -51,7 +51,10 @@ WORKLOADS = {
     "babyiaxo_xmm_rot": "BabyIAXO magnet + XMM-Newton shells, telescope turned 0.1 deg, effective-area flags, chip 100 mm "
                         "(one angle bin of BASELINE configs[3])",
     "babyiaxo_xmm_small_tables": "diagnostic only: the headline workload on 400 x 300 / 200 x 200 tables that stay in every XCD's L2",
+    "babyiaxo_xmm_gas_scan32": "fused m_a scan, 32 masses 0 .. 0.02 eV: BabyIAXO + XMM-Newton shells, gas stage, full AGSS09 emission (all "
+                               "terms, tables made on the device) - every ray traced once and weighed for every mass (BASELINE configs[4])",
 }
+SCAN_MASSES = 32   # the m_a scan workload: masses linspace(0, 0.02 eV, 32) around m_gamma = 0.008235 eV
 
 
 def parse():
@@ -86,6 +89,8 @@ def make_setup(workload: str):
         full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
     elif workload == "babyiaxo_xmm_gas":
         full = sa.initFullSetup(stage=L.SK_GAS)
+    elif workload == "babyiaxo_xmm_gas_scan32":
+        full = sa.initFullSetup(stage=L.SK_GAS, emission="agss09-device")
     elif workload == "babyiaxo_xmm_rot":
         full = sa.initFullSetup()
         full.setup.chip_x_max = full.setup.chip_y_max = 100.0
@@ -234,14 +239,20 @@ def main():
     rt.set_stream(stream.cuda_stream)
     fixed64 = args.accumulation == "fixed64"
     rt.set_accumulation_mode(args.accumulation)
-    acc = torch.zeros(sa.accumulator_len(256), dtype=torch.float64, device=dev)   # 8-byte slots: doubles, or int64 in fixed64 mode
+    import numpy as np
+    scan_masses = np.linspace(0.0, 0.02, SCAN_MASSES) if args.workload == "babyiaxo_xmm_gas_scan32" else None
+    # 8-byte slots: doubles, or int64 in fixed64 mode.  Image accumulator - or, for the m_a scan, (masses + 1) rows of 8 slots
+    acc = torch.zeros(sa.accumulator_len(256) if scan_masses is None else sa.mass_scan_len(SCAN_MASSES), dtype=torch.float64, device=dev)
     seed = 299792458
 
     def step(k: int):
         # global ray ids: step-major, rank-minor => the union over ranks and steps is a contiguous id range
         offset = k * step_total + lo_in_step
         p = rt.trace_params(rays_rank, seed=seed, ray_id_offset=offset, accumulate=True, flags=flags)
-        rt.trace_histogram_device(p, acc.data_ptr())
+        if scan_masses is None:
+            rt.trace_histogram_device(p, acc.data_ptr())
+        else:
+            rt.trace_mass_scan_device(p, scan_masses, acc.data_ptr())   # one pass over the rays, every mass
 
     def barrier():
         if world > 1:
@@ -263,9 +274,13 @@ def main():
     t_red = time.perf_counter()
     D.reduce_accumulator(acc, dst=0, fixed64=fixed64)     # the single RCCL reduce of the output histograms
     if fixed64 and rank == 0:            # raw integer accumulator -> doubles, in place (part of the timed region)
-        rt.finalize_accumulator_device(rt.trace_params(1), acc.data_ptr())
+        if scan_masses is None:
+            rt.finalize_accumulator_device(rt.trace_params(1), acc.data_ptr())
+        else:
+            rt.finalize_mass_scan_device(rt.trace_params(1, flags=flags), scan_masses, acc.data_ptr())
     barrier()
     t1 = time.perf_counter()
+    rt.synchronize()                     # raises what the FIXED64 finalize found (unresolved weights, a wrapped slot)
     # MAX over ranks of the whole timed region; of the reduce (its wait for the slowest rank included) rank 0's figure
     times = torch.tensor([t1 - t0, t_red - t0], dtype=torch.float64, device=dev)
     rays_all = torch.zeros(world, dtype=torch.float64, device=dev)
@@ -283,10 +298,28 @@ def main():
     if rank == 0:
         host = acc.cpu().numpy()
         n_img = 256 * 256
-        summ = {k: float(host[n_img + i]) for k, i in L.ACC.items()}
         total_rays = float(args.steps) * step_total
-        assert summ["N_RAYS"] == total_rays, (summ["N_RAYS"], total_rays)
-        img_sum = check_image(host, n_img, summ)
+        scan_block = None
+        if scan_masses is None:
+            summ = {k: float(host[n_img + i]) for k, i in L.ACC.items()}
+            assert summ["N_RAYS"] == total_rays, (summ["N_RAYS"], total_rays)
+            img_sum = check_image(host, n_img, summ)
+        else:
+            # the scan's own checks: every ray counted once, every mass got weights, the curve peaks at the resonance
+            per_mass, shared = sa.split_mass_scan(host, SCAN_MASSES)
+            assert shared["N_RAYS"] == total_rays, (shared, total_rays)
+            assert per_mass["N_PASSED"].min() > 0 and per_mass["SUM_WEIGHTS"].min() > 0.0
+            k_res = int(np.argmin(np.abs(scan_masses - 0.008235)))
+            assert int(np.argmax(per_mass["SUM_WEIGHTS"])) == k_res, per_mass["SUM_WEIGHTS"].tolist()
+            k0 = int(np.argmax(per_mass["SUM_WEIGHTS"]))
+            summ = {"SUM_WEIGHTS": float(per_mass["SUM_WEIGHTS"][k0]), "N_PASSED": float(per_mass["N_PASSED"][k0]),
+                    "N_PASSED_TILL_WINDOW": float(shared["N_ON_DETECTOR"]), "N_SHELL_SELECTED": shared["N_SHELL_SELECTED"],
+                    "N_REACHED_TELESCOPE": shared["N_REACHED_TELESCOPE"]}
+            img_sum = summ["SUM_WEIGHTS"]
+            scan_block = {"masses": SCAN_MASSES, "m_a_ev": [round(float(m), 6) for m in scan_masses],
+                          "ray_mass_evaluations_per_s": total_rays * SCAN_MASSES / elapsed_s,
+                          "relative_flux": [round(float(x), 6) for x in per_mass["SUM_WEIGHTS"] / per_mass["SUM_WEIGHTS"].max()],
+                          "relative_error_at_resonance": float(np.sqrt(per_mass["SUM_WEIGHTS_SQ"][k0]) / per_mass["SUM_WEIGHTS"][k0])}
         value = total_rays / elapsed_s
         avg_kernel_s = kernel_ms / 1e3 / max(1, n_launch)
         out = {
@@ -316,6 +349,8 @@ def main():
                         "reached_telescope_fraction": summ["N_REACHED_TELESCOPE"] / total_rays,
                         "shell_selected_fraction": summ["N_SHELL_SELECTED"] / total_rays},
         }
+        if scan_block is not None:
+            out["mass_scan"] = scan_block
         if world == 1 and not args.profile_run:
             en = energy_block(step, stream, float(rays_rank))
             out["roofline"].update({"socket_power_w": en["socket_power_w"], "sclk_mhz": en["sclk_mhz"], "nj_per_ray": en["nj_per_ray"]})
@@ -323,6 +358,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(full, int(args.cpu_sample), seed)
             if args.workload == "babyiaxo_xmm":
                 out["other_workloads"] = [other_workload_rate(w) for w in ("cast_llnl_gold", "babyiaxo_xmm_gas", "babyiaxo_xmm_rot")]
+                out["other_workloads"].append(mass_scan_rate())
                 out["other_workloads"].append(emission_table_rate())
                 out["deterministic_accumulation"] = fixed64_block(full, value)
                 out["effective_area_rms"] = effective_area_rms()
@@ -403,6 +439,45 @@ def other_workload_rate(workload: str, n: int = 100_000_000, launches: int = 20)
     avg_s = ms / 1e3 / n_launch
     return {"workload": WORKLOADS[workload], "rays_per_s": n / avg_s, "ms_per_launch": ms / n_launch,
             "passed_fraction": s["N_PASSED"] / s["N_RAYS"], "roofline": roofline_block(workload, float(n), avg_s, n_launch, s, total)}
+
+
+def mass_scan_rate(n: int = 1_000_000_000, host_loop_points: int = 4):
+    """BASELINE configs[4] through the fused scan kernel: 32 masses on 1e9 rays of the full AGSS09 workload, against the
+    reference-shaped host loop (set the mass, re-trace, sum: timed on `host_loop_points` of the masses, same ray count each).
+    Unit: (ray, mass) evaluations per second."""
+    import numpy as np
+    import solaraxionraytracing_amd as sa
+    full, flags = make_setup("babyiaxo_xmm_gas_scan32")
+    masses = np.linspace(0.0, 0.02, SCAN_MASSES)
+    with sa.RayTracer(full) as rt:
+        rt.trace_mass_scan(masses, 50_000_000, seed=2)            # clocks up, tables in cache
+        rt.enable_kernel_timing(True)
+        t0 = time.perf_counter()
+        per_mass, shared = rt.trace_mass_scan(masses, n, seed=1)
+        wall = time.perf_counter() - t0
+        ms, n_launch = rt.kernel_timing()
+        pick = np.linspace(0, SCAN_MASSES - 1, host_loop_points).astype(int)
+        rt.trace_histogram(50_000_000, seed=2)
+        loop = []
+        for k in pick:
+            rt.set_axion_mass(float(masses[k]))
+            _, s = rt.trace_histogram(n, seed=1)
+            loop.append(s["SUM_WEIGHTS"])
+        ms_loop, n_loop = rt.kernel_timing()
+        rt.enable_kernel_timing(False)
+    assert shared["N_RAYS"] == n and n_launch == (SCAN_MASSES + 15) // 16 and n_loop == host_loop_points
+    rel = np.abs(per_mass["SUM_WEIGHTS"][pick] / np.array(loop) - 1.0).max()
+    assert rel < 1e-12, rel                                        # the same rays, the same weights
+    fused = n * SCAN_MASSES / (ms / 1e3)
+    host_loop = n / (ms_loop / 1e3 / n_loop)                       # (ray, mass) evaluations per second of one re-trace per mass
+    avg_s = ms / 1e3 / n_launch
+    summ = {"N_PASSED_TILL_WINDOW": shared["N_ON_DETECTOR"], "N_SHELL_SELECTED": shared["N_SHELL_SELECTED"]}
+    return {"workload": WORKLOADS["babyiaxo_xmm_gas_scan32"], "ray_mass_evaluations_per_s": fused, "rays_per_s": n / (ms / 1e3),
+            "ms_per_scan": ms, "launches_per_scan": n_launch, "wall_ms_per_scan": wall * 1e3,
+            "host_loop_ray_mass_evaluations_per_s": host_loop, "host_loop_ms_per_mass": ms_loop / n_loop,
+            "speedup_over_host_loop": fused / host_loop, "max_rel_diff_to_host_loop": float(rel),
+            "passed_fraction": float(per_mass["N_PASSED"].max() / n),
+            "roofline": roofline_block("babyiaxo_xmm_gas_scan32", float(n), avg_s, n_launch, summ, float(n))}
 
 
 def fixed64_block(full, f64_rate: float, n: int = 1_000_000_000, launches: int = 10):

@@ -237,7 +237,11 @@ enum {
   SART_ACC_SUM_Y_HI = 14,
   SART_ACC_SUM_R_HI = 15,
   SART_ACC_SUM_WEIGHTS_SQ_HI = 16,   /* FIXED64 raw accumulators only, like 12 .. 15 */
-  /* 17 .. 23: reserved, 0 */
+  /* FIXED64 raw accumulators only (two limbs; 0 in every f64 accumulator): sum of the weights of the passed rays that fall outside
+   * the image - with it sart_finalize_accumulator_device checks that the pixels add up to SUM_WEIGHTS exactly (a wrapped slot cannot) */
+  SART_ACC_SUM_WEIGHTS_OUTSIDE = 17,
+  SART_ACC_SUM_WEIGHTS_OUTSIDE_HI = 18,
+  /* 19 .. 23: reserved, 0 */
   SART_ACC_COUNT = 24
 };
 

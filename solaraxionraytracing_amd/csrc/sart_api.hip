@@ -28,11 +28,12 @@ namespace sart {
 void launch_trace_histogram(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
                             hipStream_t stream, int variant, bool fixed);
 void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectra, int n_radial_bins, int n_energies1, double q_w,
-                           double q_w2, double q_pos, double q_refl, uint32_t* status_dev, hipStream_t stream);
+                           double q_w2, double q_pos, double q_refl, void* check_dev, hipStream_t stream);
+size_t fixed_check_bytes();
 bool launch_trace_mass_scan(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, const ScanArgs& SC, double* rows,
                             double* shared_row, int n_blocks, hipStream_t stream, int variant, bool fixed);
 void launch_finalize_scan(const void* in, double* out, int n_masses, const double* q_w, const double* q_w2, int shared_row,
-                          uint32_t* status_dev, hipStream_t stream);
+                          void* check_dev, hipStream_t stream);
 int histogram_block_of(int variant);
 void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream, const double* uniforms_dev);
@@ -225,7 +226,7 @@ struct sart_context {
   DevBuf<double> d_fin;              // f64 image of d_acc for the blocking host-output calls in FIXED64 mode
   // What the finalize kernels found wrong with a raw FIXED64 accumulator (sart_kernels.hip: kFixedStatus*): OR-ed into d_status,
   // copied to the pinned h_status behind every finalize, read - and turned into an error - by the next synchronising call.
-  DevBuf<uint32_t> d_status;
+  DevBuf<uint8_t> d_status;          // a FixedCheck (sart_kernels.hip); its first word is the status
   uint32_t* h_status = nullptr;
   bool status_pending = false;
   // fused mass scan: per-workgroup per-mass partial sums, scratch accumulators of the blocking call
@@ -849,8 +850,8 @@ struct TimedLaunch {
 // finalize kernels found into an error (once) and clears it.
 int status_ensure(sart_context* c) {
   if (!c->d_status.p) {
-    if (int rc = c->d_status.resize(4)) return rc;
-    SART_HIP(hipMemset(c->d_status.p, 0, 4 * sizeof(uint32_t)));
+    if (int rc = c->d_status.resize(fixed_check_bytes())) return rc;
+    SART_HIP(hipMemset(c->d_status.p, 0, fixed_check_bytes()));
   }
   if (!c->h_status) {
     SART_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_status), 4 * sizeof(uint32_t), hipHostMallocDefault));
@@ -873,6 +874,8 @@ int status_take(sart_context* c) {   // the stream has been synchronised
   std::string msg = "FIXED64:";
   if (st & 1u) msg += " a slot of the accumulator is negative or >= 2^62 - it wrapped, or is about to (more bound-weight rays on one pixel "
                       "/ bin than 2^headroom_bits: use a larger headroom, or finalize and start a new accumulator earlier);";
+  if (st & 4u) msg += " the pixels / radial / energy bins of the accumulator do not add up to its SUM_WEIGHTS: a slot wrapped since the accumulator "
+                      "was zeroed (use a larger headroom, or finalize and start a new accumulator earlier);";
   if (st & 2u) msg += " the accumulated weights average below 2^12 quanta per passed ray (bound " + std::to_string(c->weight_bound) +
                       ": an outlier in a table inflated it) - choose a smaller headroom or SART_ACCUM_F64;";
   return fail(SART_ERR_INVALID_ARGUMENT, msg);

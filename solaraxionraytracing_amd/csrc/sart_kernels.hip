@@ -1291,6 +1291,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   uint32_t n_reached = 0, n_shell = 0, n_nickel = 0, n_till = 0, n_passed = 0, n_outside = 0;
   using Sum = std::conditional_t<FIXED, long long, double>;   // per-lane sums: quanta (FIXED) or f64
   Sum sum_w = 0, sum_w2 = 0, sum_x = 0, sum_y = 0, sum_r = 0;
+  long long sum_wo = 0;      // FIXED: weights of the passed rays outside the image (the finalize kernel's conservation check)
 #ifdef SART_STAGE_TIMING   // diagnostic build (make STAGE_TIMING=1): shader-clock cycles per stage, summed over waves, in scalars 12..15
   uint64_t cyc_a0 = 0, cyc_a1 = 0, cyc_b = 0, cyc_bs[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -1453,6 +1454,12 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       const uint64_t inside_m = ballot64(fx >= 0.0) & ballot64(fx < (double)nx) & ballot64(fy >= 0.0) & ballot64(fy < (double)ny);
       n_outside += (uint32_t)__popcll(out.m_passed & ~inside_m);
       const bool inside = __builtin_amdgcn_inverse_ballot_w64(inside_m);
+      if constexpr (FIXED) {
+        if (out.m_passed & ~inside_m) {   // wave-uniform: no ray of a wave is outside for images that cover the chip
+          asm volatile("; rare: passed rays outside the image");
+          sum_wo += inside ? 0ll : w_fx;
+        }
+      }
       // this wave's replica of the image; the pixel's byte offset is 32-bit (image < 2^29 pixels, checked on the host)
 #ifdef SART_DEBUG_KNOBS
       const uint32_t rep_key = (Al.flags & 0x08000000u) ? blockIdx.x : (uint32_t)wave_global;   // experiment: replica per XCD
@@ -1651,6 +1658,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   } else {
     sw = wave_sum(sum_w); sw2 = wave_sum(sum_w2); sxx = wave_sum(sum_x); syy = wave_sum(sum_y); srr = wave_sum(sum_r);
   }
+  const long long swo = FIXED ? wave_sum_i64(sum_wo) : 0ll;
   if (lane == 0) {
     Sum* r = red[wave];
     for (int k = 0; k < SART_ACC_COUNT; ++k) r[k] = 0;
@@ -1665,6 +1673,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     r[SART_ACC_N_REACHED_TELESCOPE] = (Sum)n_reached;
     r[SART_ACC_N_SHELL_SELECTED] = (Sum)n_shell;
     r[SART_ACC_N_OUTSIDE_IMAGE] = (Sum)n_outside;
+    if constexpr (FIXED) r[SART_ACC_SUM_WEIGHTS_OUTSIDE] = swo;
 #ifdef SART_STAGE_TIMING
     r[12] = (Sum)cyc_a0; r[13] = (Sum)cyc_a1; r[14] = (Sum)cyc_b;
     r[15] = (Sum)(__builtin_readcyclecounter() - cyc_start);
@@ -1707,10 +1716,10 @@ __global__ __launch_bounds__(256) void fold_scalars_kernel(double* __restrict__ 
 __device__ __forceinline__ int fixed_hi_slot(int k) {
   return k == SART_ACC_SUM_WEIGHTS ? SART_ACC_SUM_WEIGHTS_HI : k == SART_ACC_SUM_X ? SART_ACC_SUM_X_HI
          : k == SART_ACC_SUM_Y ? SART_ACC_SUM_Y_HI : k == SART_ACC_SUM_R ? SART_ACC_SUM_R_HI
-         : k == SART_ACC_SUM_WEIGHTS_SQ ? SART_ACC_SUM_WEIGHTS_SQ_HI : -1;
+         : k == SART_ACC_SUM_WEIGHTS_SQ ? SART_ACC_SUM_WEIGHTS_SQ_HI : k == SART_ACC_SUM_WEIGHTS_OUTSIDE ? SART_ACC_SUM_WEIGHTS_OUTSIDE_HI : -1;
 }
 __device__ __forceinline__ bool fixed_is_hi_slot(int k) {
-  return (k >= SART_ACC_SUM_WEIGHTS_HI && k <= SART_ACC_SUM_R_HI) || k == SART_ACC_SUM_WEIGHTS_SQ_HI;
+  return (k >= SART_ACC_SUM_WEIGHTS_HI && k <= SART_ACC_SUM_R_HI) || k == SART_ACC_SUM_WEIGHTS_SQ_HI || k == SART_ACC_SUM_WEIGHTS_OUTSIDE_HI;
 }
 __global__ __launch_bounds__(256) void fold_scalars_fixed_kernel(long long* __restrict__ scalars, const long long* __restrict__ partials,
                                                                  int n_blocks, long long n_rays) {
@@ -1815,6 +1824,40 @@ __global__ __launch_bounds__(64) void fold_scan_kernel(double* __restrict__ rows
 // sart_synchronize reads): integers that no longer mean what they should.
 constexpr uint32_t kFixedStatusWrapped = 1u;       // a slot is negative or >= 2^62: wrapped, or about to (weights and counts are >= 0)
 constexpr uint32_t kFixedStatusUnresolved = 2u;    // the accumulated weights average below 2^12 quanta per passed ray
+constexpr uint32_t kFixedStatusNotConserved = 4u;  // pixels (+ outside) / radial / energy weight bins do not add up to SUM_WEIGHTS: a slot wrapped
+// Scratch of one finalize (device memory of the context; word 0 = the status, kept; the rest zeroed before every finalize): exact
+// two-limb sums of the raw slots that must add up to SUM_WEIGHTS.  Every passed ray adds the SAME integer to SUM_WEIGHTS and to one
+// pixel (or to SUM_WEIGHTS_OUTSIDE), one radial bin and one energy bin, so the equalities hold exactly - unless a slot wrapped,
+// however often: each wrap takes 2^64 out of its sum.
+struct FixedCheck {
+  uint32_t status, _pad;
+  long long pix_lo, pix_hi, rad_lo, rad_hi, en_lo, en_hi;   // sums over the slots
+  long long want_in_lo, want_in_hi;                         // SUM_WEIGHTS - SUM_WEIGHTS_OUTSIDE
+  long long want_lo, want_hi;                               // SUM_WEIGHTS
+  long long spectra;
+};
+__device__ __forceinline__ void fixed_check_add(long long v, bool mine, long long* lo_dst, long long* hi_dst) {
+  constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
+  if (!__builtin_amdgcn_ballot_w64(mine)) return;   // wave-uniform
+  long long lo = wave_sum_i64(mine ? (v & kMask) : 0ll), hi = wave_sum_i64(mine ? (v >> kFixedLimbBits) : 0ll);
+  if ((threadIdx.x & 63) == 0) {
+    hi += lo >> kFixedLimbBits;
+    lo &= kMask;
+    atomicAdd(reinterpret_cast<unsigned long long*>(lo_dst), (unsigned long long)lo);
+    atomicAdd(reinterpret_cast<unsigned long long*>(hi_dst), (unsigned long long)hi);
+  }
+}
+__global__ void fixed_check_kernel(FixedCheck* C) {
+  constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
+  auto same = [&](long long alo, long long ahi, long long blo, long long bhi) {
+    ahi += alo >> kFixedLimbBits; alo &= kMask;
+    bhi += blo >> kFixedLimbBits; blo &= kMask;
+    return alo == blo && ahi == bhi;
+  };
+  bool ok = same(C->pix_lo, C->pix_hi, C->want_in_lo, C->want_in_hi);
+  if (C->spectra) ok = ok && same(C->rad_lo, C->rad_hi, C->want_lo, C->want_hi) && same(C->en_lo, C->en_hi, C->want_lo, C->want_hi);
+  if (!ok) atomicOr(&C->status, kFixedStatusNotConserved);
+}
 __device__ __forceinline__ void fixed_status_check_slot(long long v, uint32_t* status) {
   if (v < 0 || v >= (1ll << 62)) atomicOr(status, kFixedStatusWrapped);
 }
@@ -1834,9 +1877,21 @@ struct FinalizeArgs {
   int32_t spectra, n_radial_bins, n_energies1, _pad;
   double q_w, q_w2, q_pos, q_refl;
 };
-__global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in, double* out, FinalizeArgs F, uint32_t* status) {
+__global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in, double* out, FinalizeArgs F, FixedCheck* C) {
+  uint32_t* const status = &C->status;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long n_scalar0 = F.n_img, n_spec0 = F.n_img + SART_ACC_COUNT;
+  const long long total = n_spec0 + (F.spectra ? 2ll * F.n_radial_bins + 3ll * F.n_energies1 : 0ll);
+  {
+    // conservation sums (whole waves take part: the block size divides into waves, the last block is padded with idle threads)
+    const long long v = i < total ? in[i] : 0ll;
+    const long long j = i - n_spec0, nr = F.n_radial_bins, ne = F.n_energies1;
+    fixed_check_add(v, i < n_scalar0, &C->pix_lo, &C->pix_hi);
+    if (F.spectra) {
+      fixed_check_add(v, j >= nr && j < 2 * nr, &C->rad_lo, &C->rad_hi);
+      fixed_check_add(v, j >= 2 * nr + ne && j < 2 * nr + 2 * ne, &C->en_lo, &C->en_hi);
+    }
+  }
   if (i < n_scalar0) {
     const long long v = in[i];
     fixed_status_check_slot(v, status);
@@ -1849,6 +1904,11 @@ __global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in
     };
     const bool sq_ok = fixed_status_check_means(limbs(SART_ACC_SUM_WEIGHTS, SART_ACC_SUM_WEIGHTS_HI),
                                                 limbs(SART_ACC_SUM_WEIGHTS_SQ, SART_ACC_SUM_WEIGHTS_SQ_HI), (double)v[SART_ACC_N_PASSED], status);
+    C->want_lo = v[SART_ACC_SUM_WEIGHTS];
+    C->want_hi = v[SART_ACC_SUM_WEIGHTS_HI];
+    C->want_in_lo = v[SART_ACC_SUM_WEIGHTS] - v[SART_ACC_SUM_WEIGHTS_OUTSIDE];
+    C->want_in_hi = v[SART_ACC_SUM_WEIGHTS_HI] - v[SART_ACC_SUM_WEIGHTS_OUTSIDE_HI];
+    C->spectra = F.spectra;
     for (int k = 0; k < SART_ACC_COUNT; ++k) {
       double r;
       switch (k) {
@@ -1857,6 +1917,7 @@ __global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in
         case SART_ACC_SUM_Y: r = limbs(k, SART_ACC_SUM_Y_HI) * F.q_pos; break;
         case SART_ACC_SUM_R: r = limbs(k, SART_ACC_SUM_R_HI) * F.q_pos; break;
         case SART_ACC_SUM_WEIGHTS_SQ: r = sq_ok ? limbs(k, SART_ACC_SUM_WEIGHTS_SQ_HI) * F.q_w2 : __builtin_nan(""); break;
+        case SART_ACC_SUM_WEIGHTS_OUTSIDE: r = 0.0; break;   // (a raw-accumulator slot: the f64 layout has none)
         default: r = fixed_is_hi_slot(k) ? 0.0 : (double)v[k]; break;   // counters (the reserved slots hold 0)
       }
       out[n_scalar0 + k] = r;
@@ -1879,7 +1940,8 @@ struct FinalizeScanArgs {
   int32_t n_masses, shared_row;    // shared_row: row index of the counters relative to `in`, or -1
   double q_w[kScanMaxMasses], q_w2[kScanMaxMasses];
 };
-__global__ __launch_bounds__(64) void finalize_scan_kernel(const long long* in, double* out, FinalizeScanArgs F, uint32_t* status) {
+__global__ __launch_bounds__(64) void finalize_scan_kernel(const long long* in, double* out, FinalizeScanArgs F, FixedCheck* C) {
+  uint32_t* const status = &C->status;
   const int k = threadIdx.x;
   long long v[SART_SCAN_ROW];
   if (k < F.n_masses) {
@@ -2082,22 +2144,26 @@ bool launch_trace_mass_scan(const HotA& H, const HotB& HB, const DevBlob* blob, 
   return true;
 }
 
+size_t fixed_check_bytes() { return sizeof(FixedCheck); }
 void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectra, int n_radial_bins, int n_energies1, double q_w,
-                           double q_w2, double q_pos, double q_refl, uint32_t* status_dev, hipStream_t stream) {
+                           double q_w2, double q_pos, double q_refl, void* check_dev, hipStream_t stream) {
   FinalizeArgs F{(long long)n_img, spectra, n_radial_bins, n_energies1, 0, q_w, q_w2, q_pos, q_refl};
   const size_t total = n_img + SART_ACC_COUNT + (spectra ? 2 * (size_t)n_radial_bins + 3 * (size_t)n_energies1 : 0);
+  FixedCheck* const C = static_cast<FixedCheck*>(check_dev);
+  (void)hipMemsetAsync(reinterpret_cast<char*>(C) + 8, 0, sizeof(FixedCheck) - 8, stream);   // everything but the status word
   hipLaunchKernelGGL(finalize_fixed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                     reinterpret_cast<const long long*>(in), out, F, status_dev);
+                     reinterpret_cast<const long long*>(in), out, F, C);
+  hipLaunchKernelGGL(fixed_check_kernel, dim3(1), dim3(1), 0, stream, C);
 }
 // rows [0, n_masses) of in / out with the quanta q_w[k], q_w2[k]; shared_row >= 0: that row (relative to `in`) holds the counters
 void launch_finalize_scan(const void* in, double* out, int n_masses, const double* q_w, const double* q_w2, int shared_row,
-                          uint32_t* status_dev, hipStream_t stream) {
+                          void* check_dev, hipStream_t stream) {
   FinalizeScanArgs F;
   memset(&F, 0, sizeof F);
   F.n_masses = n_masses;
   F.shared_row = shared_row;
   for (int k = 0; k < n_masses; ++k) { F.q_w[k] = q_w[k]; F.q_w2[k] = q_w2[k]; }
-  hipLaunchKernelGGL(finalize_scan_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const long long*>(in), out, F, status_dev);
+  hipLaunchKernelGGL(finalize_scan_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const long long*>(in), out, F, static_cast<FixedCheck*>(check_dev));
 }
 void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream, const double* uniforms_dev) {

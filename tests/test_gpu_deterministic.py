@@ -332,3 +332,125 @@ def test_fixed64_says_when_the_quantum_does_not_resolve_the_weights():
     assert s_x["N_PASSED"] == s_f["N_PASSED"]
     # 47 fractional bits under a bound that is 1e8 too high: ~7e-7 of a real weight per ray, 6e-8 of the peak measured
     assert np.abs(img_x - img_f).max() <= 1e-6 * img_f.max() and s_x["SUM_WEIGHTS"] == pytest.approx(s_f["SUM_WEIGHTS"], rel=1e-8)
+
+
+# ---- round 4: the checks live on the device path, the bound follows the axion mass, slots that wrap are reported -----------------
+
+def _device_fixed_run(rt, torch, n, seed, image_n=256, flags=None, launches=1):
+    """trace_histogram_device (raw int64) + finalize in place + synchronize, as bench.py / tools/scan.py drive the library."""
+    acc = torch.zeros(sa.accumulator_len(image_n), dtype=torch.float64, device="cuda")
+    for k in range(launches):
+        p = rt.trace_params(n, seed=seed, ray_id_offset=k * n, image_n=image_n, flags=flags, accumulate=True)
+        rt.trace_histogram_device(p, acc.data_ptr())
+    rt.finalize_accumulator_device(p, acc.data_ptr())
+    rt.synchronize()
+    return acc.cpu().numpy()
+
+
+def test_fixed64_device_path_resolves_a_mass_far_off_resonance():
+    """off resonance the gas-stage conversion probability falls like 4 / (q L)^2 - at m_a = 50 m_gamma it is ~1e-7
+    of the coherent maximum the quantum used to be derived from, at the edge of what the integers resolve, and the device path
+    (trace_histogram_device + finalize, what the multi-GPU drivers use) had no check.  Now the weight bound follows the mass
+    (re-frozen when the mass changes): the far point resolves as well as the resonance does."""
+    import torch
+    full = full_setup("babyiaxo_xmm_gas")
+    m_gamma = 0.008235
+    n = 5_000_000
+    k = 256 * 256
+    with sa.RayTracer(full) as rt:
+        out = {}
+        for m in (m_gamma, 50.0 * m_gamma):
+            rt.set_axion_mass(m)
+            rt.set_accumulation_mode("f64")
+            img_f, s_f = rt.trace_histogram(n, seed=13)
+            rt.set_accumulation_mode("fixed64")
+            host = _device_fixed_run(rt, torch, n, seed=13)
+            q = rt.fixed_quanta()["weight"]
+            s_x = {key: host[k + i] for key, i in L.ACC.items()}
+            assert s_x["N_PASSED"] == s_f["N_PASSED"] and s_x["N_RAYS"] == n
+            assert s_x["SUM_WEIGHTS"] == pytest.approx(s_f["SUM_WEIGHTS"], rel=1e-9)
+            assert s_x["SUM_WEIGHTS_SQ"] == pytest.approx(s_f["SUM_WEIGHTS_SQ"], rel=1e-9)
+            assert np.abs(host[:k].reshape(256, 256) - img_f).max() <= 1e-9 * img_f.max()
+            out[m] = (s_x["SUM_WEIGHTS"], q)
+    (w_res, q_res), (w_far, q_far) = out[m_gamma], out[50.0 * m_gamma]
+    assert w_far < 1e-4 * w_res and q_far < 1e-3 * q_res       # the quantum went down with the weights
+
+
+def test_fixed64_unresolved_weights_fail_on_the_device_path_too():
+    """The outlier-in-a-table case of test_fixed64_says_when_the_quantum_does_not_resolve_the_weights, through
+    trace_histogram_device + finalize: the finalize kernel sets the status word, the next synchronize raises (once)."""
+    import copy
+    import torch
+    base = full_setup("babyiaxo_xmm")
+    full = copy.copy(base)
+    refl = copy.copy(base.reflectivity)
+    refl.data = base.reflectivity.data.copy()
+    refl.data[0, 0, :] = 1e4
+    full.reflectivity = refl
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode("fixed64")
+        with pytest.raises(L.SartError) as e:
+            _device_fixed_run(rt, torch, 2_000_000, seed=3)
+        assert e.value.code == -1 and "quanta" in str(e.value)
+        rt.synchronize()                                         # reported once
+        rt.set_accumulation_mode("fixed64", headroom_bits=16)
+        host = _device_fixed_run(rt, torch, 2_000_000, seed=3)   # resolves with 47 fractional bits ...
+        assert host[256 * 256 + L.ACC["SUM_WEIGHTS"]] > 0
+        assert np.isnan(host[256 * 256 + L.ACC["SUM_WEIGHTS_SQ"]])   # ... but not the squares (1e-16 of their bound): NaN, not a made-up number
+
+
+def test_fixed64_reports_a_slot_that_wrapped():
+    """pixels, spectra bins and sums are int64 slots; at headroom_bits = 16 a pixel holds 2^16 bound-weight
+    rays.  A one-pixel image takes every passed ray and wraps - several times over - within 2e8 rays.  The finalize kernel
+    checks every slot's sign / size AND that the pixels add up to SUM_WEIGHTS exactly (each wrap takes 2^64 out of that sum, so
+    the check does not depend on where the wrapped value lands): the next synchronising call fails instead of handing out a
+    wrapped number."""
+    import torch
+    full = full_setup("babyiaxo_xmm")
+    n = 40_000_000
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode("fixed64", headroom_bits=16)
+        host = _device_fixed_run(rt, torch, 50_000, seed=2, image_n=1)           # ~1e4 passed rays: fits
+        assert host[0] == pytest.approx(host[1 + L.ACC["SUM_WEIGHTS"]], rel=1e-12) and host[0] > 0
+        with pytest.raises(L.SartError) as e:
+            _device_fixed_run(rt, torch, n, seed=2, image_n=1, launches=5)
+        assert e.value.code == -1 and "wrapped" in str(e.value)
+        with pytest.raises(L.SartError) as e:                     # the blocking call reports it, too
+            for k in range(5):
+                rt.trace_histogram(n, seed=2, ray_id_offset=k * n, image_n=1, accumulate=(k > 0))
+        assert "wrapped" in str(e.value)
+        # spectra bins: one radial bin for everything wraps the same way, the image (256 x 256) does not
+        with pytest.raises(L.SartError) as e:
+            for k in range(5):
+                rt.trace_spectra(n, seed=2, ray_id_offset=k * n, n_radial_bins=1, radial_max=10.0, accumulate=(k > 0))
+        assert "wrapped" in str(e.value)
+        rt.set_accumulation_mode("fixed64", headroom_bits=40)
+        host = _device_fixed_run(rt, torch, n, seed=2, image_n=1, launches=5)
+        assert host[0] == pytest.approx(host[1 + L.ACC["SUM_WEIGHTS"]], rel=1e-9)
+
+
+def test_setting_the_same_accumulation_mode_again_keeps_the_frozen_quanta():
+    """sart_set_accumulation_mode used to clear the frozen quanta even when nothing changed; an accumulate = 1
+    launch behind it could then re-freeze other quanta into an accumulator that already held data."""
+    full = full_setup("babyiaxo_xmm")
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode("fixed64")
+        _, s1 = rt.trace_histogram(1_000_000, seed=4)
+        q = rt.fixed_quanta()
+        rt.set_accumulation_mode("fixed64")                      # no change
+        assert rt.fixed_quanta() == q
+        # an accumulating launch whose weights would ask for another quantum still meets the frozen one: refused, not re-frozen
+        with pytest.raises(L.SartError):
+            rt.trace_histogram(1_000_000, seed=4, ray_id_offset=1_000_000, accumulate=True, flags=L.CF_IGNORE_CONV_PROB)
+        _, s2 = rt.trace_histogram(1_000_000, seed=4, ray_id_offset=1_000_000, accumulate=True)
+        assert s2["N_RAYS"] == 2_000_000 and rt.fixed_quanta() == q
+
+
+@pytest.mark.parametrize("name", ["babyiaxo_xmm", "cast_llnl_gold", "babyiaxo_xmm_gas", "babyiaxo_xmm_xray"])
+def test_fixed64_sum_of_squared_weights_has_a_high_limb(name):
+    """SUM_WEIGHTS_SQ was one int64 with a quantum of 2^-19 of the squared bound.  It now has a high limb and a
+    quantum of 2^-39: it agrees with the f64 mode to 1e-9 on every workload."""
+    f = run(name, "f64")
+    x = run(name, "fixed64")
+    assert x[1]["SUM_WEIGHTS_SQ"] == pytest.approx(f[1]["SUM_WEIGHTS_SQ"], rel=1e-9)
+    assert x[3]["weight_sq"] == x[3]["weight"] ** 2 * 2.0 ** (2 * (63 - 27) - 39)     # 2^(2e - 39) beside 2^(e - 63 + 27)
