@@ -427,7 +427,7 @@ int sart_finalize_accumulator_device(sart_context* ctx, const sart_trace_params_
  *   row n_masses       mass-independent counters SART_SCAN_N_* below
  * Only params->n_rays, seed, ray_id_offset, flags and accumulate are read (no image is accumulated).
  * SART_ERR_INVALID_ARGUMENT unless the setup's stage is SART_SK_GAS (the vacuum probability :363-365 has no m_a in it).
- * Masses are processed in groups of 16 per kernel launch (the per-mass accumulators of a workgroup live in LDS).
+ * Masses are processed in groups of 32 per kernel launch (the per-mass accumulators of a workgroup live in LDS).
  * FIXED64: the quanta of mass k are a function of (setup, tables, flags, headroom, masses_ev[k]) alone - every rank of a
  * multi-GPU job computes the same ones; a reduce is an int64 sum of the raw scan accumulators;
  * sart_finalize_mass_scan_device (same masses) converts to doubles.

@@ -232,10 +232,11 @@ struct TraceArgs {
   double fx_scale_w, fx_scale_w2;
 };
 // Fused axion-mass scan (include/sart.h: sart_trace_mass_scan): phase B evaluates the gas-stage conversion probability of every
-// surviving ray for the masses of this table and accumulates per mass.  One launch takes up to kScanMaxMasses masses: their per-lane
-// accumulators ([mass][sum of w, sum of w^2][64 lanes] f64 or int64 = 1 KB per mass) live in the 16 KB of LDS that the image tile uses
-// in the histogram kernels (a scan accumulates no image).
-constexpr int kScanMaxMasses = 16;
+// surviving ray for the masses of this table and accumulates per mass.  One launch takes up to kScanMaxMasses masses: their
+// accumulators ([mass][sum of w, sum of w^2][kScanLanes] f64 or int64 = 512 B per mass; lanes l and l + 32 of a wave share a cell) live
+// in the 16 KB of LDS that the image tile uses in the histogram kernels (a scan accumulates no image).
+constexpr int kScanMaxMasses = 32;
+constexpr int kScanLanes = 32;
 struct ScanMass {
   double dm2_abs;                 // |m_gamma^2 - m_a^2| in eV^2 (host: the same IEEE subtraction the single-mass kernel performs)
   double fx_scale_w, fx_scale_w2; // SART_ACCUM_FIXED64: 1 / quantum of the weights and of the squared weights of THIS mass

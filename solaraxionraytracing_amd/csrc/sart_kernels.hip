@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   QueueLds<BLOCK / 64>& Q = lds.Q;
   static_assert(!PATHC || (FAST && !ROT && GAS >= 0), "the constant-path form belongs to the unrotated specialisations");
   static_assert(!SCAN || GAS != 0, "a mass scan needs the gas stage");
-  static_assert(!SCAN || kScanMaxMasses * 2 * 64 <= (BLOCK / 64) * kQueue, "the scan accumulators live in the image tile's 128 doubles per wave");
+  static_assert(!SCAN || kScanMaxMasses * 2 * kScanLanes <= (BLOCK / 64) * kQueue, "the scan accumulators live in the image tile's 128 doubles per wave");
   __shared__ uint32_t scan_zero[kScanMaxMasses];   // SCAN: rays whose weight vanishes for one mass only (conversion probability exactly 0)
   static_assert(kImageTileMax * kImageTileMax <= (BLOCK / 64) * kQueue,
                 "the LDS image tile (host: kImageTileMax) lives in 128 doubles per wave of this workgroup's rings");
@@ -1399,15 +1399,17 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
             if (lane == 0) atomicAdd(&scan_zero[k], (uint32_t)__popcll(out.m_passed & ~nz));
           }
           if (__builtin_amdgcn_inverse_ballot_w64(nz)) {
-            const uint32_t t = ((uint32_t)k << 7) + (uint32_t)lane;   // cell [k][0][lane]; [k][1][lane] is 64 further on
+            // cell [k][0][lane % 32]; [k][1][.] is kScanLanes further on (lanes l and l + 32 add to the same cell: the LDS unit
+            // takes a wave's 64-bit atomics in groups of lanes, the two never meet in one group)
+            const uint32_t t = (uint32_t)k * (2u * kScanLanes) + ((uint32_t)lane & (kScanLanes - 1u));
             if constexpr (FIXED) {
               __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell(t)), (unsigned long long)to_fixed(w, M.fx_scale_w),
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell(t + 64u)), (unsigned long long)to_fixed(w * w, M.fx_scale_w2),
+              __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell(t + kScanLanes)), (unsigned long long)to_fixed(w * w, M.fx_scale_w2),
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
               __hip_atomic_fetch_add(tile_cell(t), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_fetch_add(tile_cell(t + 64u), w * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_add(tile_cell(t + kScanLanes), w * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
         }
@@ -1610,22 +1612,21 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
 
   SART_STAGE_MARK("EPILOGUE");
   if constexpr (SCAN) {
-    // per-mass sums of this workgroup: wave k adds up the 64 per-lane accumulators of mass k (fixed order: the result does not
-    // depend on which wave added what when) -> one plain store per mass and quantity, folded by fold_scan_kernel
+    // per-mass sums of this workgroup: a wave adds up the accumulator cells of a mass (a wave-wide sum over a cell per lane: the
+    // order is fixed) -> one plain store per mass and quantity, folded by fold_scan_kernel.  One wave-wide read covers [k][0][.]
+    // and [k][1][.]: lanes 0 .. 31 hold the sum-of-w cells, lanes 32 .. 63 the sum-of-w^2 cells.
     __syncthreads();   // every wave of the workgroup has left the loop
-    if (wave < SCarg.n_masses) {
+    static_assert(2 * kScanLanes == 64, "one cell per lane");
+    for (int k = wave; k < SCarg.n_masses; k += BLOCK / 64) {
       using Sum = std::conditional_t<FIXED, long long, double>;
-      Sum* const dst = reinterpret_cast<Sum*>(SCarg.partials) + ((size_t)blockIdx.x * kScanMaxMasses + (size_t)wave) * kScanPartialSlots;
-      const uint32_t t = ((uint32_t)wave << 7) + (uint32_t)lane;
-      Sum a, b;
-      if constexpr (FIXED) {
-        a = wave_sum_i64(__double_as_longlong(*tile_cell(t)));
-        b = wave_sum_i64(__double_as_longlong(*tile_cell(t + 64u)));
-      } else {
-        a = wave_sum(*tile_cell(t));
-        b = wave_sum(*tile_cell(t + 64u));
-      }
-      if (lane == 0) { dst[0] = a; dst[1] = b; dst[2] = (Sum)scan_zero[wave]; dst[3] = 0; }
+      Sum* const dst = reinterpret_cast<Sum*>(SCarg.partials) + ((size_t)blockIdx.x * kScanMaxMasses + (size_t)k) * kScanPartialSlots;
+      const double cell = *tile_cell((uint32_t)k * 64u + (uint32_t)lane);
+      Sum v;
+      if constexpr (FIXED) v = __double_as_longlong(cell); else v = cell;
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);   // within each half of the wave
+      if (lane == 0) { dst[0] = v; dst[2] = (Sum)scan_zero[k]; dst[3] = 0; }
+      if (lane == 32) dst[1] = v;
     }
   }
   // flush of the LDS image tile: one global atomic per non-empty tile pixel and workgroup
@@ -1771,7 +1772,7 @@ __global__ __launch_bounds__(256) void fold_replicas_kernel(T* __restrict__ acc,
 // group of masses of a scan only, else nullptr): the mass-independent counters.  Summation order = workgroup order: fixed
 // for a given grid.  FIXED: integers, the two sums in two limbs like fold_scalars_fixed_kernel.
 template <bool FIXED>
-__global__ __launch_bounds__(64) void fold_scan_kernel(double* __restrict__ rows_, double* __restrict__ shared_row_, const double* __restrict__ scal_partials_,
+__global__ __launch_bounds__(128) void fold_scan_kernel(double* __restrict__ rows_, double* __restrict__ shared_row_, const double* __restrict__ scal_partials_,
                                                        const double* __restrict__ scan_partials_, int n_blocks, int n_masses, double n_rays) {
   using Sum = std::conditional_t<FIXED, long long, double>;
   constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
@@ -1779,7 +1780,7 @@ __global__ __launch_bounds__(64) void fold_scan_kernel(double* __restrict__ rows
   Sum* const shared_row = reinterpret_cast<Sum*>(shared_row_);
   const Sum* const scal = reinterpret_cast<const Sum*>(scal_partials_);
   const Sum* const scan = reinterpret_cast<const Sum*>(scan_partials_);
-  static_assert(kScanMaxMasses * kScanPartialSlots == 64, "one thread per (mass, partial slot)");
+  static_assert(kScanMaxMasses * kScanPartialSlots == 128, "one thread per (mass, partial slot)");
   const int k = threadIdx.x >> 2, j = threadIdx.x & 3;
   if (k < n_masses && j < 3) {
     Sum* const row = rows + (size_t)k * SART_SCAN_ROW;
@@ -1809,8 +1810,8 @@ __global__ __launch_bounds__(64) void fold_scan_kernel(double* __restrict__ rows
       row[j == 0 ? SART_SCAN_SUM_WEIGHTS : j == 1 ? SART_SCAN_SUM_WEIGHTS_SQ : SART_SCAN_N_PASSED] += t;
     }
   }
-  if (shared_row && threadIdx.x >= 60) {   // threads (15, 0..3): the four counters that come from the workgroup partials
-    const int c = threadIdx.x - 60;
+  if (shared_row && threadIdx.x >= 124) {   // threads (31, 0..3): the four counters that come from the workgroup partials
+    const int c = threadIdx.x - 124;
     const int src = c == 0 ? SART_ACC_N_REACHED_TELESCOPE : c == 1 ? SART_ACC_N_SHELL_SELECTED : c == 2 ? SART_ACC_N_HIT_NICKEL : SART_ACC_N_PASSED;
     const int dst = c == 0 ? SART_SCAN_N_REACHED_TELESCOPE : c == 1 ? SART_SCAN_N_SHELL_SELECTED : c == 2 ? SART_SCAN_N_HIT_NICKEL : SART_SCAN_N_ON_DETECTOR;
     Sum t = 0;
@@ -2138,9 +2139,9 @@ bool launch_trace_mass_scan(const HotA& H, const HotB& HB, const DevBlob* blob, 
     default: return false;
   }
   if (fixed)
-    hipLaunchKernelGGL(fold_scan_kernel<true>, dim3(1), dim3(64), 0, stream, rows, shared_row, A.partials, SC.partials, n_blocks, SC.n_masses, (double)A.n_rays);
+    hipLaunchKernelGGL(fold_scan_kernel<true>, dim3(1), dim3(128), 0, stream, rows, shared_row, A.partials, SC.partials, n_blocks, SC.n_masses, (double)A.n_rays);
   else
-    hipLaunchKernelGGL(fold_scan_kernel<false>, dim3(1), dim3(64), 0, stream, rows, shared_row, A.partials, SC.partials, n_blocks, SC.n_masses, (double)A.n_rays);
+    hipLaunchKernelGGL(fold_scan_kernel<false>, dim3(1), dim3(128), 0, stream, rows, shared_row, A.partials, SC.partials, n_blocks, SC.n_masses, (double)A.n_rays);
   return true;
 }
 

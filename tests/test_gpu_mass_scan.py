@@ -24,7 +24,7 @@ N_IMG = 256 * 256
 
 
 def masses(k):
-    """k masses around the resonance, including it, zero and far-off points (two groups of 16 when k > 16)."""
+    """k masses around the resonance, including it, zero and far-off points (two groups of masses when k > 32)."""
     m = np.concatenate([[0.0, M_GAMMA], np.linspace(0.002, 0.02, max(0, k - 3)), [0.05]])
     return np.ascontiguousarray(m[:k])
 
@@ -94,7 +94,7 @@ def variant_setup(name):
 def test_fixed64_scan_equals_single_mass_launches_bit_for_bit(name):
     import torch
     full, knobs, flags = variant_setup(name)
-    ms = masses(20)                      # two groups of masses: 16 + 4
+    ms = masses(37)                      # two groups of masses: 32 + 5
     n, seed = 3_000_000, 17
     with env(**knobs):
         with sa.RayTracer(full) as rt:
@@ -139,7 +139,7 @@ def test_fixed64_scan_finalize_equals_finalized_single_launches():
 @pytest.mark.parametrize("name", ["gas_pathc", "gas_ring_path", "generic_rotated"])
 def test_f64_scan_equals_single_mass_launches(name):
     full, knobs, flags = variant_setup(name)
-    ms = masses(18)
+    ms = masses(35)
     n, seed = 3_000_000, 5
     with env(**knobs):
         with sa.RayTracer(full) as rt:
@@ -178,24 +178,24 @@ def test_scan_matches_the_oracle_per_mass(tables):
 
 def test_scan_on_full_size_agss09_tables_matches_the_oracle_and_the_host_loop():
     """BASELINE configs[4] at its table sizes: full AGSS09 emission (all terms, made on the device), 1968 x 1500 CDFs, 1000 x 1000
-    reflectivity; 32 masses (two groups), the scan through the C++ host driver."""
+    reflectivity; 40 masses (two groups: 32 + 8), the scan through the C++ host driver."""
     from oracle.oracle import Oracle
     full = sa.initFullSetup(stage=L.SK_GAS, emission="agss09-device")
-    ms = np.linspace(0.0, 0.02, 32)
+    ms = np.linspace(0.0, 0.02, 40)
     n, seed = 4_000_000, 11
     with sa.RayTracer(full) as rt:
         flux, err, n_pass = sa.performAxionMassScan(rt, ms, n, seed=seed, errors=True)
-        loop = sa.performAxionMassScanHostLoop(rt, ms[[0, 13, 31]], n, seed=seed)
+        loop = sa.performAxionMassScanHostLoop(rt, ms[[0, 13, 39]], n, seed=seed)
         full.fetch_solar_tables(rt)
-    assert np.abs(flux[[0, 13, 31]] / loop - 1.0).max() < 1e-12
+    assert np.abs(flux[[0, 13, 39]] / loop - 1.0).max() < 1e-12
     assert np.all(err > 0) and np.all(err < 0.05 * flux) and n_pass.min() > 1e5
     k_res = int(np.argmin(np.abs(ms - M_GAMMA)))
     assert int(np.argmax(flux)) == k_res                         # the resonance m_a = m_gamma
     o = Oracle(full, "ld")
     n_o = 400_000
     with sa.RayTracer(full) as rt:
-        per_mass, _ = rt.trace_mass_scan(ms[[0, k_res, 31]], n_o, seed=seed)
-    for j, k in enumerate((0, k_res, 31)):
+        per_mass, _ = rt.trace_mass_scan(ms[[0, k_res, 39]], n_o, seed=seed)
+    for j, k in enumerate((0, k_res, 39)):
         s = full.setup.copy()
         s.m_axion = float(ms[k])
         want = o.trace_histogram(n_o, seed=seed, setup=s)[1]["SUM_WEIGHTS"]
