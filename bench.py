@@ -72,6 +72,9 @@ def parse():
                     help="f64 (default): f64 atomics, as the reference adds on the CPU; fixed64: deterministic integer accumulation "
                          "(SART_ACCUM_FIXED64), int64 reduce - image and sums bitwise independent of the number of GPUs")
     ap.add_argument("--profile-run", action="store_true", help="no CPU baseline / side workloads (run under rocprofv3)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="first contact with a multi-GPU node: only bring the process group up (RCCL), reduce one 512 KB buffer "
+                         "once and print {world_size, backend, reduce_ms}; no tables, no rays")
     return ap.parse_args()
 
 
@@ -207,9 +210,16 @@ def main():
     # waits for them.  Either way a mismatch, or fewer devices than ranks, ends with exit code 2 BEFORE anything touches a
     # GPU - a line whose n_gpus is not what was asked for is never printed.
     # SART_BENCH_BACKEND=gloo + SART_BENCH_DEVICE=0: rehearsal of the multi-rank path on a one-GPU box.
-    rc = D.launch_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    gloo_preflight = args.preflight and os.environ.get("SART_BENCH_BACKEND") == "gloo"   # touches no card: runs anywhere
+    rc = D.launch_ranks_if_needed(args.gpus, os.path.abspath(__file__), sys.argv[1:], need_devices=not gloo_preflight)
     if rc is not None:
         raise SystemExit(rc)
+    if args.preflight:
+        res = D.preflight(os.environ.get("SART_BENCH_BACKEND"))
+        assert res["world_size"] == args.gpus, (res, args.gpus)
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps(res))
+        raise SystemExit(0 if res["preflight"] == "ok" else 4)
 
     import torch
     import torch.distributed as dist
@@ -367,6 +377,7 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    D.report_stage("done")
 
 
 def energy_block(step, stream, rays_per_step: float, seconds: float = 5.0):

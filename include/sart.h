@@ -275,6 +275,8 @@ int sart_create(int device_ordinal, sart_context** out);
 int sart_destroy(sart_context* ctx);
 /* Use an existing HIP stream (hipStream_t cast to void*) for all launches; NULL = the context's own stream. */
 int sart_set_stream(sart_context* ctx, void* hip_stream);
+/* Waits for the context's stream.  Also the place where problems found asynchronously surface: SART_ERR_INVALID_ARGUMENT if a
+ * FIXED64 finalize queued before it found unresolved weights or a wrapped slot ("accumulation mode" below; reported once). */
 int sart_synchronize(sart_context* ctx);
 
 /* ---- inputs (the captures of traceAxionWrapper, raytracer.nim:2223-2232) -- */
@@ -367,24 +369,38 @@ int sart_trace_histogram_spectra(sart_context* ctx, const sart_trace_params_t* p
  * itself); sart_finalize_accumulator_device converts a raw buffer to the f64 layout documented above.
  *   quanta   weights (image pixels, SUM_WEIGHTS, radial / energy weight spectra): q_w = 2^e with
  *            w_bound < 2^(e + 63 - headroom_bits), w_bound = the host's scale of the largest weight of one ray for the setup,
- *            tables and flags of the launch that fixes the quantum (exposure x conversion probability over lengthB x max
- *            reflectivity^2 x max window transmission x max gas absorption).  headroom_bits (default 27) = log2 of the
- *            number of w_bound-weight rays a slot can take before it wraps: a pixel holds 2^27 = 1.3e8 of them (a 256 x 256
- *            BabyIAXO image reaches that after ~5e12 traced rays); the resolution of one ray's weight is 2^-36 w_bound, and
- *            a pixel that n rays hit carries a rounding error of ~q_w sqrt(n / 12): an image of 2e7 rays agrees with the f64
- *            image to < 1e-12 of its largest pixel, larger images better.  SUM_WEIGHTS_SQ: q = w_bound^2 2^-19 (a 44-bit
- *            ray count).  SUM_X / SUM_Y / SUM_R: 2^-32 mm.  energy_reflect spectrum: 2^-40.
+ *            tables and flags of the launch that fixes the quantum (exposure x conversion probability x max reflectivity^2 x
+ *            max window transmission x max gas absorption; the conversion probability over lengthB in the vacuum stage, and
+ *            in the gas stage its bound for the context's axion mass, (g B / 2)^2 min(L^2, 4 / (q^2 + Gamma^2 / 4)) maximised
+ *            over the energy table - it follows the mass, so a far-off-resonance point resolves as well as the resonance).
+ *            headroom_bits (default 27) = log2 of the number of w_bound-weight rays a slot can take before it wraps: a pixel
+ *            holds 2^27 = 1.3e8 of them (a 256 x 256 BabyIAXO image reaches that after ~5e12 traced rays); the resolution of one
+ *            ray's weight is 2^-36 w_bound, and a pixel that n rays hit carries a rounding error of ~q_w sqrt(n / 12): an
+ *            image of 2e7 rays agrees with the f64 image to < 1e-12 of its largest pixel, larger images better.
+ *            SUM_WEIGHTS_SQ: q = 2^(2 e' - 39) with w_bound < 2^e' (two limbs; the quantum leaves room for the rays of one
+ *            workgroup of one launch).  SUM_X / SUM_Y / SUM_R: 2^-32 mm.  energy_reflect spectrum: 2^-40.
  *            The bound sees table maxima (for the X-ray test source: the values at its one energy), not what the rays
- *            actually meet: every ray's rounding error is <= q_w / 2 in absolute terms whatever its weight, and the blocking
- *            host-output calls fail with SART_ERR_INVALID_ARGUMENT when the accumulated weights average below 2^12 quanta per
- *            ray (an outlier in a table inflated the bound): use a smaller headroom then.
- *   limbs    SUM_WEIGHTS, SUM_X, SUM_Y, SUM_R receive every passed ray of every launch: value = (hi * 2^40 + lo) * q with
- *            lo in slot SART_ACC_SUM_*, hi in slot SART_ACC_SUM_*_HI (after a launch 0 <= lo < 2^40; limb-wise int64 sums
- *            over up to 2^22 ranks stay exact).
- *   freezing the quanta are computed by the first histogram launch after sart_set_accumulation_mode (or by any launch with
- *            accumulate == 0) and kept for the following accumulate == 1 launches of the context, so that launches that add
- *            into one accumulator share them; a launch whose weight bound no longer fits fails with
- *            SART_ERR_INVALID_ARGUMENT.  Contexts with equal inputs compute equal quanta (ranks of a multi-GPU job).
+ *            actually meet: every ray's rounding error is <= q_w / 2 in absolute terms whatever its weight.
+ *   limbs    SUM_WEIGHTS, SUM_X, SUM_Y, SUM_R, SUM_WEIGHTS_SQ (and SUM_WEIGHTS_OUTSIDE) receive every passed ray of every
+ *            launch: value = (hi * 2^40 + lo) * q with lo in slot SART_ACC_SUM_*, hi in slot SART_ACC_SUM_*_HI (after a launch
+ *            0 <= lo < 2^40; limb-wise int64 sums over up to 2^22 ranks stay exact).
+ *   freezing the quanta are computed by the first histogram launch after a change of the accumulation mode (or by any launch
+ *            with accumulate == 0) and kept for the following accumulate == 1 launches of the context, so that launches that
+ *            add into one accumulator share them; a launch whose weight bound no longer fits fails with
+ *            SART_ERR_INVALID_ARGUMENT.  In the gas stage sart_set_axion_mass with another mass releases them (the bound
+ *            follows the mass: a new mass starts a new accumulator).  Contexts with equal inputs compute equal quanta (ranks
+ *            of a multi-GPU job).
+ *   checks   integers can stop meaning what they should in two ways, and neither passes silently.  The finalize kernels
+ *            (sart_finalize_accumulator_device, sart_finalize_mass_scan_device, and the blocking host-output calls, which
+ *            finalize internally) examine the raw accumulator and record what they find in a status word of the context;
+ *            the next sart_synchronize - and every blocking host-output call - returns SART_ERR_INVALID_ARGUMENT for it:
+ *              unresolved  the accumulated weights average below 2^12 quanta per passed ray (an outlier in a table inflated
+ *                          the bound): use a smaller headroom.  Squared weights that average below 2^6 quanta are not an
+ *                          error - SUM_WEIGHTS_SQ (an error estimate; nothing else depends on it) then reads NaN.
+ *              wrapped     a slot is negative or >= 2^62, or the pixels (plus SUM_WEIGHTS_OUTSIDE), the radial weight bins or
+ *                          the energy weight bins do not add up to SUM_WEIGHTS - every passed ray adds the same integer to
+ *                          each of them, so the sums agree exactly unless a slot wrapped, however often (each wrap takes 2^64
+ *                          out of its sum): use a larger headroom, or finalize and start a new accumulator earlier.
  * The mode applies to sart_trace_histogram_device (raw accumulators) and to the blocking host-output calls, which
  * finalize internally and keep returning doubles.
  */
@@ -395,7 +411,8 @@ typedef struct sart_fixed_quanta_t {
   double position;      /* SUM_X, SUM_Y, SUM_R (2^-32 mm) */
   double reflect;       /* energy_reflect (2^-40) */
 } sart_fixed_quanta_t;
-/* headroom_bits: 0 = default (27); otherwise 16 .. 44.  Waits for the stream; resets the frozen quanta. */
+/* headroom_bits: 0 = default (27); otherwise 16 .. 44.  Waits for the stream; a CHANGE of mode or headroom releases the frozen
+ * quanta (setting what is already set changes nothing: an accumulator may hold data in them). */
 int sart_set_accumulation_mode(sart_context* ctx, int mode, int headroom_bits);
 int sart_get_accumulation_mode(sart_context* ctx, int* mode_out);
 /* The frozen quanta (SART_ERR_NOT_READY before the first FIXED64 launch). */
@@ -403,7 +420,8 @@ int sart_get_fixed_quanta(sart_context* ctx, sart_fixed_quanta_t* out);
 /*
  * Raw FIXED64 accumulator -> the f64 accumulator layout (image, scalars [the *_HI slots read 0], spectra if
  * params->spectra), with the context's frozen quanta.  Both pointers are DEVICE memory of the accumulator's length;
- * out_f64_device may equal acc_fixed_device (in place).  Asynchronous on the context's stream.
+ * out_f64_device may equal acc_fixed_device (in place).  Asynchronous on the context's stream; what the conversion finds
+ * wrong with the integers ("checks" above) is returned by the next sart_synchronize.
  */
 int sart_finalize_accumulator_device(sart_context* ctx, const sart_trace_params_t* params, const void* acc_fixed_device,
                                      double* out_f64_device);

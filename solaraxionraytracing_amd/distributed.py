@@ -56,9 +56,11 @@ class LaunchRefused(SystemExit):
 
 
 def visible_devices() -> int:
-    """Number of HIP devices this process could use, WITHOUT initialising one (torch.cuda.device_count() only asks the
-    driver; torch.cuda.is_available() / any tensor on a device would create a context, after which spawning or re-executing
-    is no longer safe on the GPU boxes)."""
+    """Number of HIP devices this process could use.  torch.cuda.device_count() does not create a HIP context on this image
+    (torch.cuda.is_available() or any tensor on a device would), but on ROCm it may still call hipGetDeviceCount and so load
+    the HSA runtime in this process.  That is harmless for how the result is used here - the launcher below only ever starts
+    fresh CHILD processes after it (subprocess.Popen) and never re-executes itself; a process that has asked must not
+    os.exec* another program."""
     import torch
     try:
         return int(torch.cuda.device_count())
@@ -91,7 +93,51 @@ def free_port() -> int:
         return int(s.getsockname()[1])
 
 
-def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
+START_TIMEOUT_S = 600         # from the launch to the rendezvous of every rank: interpreter + `import torch` on a fresh box (SART_START_TIMEOUT)
+RDZV_TIMEOUT_S = 120          # torch.distributed rendezvous + communicator bring-up of one rank (SART_RDZV_TIMEOUT overrides)
+LAUNCH_TIMEOUT_S = 1500       # wall-clock limit of a self-launched multi-rank run (SART_LAUNCH_TIMEOUT overrides)
+STAGES = ("started", "rendezvous", "up", "done")
+
+
+def report_stage(stage: str) -> None:
+    """Tells the launcher how far this rank has come (one small file per rank in SART_RANK_STATUS_DIR; no-op without it):
+    when a run hangs, the launcher names the rank that never reported and the stage the others reached."""
+    d = os.environ.get("SART_RANK_STATUS_DIR")
+    if not d:
+        return
+    try:
+        with open(os.path.join(d, "rank%s" % os.environ.get("RANK", "0")), "w") as f:
+            f.write(stage)
+    except OSError:
+        pass
+
+
+def _rank_stages(status_dir: str, n_ranks: int) -> list:
+    out = []
+    for r in range(n_ranks):
+        try:
+            out.append(open(os.path.join(status_dir, "rank%d" % r)).read().strip() or "nothing")
+        except OSError:
+            out.append("nothing")
+    return out
+
+
+def _forward(pipe, prefix: str, sink) -> None:
+    """Copies a child's output line by line with the rank in front (eight ranks' stderr interleaved untagged is unreadable)."""
+    try:
+        for line in iter(pipe.readline, b""):
+            sink.write(prefix.encode() + line)
+            sink.flush()
+    except (OSError, ValueError):
+        pass
+    finally:
+        try:
+            pipe.close()
+        except OSError:
+            pass
+
+
+def launch_ranks_if_needed(n_ranks: int, script: str, argv: list, need_devices: bool = True) -> int | None:
     """Makes ``<script> --gpus N`` mean N ranks whoever starts it.
 
     * Under a launcher (WORLD_SIZE set: torchrun, the driver's command line): this process is one rank; returns None after
@@ -100,11 +146,18 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
     * Stand-alone with ``n_ranks`` == 1: returns None (single process, no process group).
     * Stand-alone with ``n_ranks`` > 1: starts ``n_ranks`` fresh copies of ``script`` (children of this process, one rank
       each, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment) BEFORE any HIP call
-      here, waits for them and returns the exit code to leave with (rank 0's stdout is this process's stdout).  A rank that
-      fails ends the others (exact PIDs).
+      here, waits for them and returns the exit code to leave with.  Rank 0's stdout is this process's stdout; everything else
+      the ranks print (stderr of all, stdout of ranks > 0) arrives on this process's stderr with "[rank r] " in front.  A rank
+      that fails ends the others (exact PIDs).  Clocks guard a first contact with an 8-GPU node: every rank must reach the
+      rendezvous within SART_START_TIMEOUT (default 600 s: the first `import torch` on a fresh box takes minutes), every rank
+      must report its process group up (report_stage) within SART_RDZV_TIMEOUT + 60 s of the first rank reaching the
+      rendezvous, and the whole run must end within SART_LAUNCH_TIMEOUT (default 1500 s); past any of them the ranks are
+      ended and the exit code is 3, with one line per rank saying what it last reported - a hang becomes a diagnosable
+      failure instead of the driver's own limit.
 
     Environment: SART_BENCH_BACKEND (nccl = RCCL by default, gloo for rehearsals), SART_BENCH_DEVICE (all ranks share that
-    device: rehearsal of the multi-rank path on a one-GPU box)."""
+    device: rehearsal of the multi-rank path on a one-GPU box).  need_devices=False (a gloo preflight: nothing will touch a
+    card) skips the device count."""
     import subprocess
     import time
 
@@ -117,6 +170,8 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
         world = int(os.environ["WORLD_SIZE"])
         if world != n_ranks:
             raise LaunchRefused("--gpus %d but WORLD_SIZE=%d" % (n_ranks, world))
+        if not need_devices:
+            return None
         n_dev = visible_devices()
         if shared is None and n_dev == 1 and world > 1:
             # a launcher that shows every rank its own card only (HIP_VISIBLE_DEVICES per rank): this rank uses device 0.  If
@@ -124,16 +179,32 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
             return None
         check_world(world, backend, shared, n_dev)
         return None
-    check_world(n_ranks, backend, shared)
+    if need_devices:
+        check_world(n_ranks, backend, shared)
+    elif n_ranks < 1:
+        raise LaunchRefused("--gpus must be >= 1")
     if n_ranks == 1:
         return None
+    import tempfile
+    import threading
     port = free_port()
-    procs = []
+    rdzv_limit = float(os.environ.get("SART_RDZV_TIMEOUT", RDZV_TIMEOUT_S)) + float(os.environ.get("SART_RDZV_MARGIN", 60.0))
+    start_limit = float(os.environ.get("SART_START_TIMEOUT", START_TIMEOUT_S))
+    wall_limit = float(os.environ.get("SART_LAUNCH_TIMEOUT", LAUNCH_TIMEOUT_S))
+    status_dir = tempfile.mkdtemp(prefix="sart_ranks_")
+    procs, pumps = [], []
+    err_sink = getattr(sys.stderr, "buffer", None) or sys.stderr
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SART_BENCH_BACKEND=backend)
-        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SART_BENCH_BACKEND=backend, SART_RANK_STATUS_DIR=status_dir,
+                   PYTHONUNBUFFERED="1")
+        p = subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=None if r == 0 else subprocess.PIPE,
+                             stderr=subprocess.PIPE)
+        procs.append(p)
+        for pipe in ((p.stderr,) if r == 0 else (p.stderr, p.stdout)):
+            t = threading.Thread(target=_forward, args=(pipe, "[rank %d] " % r, err_sink), daemon=True)
+            t.start()
+            pumps.append(t)
     import signal
 
     def stop_children(signum, _frame):   # a killed launcher must not leave ranks behind on the GPUs (exact PIDs)
@@ -145,6 +216,9 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
     old = {sig: signal.signal(sig, stop_children) for sig in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
     alive = list(procs)
+    t_start = time.monotonic()
+    t_rdzv = None       # when the first rank reached the rendezvous
+    all_up = False
     try:
         while alive:
             for p in list(alive):
@@ -155,6 +229,30 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
                 if code != 0 and rc == 0:
                     rc = code if code > 0 else 1
                     for q in alive:          # a dead rank leaves the others waiting in a collective: end them
+                        q.terminate()
+            elapsed = time.monotonic() - t_start
+            if alive and rc == 0:
+                what = None
+                if not all_up:
+                    stages = _rank_stages(status_dir, n_ranks)
+                    all_up = all(s in ("up", "done") for s in stages)
+                    if t_rdzv is None and any(s != "nothing" and s != "started" for s in stages):
+                        t_rdzv = time.monotonic()
+                    if not all_up and t_rdzv is not None and time.monotonic() - t_rdzv > rdzv_limit:
+                        what = "the process group did not come up within %.0f s of the first rank's rendezvous" % rdzv_limit
+                    elif not all_up and elapsed > start_limit and any(s in ("nothing", "started") for s in stages):
+                        what = "not every rank reached the rendezvous within %.0f s" % start_limit
+                if what is None and elapsed > wall_limit:
+                    what = "the run did not end within %.0f s" % wall_limit
+                if what is not None:
+                    stages = _rank_stages(status_dir, n_ranks)
+                    print("launcher: %s; last report of every rank: %s" % (what, ", ".join("rank %d: %s" % (r, s) for r, s in enumerate(stages))),
+                          file=sys.stderr)
+                    never = [r for r, s in enumerate(stages) if s in ("nothing", "started", "rendezvous")]
+                    if never and not all_up:
+                        print("launcher: rank(s) %s never reported their process group up" % ", ".join(map(str, never)), file=sys.stderr)
+                    rc = 3
+                    for q in alive:
                         q.terminate()
             time.sleep(0.05)
     finally:
@@ -168,6 +266,13 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list) -> int | None:
                 q.kill()
         for sig, h in old.items():
             signal.signal(sig, h)
+        for t in pumps:
+            t.join(timeout=2)
+        try:
+            import shutil
+            shutil.rmtree(status_dir, ignore_errors=True)
+        except Exception:
+            pass
     return rc
 
 
@@ -178,9 +283,11 @@ def init_process_group_from_env(backend: str | None = None):
     import torch
     import torch.distributed as dist
 
+    from datetime import timedelta
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    report_stage("started")
     if world > 1 and visible_devices() == 1:
         local_rank = 0
     if world > 1 and not dist.is_initialized():
@@ -188,12 +295,51 @@ def init_process_group_from_env(backend: str | None = None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # a rendezvous or RCCL bring-up that stalls must end in an exception (non-zero exit), not in a wait for ever
+        timeout = timedelta(seconds=float(os.environ.get("SART_RDZV_TIMEOUT", RDZV_TIMEOUT_S)))
+        report_stage("rendezvous")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
+    report_stage("up")
     return rank, world, local_rank
+
+
+def preflight(backend: str | None = None, n_bytes: int = 512 * 1024) -> dict:
+    """First contact with a multi-GPU node without the workload: bring the process group up, reduce one buffer of the size of
+    the fused accumulator (512 KB) to rank 0 once, report the time.  Returns the dictionary rank 0 prints as JSON."""
+    import time
+    import torch
+    import torch.distributed as dist
+    t0 = time.perf_counter()
+    rank, world, local_rank = init_process_group_from_env(backend)
+    up_ms = (time.perf_counter() - t0) * 1e3
+    be = dist.get_backend() if world > 1 else "none"
+    on_gpu = be == "nccl" or (world == 1 and torch.cuda.is_available())
+    if "SART_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["SART_BENCH_DEVICE"])
+    dev = torch.device("cuda", local_rank) if on_gpu else torch.device("cpu")
+    buf = torch.full((n_bytes // 8,), float(rank + 1), dtype=torch.float64, device=dev)
+    if on_gpu:
+        torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    reduce_accumulator(buf, dst=0)
+    if on_gpu:
+        torch.cuda.synchronize(dev)
+    reduce_ms = (time.perf_counter() - t1) * 1e3
+    ok = True
+    if rank == 0:
+        ok = bool((buf == float(world * (world + 1) // 2)).all().item())
+    if world > 1:
+        dist.barrier()
+    out = {"preflight": "ok" if ok else "wrong sum", "world_size": world, "backend": be, "device": str(dev), "process_group_up_ms": up_ms,
+           "reduce_ms": reduce_ms, "reduce_bytes": n_bytes}
+    if world > 1:
+        dist.destroy_process_group()
+    report_stage("done")
+    return out
 
 
 def reduce_accumulator(acc, dst: int | None = 0, fixed64: bool = False):

@@ -278,3 +278,74 @@ def test_killed_launcher_takes_its_ranks_with_it(tmp_path):
         except (ProcessLookupError, FileNotFoundError):
             alive = False
         assert not alive, pid
+
+
+# ---- round 4: first contact with an 8-GPU node must end in a diagnosable exit, never in a wait for ever -----------------------
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SART_BENCH_DEVICE", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_preflight_brings_up_eight_ranks_through_the_launcher():
+    """`python bench.py --gpus 8 --preflight`: eight ranks started by the launcher, process group up, one 512 KB reduce, one JSON
+    line on stdout; every other line any rank prints arrives on stderr with its rank in front."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--preflight"], env=_clean_env(SART_BENCH_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]     # (gloo itself prints a "[Gloo] Rank 0 is connected" line)
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["preflight"] == "ok" and d["world_size"] == 8 and d["backend"] == "gloo" and d["reduce_bytes"] == 512 * 1024 and d["reduce_ms"] > 0
+    for l in r.stderr.splitlines():
+        assert l.startswith("[rank ") or l.startswith("launcher:"), l
+
+
+_STUCK_SCRIPT = '''
+import os, sys, time
+sys.path.insert(0, %r)
+from solaraxionraytracing_amd import distributed as D
+mode, stuck = sys.argv[1], int(sys.argv[2])
+if mode == "before" and int(os.environ["RANK"]) == stuck:
+    time.sleep(300)                      # never reaches the rendezvous
+if mode == "inside":
+    D.report_stage("rendezvous")         # as if hanging inside init_process_group without ever raising
+    time.sleep(300)
+print("rank %%s at the rendezvous" %% os.environ["RANK"], file=sys.stderr, flush=True)
+D.init_process_group_from_env("gloo")
+'''
+
+
+@pytest.mark.parametrize("mode", ["before", "inside"])
+def test_a_rank_stuck_at_the_rendezvous_ends_the_launch_with_a_nonzero_exit(tmp_path, mode):
+    """VERDICT r03: init_process_group had no timeout and the launcher waited for ever.  `before`: one rank never reaches the
+    rendezvous - the others' init_process_group raises after SART_RDZV_TIMEOUT and the launcher ends the straggler;
+    `inside`: every rank hangs in the bring-up without raising - the launcher's own clock ends them and names the ranks."""
+    import subprocess
+    import time
+    script = tmp_path / "stuck.py"
+    script.write_text(_STUCK_SCRIPT % ROOT)
+    launcher = tmp_path / "launcher.py"
+    launcher.write_text("import sys\nsys.path.insert(0, %r)\nfrom solaraxionraytracing_amd import distributed as D\nD.visible_devices = lambda: 3\n"
+                        "raise SystemExit(D.launch_ranks_if_needed(3, %r, [%r, '1']))\n" % (ROOT, str(script), mode))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(launcher)], env=_clean_env(SART_BENCH_BACKEND="gloo", SART_RDZV_TIMEOUT="4", SART_RDZV_MARGIN="2"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0, (r.stdout, r.stderr)
+    assert time.time() - t0 < 60
+    if mode == "inside":
+        assert r.returncode == 3 and "never reported their process group up" in r.stderr and "rank 0: rendezvous" in r.stderr
+    else:
+        assert "[rank 0] " in r.stderr or "[rank 2] " in r.stderr      # the ranks that waited say why they gave up
+
+
+def test_report_stage_is_silent_without_a_launcher(tmp_path, monkeypatch):
+    monkeypatch.delenv("SART_RANK_STATUS_DIR", raising=False)
+    D.report_stage("up")                                               # no directory: nothing happens
+    monkeypatch.setenv("SART_RANK_STATUS_DIR", str(tmp_path))
+    monkeypatch.setenv("RANK", "5")
+    D.report_stage("up")
+    assert (tmp_path / "rank5").read_text() == "up" and D._rank_stages(str(tmp_path), 6)[5] == "up" and D._rank_stages(str(tmp_path), 6)[0] == "nothing"

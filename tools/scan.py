@@ -182,6 +182,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    D.report_stage("done")
 
 
 class _Null:
