@@ -129,6 +129,8 @@ class Oracle:
             self._keep.append(a)
             return a.ctypes.data_as(_dp)
 
+        if hasattr(full, "require_solar_tables"):
+            full.require_solar_tables()   # emission="agss09-device": the CDFs live on the GPU until fetch_solar_tables(tracer)
         t.flux_radius_cdf, t.diff_flux_cdfs, t.energies_kev = dp(full.fluxRadiusCDF), dp(full.diffFluxCDFs), dp(full.energies)
         t.n_radii, t.n_energies = full.diffFluxCDFs.shape
         r = full.reflectivity

@@ -98,6 +98,7 @@ def init_full_setup_from_config(config_path: str, flags: int = 0, **overrides) -
         if opcd and os.path.exists(os.path.join(opcd, "OPCD_3.3", "mono", "fm01.mesh")):
             kw["emission"] = "agss09-device"
             kw["opcd_path"] = opcd
+            kw["opcd_optional"] = True   # an incomplete OPCD directory degrades to the table without the OPCD term (noted in meta)
             notes.append("solarModelFile %s not found: emission table from the AGSS09 model and the OPCD files in %s" % (solar, opcd))
         else:
             notes.append("solarModelFile %s not found: synthetic E1 emission table" % solar)
@@ -111,5 +112,5 @@ def init_full_setup_from_config(config_path: str, flags: int = 0, **overrides) -
     full = initFullSetup(es, dk, sk, tk, flags, **kw)
     full.outpath = os.path.normpath(os.path.join(base, res.get("outputPath", "../out")))
     full.meta["config"] = config_path
-    full.meta["notes"] = notes
+    full.meta["notes"] = notes + list(full.meta.get("notes", []))
     return full

@@ -50,13 +50,22 @@ class FullRaytraceSetup:
         self.fluxRadiusCDF, self.diffFluxCDFs = tracer.solar_tables()
         return self
 
+    def require_solar_tables(self):
+        """Consumers that need the CDFs on the host (the CPU oracle, tools/make_golden*.py) call this: with
+        emission="agss09-device" they exist on the GPU only until fetch_solar_tables(tracer) has copied them."""
+        if self.fluxRadiusCDF is None or self.diffFluxCDFs is None:
+            raise RuntimeError("this FullRaytraceSetup keeps its sampling tables on the device (emission=%r): call "
+                               "full.fetch_solar_tables(tracer) with a RayTracer built from it first" % self.meta.get("emission"))
+        return self
+
 
 def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_INGRIDIAXO,
                   stage: int = _lib.SK_VACUUM, telescope: int = _lib.TK_XMM, flags: int = 0, *,
                   emission: str | np.ndarray = "primakoff", n_radii: int = tables.N_RADII,
                   n_energies: int = tables.N_ENERGIES, reflectivity: str | tables.ReflectivityGrid = "henke",
                   refl_n_angles: int = 1000, refl_n_energies: int = 1000, solar_model_csv: str | None = None,
-                  magnet_cfg=None, source_cfg=None, install_cfg=None, opcd_path: str | None = None) -> FullRaytraceSetup:
+                  magnet_cfg=None, source_cfg=None, install_cfg=None, opcd_path: str | None = None,
+                  opcd_optional: bool = False) -> FullRaytraceSetup:
     """initFullSetup, raytracer.nim:2637-2753.  Defaults = config/config_default.toml:19-22
     (BabyIAXO / InGridIAXO / vacuum / XMM).  ``emission`` / ``reflectivity`` choose the synthetic stand-ins of
     tables.py when the reference's own input files are not available."""
@@ -84,9 +93,18 @@ def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_IN
             em, meta_em = None, "E0-agss09-all-terms-gpu-device-cdfs"
             if opcd_path is not None:   # with the absorption coefficients of the OPCD files (readOpacityFile.nim:731-745, :790-823)
                 from . import opacity as _opacity
-                dev_em["opcd"] = _opacity.OpcdSet(opcd_path, zones)
-                dev_em["n_z"] = _opacity.number_densities(n_radii=n_radii)
-                meta_em = "E0-agss09-all-terms-opcd-gpu-device-cdfs"
+                try:
+                    dev_em["opcd"] = _opacity.OpcdSet(opcd_path, zones)
+                    dev_em["n_z"] = _opacity.number_densities(n_radii=n_radii)
+                    dev_em["opcd_optional"] = bool(opcd_optional)
+                    meta_em = "E0-agss09-all-terms-opcd-gpu-device-cdfs"
+                except (_lib.SartError, OSError, ValueError) as e:
+                    # opcd_optional (a config.toml that merely HAS an OPCD directory): an incomplete or unreadable set of files
+                    # must not take the whole setup down - the table is made without the OPCD absorption term and says so
+                    if not opcd_optional:
+                        raise
+                    dev_em.pop("opcd", None)
+                    dev_em["notes"] = ["OPCD files in %s could not be loaded (%s): emission table without the OPCD absorption term" % (opcd_path, e)]
         elif emission == "flat":
             em, meta_em = tables.flat_emission_table(n_radii, n_energies), "E3-flat"
         else:
@@ -111,8 +129,10 @@ def initFullSetup(experiment: int = _lib.ES_BABYIAXO, detector: int = _lib.DK_IN
         else:
             raise ValueError("unknown reflectivity %r" % (reflectivity,))
     det = tables.detector_tables()
-    return FullRaytraceSetup(setup, np.ascontiguousarray(energies), rcdf, ecdf, refl, det, flags,
-                             meta={"emission": meta_em, "reflectivity": meta_r}, device_emission=dev_em)
+    meta = {"emission": meta_em, "reflectivity": meta_r}
+    if dev_em is not None and dev_em.get("notes"):
+        meta["notes"] = list(dev_em["notes"])
+    return FullRaytraceSetup(setup, np.ascontiguousarray(energies), rcdf, ecdf, refl, det, flags, meta=meta, device_emission=dev_em)
 
 
 class RayTracer:
@@ -137,11 +157,22 @@ class RayTracer:
         if full.device_emission is not None:
             # BASELINE configs[4]'s front end without a host round trip: emission kernel -> CDFs -> guide tables on the device
             de = full.device_emission
+            done = False
             if de.get("opcd") is not None:
-                _lib.check(lib.sart_emission_to_solar_tables_opcd(h, de["zones"], len(de["zones"]), _lib.as_dp(de["n_z"]),
-                                                                  _lib.as_dp(full.energies), full.energies.size, de["opcd"].tables,
-                                                                  C.byref(de["params"])))
-            else:
+                try:
+                    _lib.check(lib.sart_emission_to_solar_tables_opcd(h, de["zones"], len(de["zones"]), _lib.as_dp(de["n_z"]),
+                                                                      _lib.as_dp(full.energies), full.energies.size, de["opcd"].tables,
+                                                                      C.byref(de["params"])))
+                    done = True
+                except _lib.SartError as e:
+                    # e.g. a (radius, energy) cell outside a table's abscissae (sart_opacity.hip): fatal unless the OPCD term
+                    # was only an opportunistic upgrade (config.py), in which case the table is made without it - and says so
+                    if not de.get("opcd_optional"):
+                        raise
+                    full.meta.setdefault("notes", []).append("OPCD absorption coefficients failed on the device (%s): emission table "
+                                                             "without the OPCD absorption term" % e)
+                    full.meta["emission"] = "E0-agss09-all-terms-gpu-device-cdfs"
+            if not done:
                 _lib.check(lib.sart_emission_to_solar_tables(h, de["zones"], len(de["zones"]), _lib.as_dp(full.energies),
                                                              full.energies.size, None, C.byref(de["params"])))
         else:

@@ -152,3 +152,29 @@ def test_cli_parser_mirrors_the_reference_main():
     a = cli.build_parser().parse_args(["--ignoreDetWindow", "--xrayTest", "--angularScanMax", "0.3", "--numAngularScanPoints", "7"])
     full, flags = cli.setup_from_args(a)
     assert flags == (L.CF_IGNORE_DET_WINDOW | L.CF_XRAY_TEST) and full.setup.test_active == 1
+
+
+def test_incomplete_opcd_directory_degrades_with_a_note_instead_of_failing(tmp_path):
+    """a config.toml whose opcdPath merely EXISTS (fm01.mesh there, the rest missing or unreadable) used to switch
+    the whole setup to the OPCD path, which then failed hard.  From a config file the OPCD term is an opportunistic upgrade:
+    the setup comes up with the analytic emission terms and says so; asked for explicitly (opcd_path=...) it still raises.
+    A setup that keeps its CDFs on the device tells a host-side consumer what to do instead of failing with a None."""
+    from oracle.oracle import Oracle
+    cfgdir = tmp_path / "config"
+    (cfgdir / "res").mkdir(parents=True)
+    mono = cfgdir / "OPCD" / "OPCD_3.3" / "mono"
+    mono.mkdir(parents=True)
+    (mono / "fm01.mesh").write_text("not a mesh file\n")
+    p = cfgdir / "config.toml"
+    p.write_text(SAMPLE)
+    full = config.init_full_setup_from_config(str(p), n_radii=60, n_energies=50, refl_n_angles=30, refl_n_energies=30)
+    notes = " | ".join(full.meta["notes"])
+    assert "could not be loaded" in notes and "without the OPCD absorption term" in notes
+    assert full.device_emission is not None and full.device_emission.get("opcd") is None
+    with pytest.raises((L.SartError, OSError, ValueError)):
+        sa_init = __import__("solaraxionraytracing_amd").initFullSetup
+        sa_init(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, emission="agss09-device", opcd_path=str(cfgdir / "OPCD"),
+                n_radii=60, n_energies=50, refl_n_angles=30, refl_n_energies=30)
+    with pytest.raises(RuntimeError) as e:
+        Oracle(full)
+    assert "fetch_solar_tables" in str(e.value)
