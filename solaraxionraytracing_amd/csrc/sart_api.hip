@@ -334,8 +334,7 @@ int hoist_setup(sart_context* c) {
     const double g_ev = s.g_agamma * 1e-9, beV = s.magnet_B * 1e3 / 1.444;
     P.gas_term1 = std::pow(g_ev * beV / 2.0, 2);
     P.gas_inv_hbarc_m = 1e-3 / 1.97e-7;
-    P.m_axion_sq = s.m_axion * s.m_axion;
-    P.gas_dm2_abs = std::fabs(P.gas_m_gamma_sq - P.m_axion_sq);
+    P.gas_dm2_abs = std::fabs(P.gas_m_gamma_sq - s.m_axion * s.m_axion);
   }
   // reflectivity
   P.n_coatings = c->refl_nc;
@@ -1037,8 +1036,7 @@ int sart_set_axion_mass(sart_context* c, double m) {
   // mass starts a new accumulator
   if (changed && c->setup.stage == SART_SK_GAS) c->quanta_frozen = false;
   if (c->derived_dirty) return 0;
-  c->params.m_axion_sq = m * m;
-  c->params.gas_dm2_abs = std::fabs(c->params.gas_m_gamma_sq - c->params.m_axion_sq);
+  c->params.gas_dm2_abs = std::fabs(c->params.gas_m_gamma_sq - m * m);
   c->blob_dirty = true;
   return 0;
 }

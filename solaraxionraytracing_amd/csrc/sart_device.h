@@ -135,8 +135,10 @@ struct DevParams {
   double conv_k;              // P(a->gamma) = conv_k * pathCB^2 (vacuum)
   double exposure;            // 3.585e3*3600*1.5*90 | 9.5e6*3600*12*90
   double gas_m_gamma_sq, gas_term1, gas_inv_hbarc_m;   // m_gamma^2, (g B / 2)^2, 1e-3 / 1.97e-7 (mm -> 1/eV)
-  double m_axion_sq;
-  double gas_dm2_abs;         // |m_gamma^2 - m_a^2| (one IEEE subtraction; the mass scan's table holds the same expression per mass)
+  // |m_gamma^2 - m_a^2| (one IEEE subtraction of the two squares; the mass scan's table holds the same expression per mass).
+  // (Takes the place of m_a^2 in this block: the LDS copy of the blob keeps its size, and with it the rings their addresses -
+  // 16 bytes more and every ring access needs an extra address add, +2 vector instructions per loop iteration.)
+  double gas_dm2_abs;
   // ---- reflectivity (raytracer.nim:1533-1580) ----
   int32_t refl_n_angles, n_coatings;
   double refl_angle_min, refl_inv_dangle, refl_dangle;

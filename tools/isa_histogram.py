@@ -38,7 +38,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "solaraxionraytracing_amd", "csrc")
 VARIANTS = {0: "Lb1ELb0ELi0ELb0E", 1: "Lb0ELb0ELin1ELb0E", 2: "Lb0ELb1ELin1ELb0E", 3: "Lb1ELb0ELi1ELb0E", 4: "Lb1ELb1ELi0ELb0E",
-            5: "Lb1ELb0ELi0ELb1E"}
+            5: "Lb1ELb0ELi0ELb1E", 6: "Lb1ELb0ELi1ELb1E"}
 
 F64 = re.compile(r"v_(fma|fmac|mul|add|rcp|rsq|sqrt|rndne|trunc|floor|ceil|fract|ldexp|frexp_mant|frexp_exp_i32|div_scale|div_fmas|div_fixup|min|max)_f64")
 CMP = re.compile(r"v_cmpx?_")
@@ -89,8 +89,8 @@ def build_asm() -> str:
     return os.path.join(out_dir, "sart_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
 
 
-def kernel_lines(asm_path: str, variant: int, fixed: bool):
-    tag = "_ZN4sart22trace_histogram_kernelILi1024E" + VARIANTS[variant] + ("Lb1E" if fixed else "Lb0E")
+def kernel_lines(asm_path: str, variant: int, fixed: bool, scan: bool = False):
+    tag = "_ZN4sart22trace_histogram_kernelILi1024E" + VARIANTS[variant] + ("Lb1E" if fixed else "Lb0E") + ("Lb1E" if scan else "Lb0E")
     lines = open(asm_path).read().splitlines()
     start = next(i for i, l in enumerate(lines) if l.startswith(tag) and l.rstrip().split(":")[0].startswith(tag) and ":" in l)
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
@@ -179,6 +179,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variant", type=int, default=5, help="0 vacuum, 1 generic, 2 generic rotated, 3 gas, 4 rotated, 5 vacuum + constant path (headline)")
     ap.add_argument("--fixed", action="store_true", help="the SART_ACCUM_FIXED64 instantiation")
+    ap.add_argument("--scan", action="store_true", help="the fused mass-scan instantiation (variants 1, 2, 3, 6)")
     ap.add_argument("--asm", default=None, help="existing listing (default: compile now)")
     ap.add_argument("--pmc", default=None, help="profiles/<tag>_<workload>_pmc_summary.json of the same build: measured totals beside the model")
     ap.add_argument("--passes-b", type=float, default=None, help="phase-B passes per 64 launched rays (default: from --pmc results or 0.3295)")
@@ -186,7 +187,7 @@ def main():
     ap.add_argument("--dump", default=None, help="comma-separated classes: print the hot-path instructions of these classes (e.g. mov,select,cvt,lane)")
     args = ap.parse_args()
     asm = args.asm or build_asm()
-    h = histogram(kernel_lines(asm, args.variant, args.fixed))
+    h = histogram(kernel_lines(asm, args.variant, args.fixed, args.scan))
     report = {"variant": args.variant, "fixed64": args.fixed, "stages": {}, "how": "tools/isa_histogram.py: static counts of the hot path "
               "(blocks without a `; rare` marker) per stage of the gfx950 listing; rare = the divergent alternatives"}
     print("%-9s %5s | " % ("stage", "VALU") + " ".join("%6s" % c for c in VALU_CLASSES) + " | salu  lds vmem atom wait | rare VALU")
