@@ -738,15 +738,18 @@ def test_interleaved_contexts_and_extreme_seeds_and_ids():
     assert abs(sa1["N_PASSED"] - so["N_PASSED"]) <= 2 and abs(sa1["N_REACHED_TELESCOPE"] - so["N_REACHED_TELESCOPE"]) <= 2
 
 
-def test_scan_driver_sharded_by_rays_equals_sharded_by_bins(tmp_path):
-    """tools/scan.py: the axion-mass scan with every point's rays sharded over 2 ranks (one accumulator reduce per point,
-    BASELINE config 5; gloo on this one GPU) gives the curve of the bin-sharded single-process scan."""
+@pytest.mark.parametrize("host_loop", [False, True])
+def test_scan_driver_sharded_over_two_ranks_equals_one_process(tmp_path, host_loop):
+    """tools/scan.py mass: the fused scan (every rank traces its share of the ray ids once for all masses, one reduce of the
+    scan accumulator; BASELINE configs[4]) and, --host-loop, the reference-shaped scan (a re-trace per mass point, sharded by
+    bin in one process / by ray id over the ranks with one accumulator reduce per point) - two gloo ranks on this one GPU give
+    the curve of the single process."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    a, b = str(tmp_path / "bins.csv"), str(tmp_path / "rays.csv")
-    common = ["mass", "--points", "4", "--rays", "500000"]
+    a, b = str(tmp_path / "one.csv"), str(tmp_path / "two.csv")
+    common = ["mass", "--points", "4", "--rays", "500000"] + (["--host-loop"] if host_loop else [])
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "scan.py")] + common + ["--out", a], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     env = dict(os.environ, SART_BENCH_BACKEND="gloo", SART_BENCH_DEVICE="0")
@@ -754,8 +757,9 @@ def test_scan_driver_sharded_by_rays_equals_sharded_by_bins(tmp_path):
                         "--master-port", "29571", os.path.join(root, "tools", "scan.py")] + common + ["--shard", "rays", "--out", b],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    ca, cb = np.loadtxt(a, delimiter=",", skiprows=1), np.loadtxt(b, delimiter=",", skiprows=1)
+    ca, cb = np.loadtxt(a, delimiter=",", skiprows=1, usecols=(0, 1, 2)), np.loadtxt(b, delimiter=",", skiprows=1, usecols=(0, 1, 2))
     np.testing.assert_allclose(cb[:, 1], ca[:, 1], rtol=1e-9)
+    assert ca[:, 1].min() > 0
 
 
 def test_setup_change_between_async_launches_needs_no_explicit_sync():
