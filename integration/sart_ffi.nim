@@ -299,6 +299,23 @@ proc performAngularScanGpu*(ctx: ptr SartContext, angles: seq[float], nRaysPerAn
     result.add s.v[AccSumWeights]
   sartCheck sart_set_telescope_angles(ctx, NaN, setup.telescope_turned_y_deg)   # the reference scans a copy (:2794)
 
+proc performAxionMassScanGpu*(ctx: ptr SartContext, massesEv: seq[float], nRays: int, flags: set[ConfigFlags],
+                               seed = 299792458'u64, rayIdOffset = 0'u64): tuple[flux, fluxSq, nPassed: seq[float]] =
+  ## Axion-mass scan in the gas stage (stageSetup = "gas"): the reference would change `mAxion` (:255) and re-run
+  ## calculateFluxFractions per mass; here every ray is traced ONCE and weighed for every mass (sart_trace_mass_scan: the mass
+  ## enters a ray's weight through axionConversionProb2 alone, :1599-1625).  All masses see the same rays.
+  ## flux[k] = sum of weights of the passed rays for massesEv[k]; sqrt(fluxSq[k]) = its Monte-Carlo error.
+  doAssert massesEv.len > 0
+  var p = sartParams(nRays, flags, seed, rayIdOffset)
+  var m = newSeq[cdouble](massesEv.len)
+  for i, x in massesEv: m[i] = x
+  var rows = newSeq[cdouble]((massesEv.len + 1) * SartScanRow)
+  sartCheck sart_trace_mass_scan(ctx, addr p, addr m[0], m.len.int32, addr rows[0])
+  for k in 0 ..< massesEv.len:
+    result.flux.add rows[k * SartScanRow + 0]        # SART_SCAN_SUM_WEIGHTS
+    result.fluxSq.add rows[k * SartScanRow + 1]      # SART_SCAN_SUM_WEIGHTS_SQ
+    result.nPassed.add rows[k * SartScanRow + 2]     # SART_SCAN_N_PASSED
+
 proc traceHistogramDeterministic*(ctx: ptr SartContext, nRays: int, flags: set[ConfigFlags], image: var seq[cdouble],
                                   seed = 299792458'u64, rayIdOffset = 0'u64): SartSummary =
   ## The same image and sums, bit for bit reproducible: integer accumulation (SART_ACCUM_FIXED64) instead of f64 atomics - the

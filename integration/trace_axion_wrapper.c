@@ -14,7 +14,9 @@
  * 3. sart_trace_records into a caller-owned array of 208-byte Axion records  = traceAxionWrapper(axBuf, bufLen, ...).
  * 4. sart_trace_histogram over the same ray ids = the same rays without the records: prepareHeatmap + flux sum + counters.
  * 5. The two must agree: counters exactly, image and flux to rounding (the histogram adds in another order).
- * Exit code 0 when they do.
+ * 6. The fused axion-mass scan (sart_trace_mass_scan): the same setup in the gas stage, every ray traced once and weighed for
+ *    five axion masses - against the reference-shaped loop (set mAxion, :255, re-trace, sum the weights of the records).
+ * Exit code 0 when everything agrees.
  */
 #include <math.h>
 #include <stdio.h>
@@ -117,7 +119,33 @@ int main(int argc, char** argv) {
          "\"flux_records\": %.17g, \"flux_histogram\": %.17g, \"image_max_abs_diff\": %.3g, \"agree\": %s}\n",
          sart_abi_version(), sart_build_id(), (unsigned long long)n_rays, (unsigned long long)n_passed, (unsigned long long)n_till,
          (unsigned long long)n_nickel, flux, s.v[SART_ACC_SUM_WEIGHTS], max_diff, ok ? "true" : "false");
+  /* 6. gas stage: one pass over the rays for all masses vs one traceAxionWrapper per mass */
+  enum { N_MASSES = 5 };
+  const double masses[N_MASSES] = {0.0, 0.004, 0.008235, 0.012, 0.05};   /* eV; m_gamma = 0.008235 eV for this magnet (literal units) */
+  sart_setup_t gas = setup;
+  gas.stage = SART_SK_GAS;
+  CHECK(sart_set_setup(ctx, &gas));
+  double scan[(N_MASSES + 1) * SART_SCAN_ROW];
+  CHECK(sart_trace_mass_scan(ctx, &p, masses, N_MASSES, scan));
+  int scan_ok = scan[N_MASSES * SART_SCAN_ROW + SART_SCAN_N_RAYS] == (double)n_rays;
+  double scan_max_rel = 0.0;
+  for (int k = 0; k < N_MASSES; ++k) {
+    CHECK(sart_set_axion_mass(ctx, masses[k]));
+    CHECK(sart_host_trace_axion_wrapper(ctx, ax_buf, (int64_t)n_rays, p.seed, p.ray_id_offset, p.flags));
+    double f = 0.0;
+    uint64_t np = 0;
+    for (uint64_t i = 0; i < n_rays; ++i)
+      if (ax_buf[i].passed) { f += ax_buf[i].weights; ++np; }
+    const double* row = scan + k * SART_SCAN_ROW;
+    const double rel = fabs(row[SART_SCAN_SUM_WEIGHTS] - f) / f;
+    if (rel > scan_max_rel) scan_max_rel = rel;
+    scan_ok = scan_ok && row[SART_SCAN_N_PASSED] == (double)np && rel <= 1e-9 && np > 0;
+  }
+  scan_ok = scan_ok && scan[2 * SART_SCAN_ROW + SART_SCAN_SUM_WEIGHTS] > scan[0 * SART_SCAN_ROW + SART_SCAN_SUM_WEIGHTS] &&
+            scan[2 * SART_SCAN_ROW + SART_SCAN_SUM_WEIGHTS] > scan[4 * SART_SCAN_ROW + SART_SCAN_SUM_WEIGHTS];   /* the resonance */
+  printf("{\"mass_scan\": {\"masses\": %d, \"flux_on_resonance\": %.17g, \"max_rel_diff_to_per_mass_records\": %.3g, \"agree\": %s}}\n",
+         N_MASSES, scan[2 * SART_SCAN_ROW + SART_SCAN_SUM_WEIGHTS], scan_max_rel, scan_ok ? "true" : "false");
   free(ax_buf);
   CHECK(sart_destroy(ctx));
-  return ok ? 0 : 1;
+  return (ok && scan_ok) ? 0 : 1;
 }

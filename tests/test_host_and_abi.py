@@ -194,9 +194,12 @@ def test_c_host_records_agree_with_histogram(tmp_path):
     import subprocess
     r = subprocess.run([_build_c_host(tmp_path), "200000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    out = json.loads(r.stdout)
-    assert out["agree"] is True and out["passed"] > 10000 and out["build"] == L.build_id()
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    out, scan = lines[0], lines[1]["mass_scan"]
+    assert out["agree"] is True and out["passed"] > 10000 and out["build"] == L.build_id() and out["abi"] == 2
     assert abs(out["flux_records"] - out["flux_histogram"]) <= 1e-11 * out["flux_histogram"]
+    # step 6 of the program: the fused mass scan (gas stage) against one traceAxionWrapper per mass, from plain C
+    assert scan["agree"] is True and scan["masses"] == 5 and scan["max_rel_diff_to_per_mass_records"] <= 1e-9
 
 
 def test_product_does_not_link_or_import_the_oracle():
