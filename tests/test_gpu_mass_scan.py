@@ -75,6 +75,10 @@ VARIANTS = {
     "generic_rotated": ("babyiaxo_xmm_gas", {}, "rot"),
     # variant 1 with the X-ray test source (one energy row, no exposure factor)
     "xray_test_source": ("babyiaxo_xmm_gas", {}, "xray"),
+    # cone optics, four coatings, a 43 mm bore that rays do enter through the wall: stage A0 has no zones, the path varies per ray
+    "cast_llnl_gas": ("cast_llnl", {}, "gas"),
+    # the third telescope: CAST + Abrixas (27 Wolter shells, six spokes)
+    "cast_abrixas_gas": ("cast_abrixas", {}, "gas"),
 }
 
 
@@ -87,6 +91,8 @@ def variant_setup(name):
         full = make_setup(setup_name)
     if tweak == "rot":
         full.setup.telescope_turned_x_deg, full.setup.telescope_turned_y_deg = 0.01, 0.03
+    if tweak == "gas":
+        full.setup.stage = L.SK_GAS
     return full, knobs, flags
 
 
