@@ -122,6 +122,25 @@ def test_fixed64_scan_equals_single_mass_launches_bit_for_bit(name):
         assert 0 <= row[L.SCAN["SUM_WEIGHTS"]] < 2 ** L.FIXED_LIMB_BITS
 
 
+@pytest.mark.parametrize("flags", [L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS, L.CF_IGNORE_REFLECTION, L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_REFLECTION | L.CF_IGNORE_GAS_ABS])
+def test_fixed64_scan_equals_single_mass_launches_under_the_ignore_flags(flags):
+    """The command-line switches of the reference (--ignoreDetWindow, --ignoreGasAbs, --ignoreReflection; raytracer.nim:2842-2849)
+    change which factors the mass-independent part of the weight has (and the FIXED64 weight bound): the scan still equals the
+    single-mass launches bit for bit."""
+    import torch
+    full = make_setup("babyiaxo_xmm_gas")
+    ms = masses(6)
+    n, seed = 1_000_000, 23
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode("fixed64")
+        scan = raw_scan(rt, torch, ms, [(0, n)], seed, flags)
+        for k, m in enumerate(ms):
+            s = raw_single(rt, torch, m, n, seed, flags=flags)
+            for a, b in (("SUM_WEIGHTS", "SUM_WEIGHTS"), ("SUM_WEIGHTS_SQ", "SUM_WEIGHTS_SQ")):
+                assert scan[k][L.SCAN[a]] == s[L.ACC[b]] and scan[k][L.SCAN_HI[a]] == s[L.ACC_HI[b]], (flags, k, a)
+            assert scan[k][L.SCAN["N_PASSED"]] == s[L.ACC["N_PASSED"]] > 0
+
+
 def test_fixed64_scan_finalize_equals_finalized_single_launches():
     """The per-mass quanta are a function of (setup, tables, flags, headroom, mass): finalize of the raw scan gives the very
     doubles the blocking single-mass call returns, and the blocking scan call returns them, too."""
