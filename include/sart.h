@@ -387,9 +387,10 @@ int sart_trace_histogram_spectra(sart_context* ctx, const sart_trace_params_t* p
  *   freezing the quanta are computed by the first histogram launch after a change of the accumulation mode (or by any launch
  *            with accumulate == 0) and kept for the following accumulate == 1 launches of the context, so that launches that
  *            add into one accumulator share them; a launch whose weight bound no longer fits fails with
- *            SART_ERR_INVALID_ARGUMENT.  In the gas stage sart_set_axion_mass with another mass releases them (the bound
- *            follows the mass: a new mass starts a new accumulator).  Contexts with equal inputs compute equal quanta (ranks
- *            of a multi-GPU job).
+ *            SART_ERR_INVALID_ARGUMENT.  In the gas stage the bound follows the axion mass: start the accumulator of every
+ *            scan point with an accumulate == 0 launch (an accumulate == 1 launch after sart_set_axion_mass keeps the frozen
+ *            quanta: refused if the new bound does not fit them, and reported by the checks below if the new weights fall
+ *            under their resolution).  Contexts with equal inputs compute equal quanta (ranks of a multi-GPU job).
  *   checks   integers can stop meaning what they should in two ways, and neither passes silently.  The finalize kernels
  *            (sart_finalize_accumulator_device, sart_finalize_mass_scan_device, and the blocking host-output calls, which
  *            finalize internally) examine the raw accumulator and record what they find in a status word of the context;

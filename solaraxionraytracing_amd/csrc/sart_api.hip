@@ -1030,11 +1030,11 @@ int sart_set_telescope_angles(sart_context* c, double tx, double ty) {
 int sart_set_axion_mass(sart_context* c, double m) {
   if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (!c->have_setup) return fail(SART_ERR_NOT_READY, "no setup");
-  const bool changed = c->setup.m_axion != m;
   c->setup.m_axion = m;
-  // gas stage: the weight bound follows the mass (gas_prob_bound), so the FIXED64 quanta of the next launch do, too - a new
-  // mass starts a new accumulator
-  if (changed && c->setup.stage == SART_SK_GAS) c->quanta_frozen = false;
+  // (FIXED64, gas stage: the weight bound follows the mass - gas_prob_bound - and with it the quanta of the next launch that
+  // STARTS an accumulator, accumulate == 0.  Frozen quanta are not released here: an accumulate == 1 launch adds into integers
+  // that were counted in them; it is refused if the new mass's bound does not fit, and a bound that shrank far below them shows
+  // up in the finalize kernel's resolution check.)
   if (c->derived_dirty) return 0;
   c->params.gas_dm2_abs = std::fabs(c->params.gas_m_gamma_sq - m * m);
   c->blob_dirty = true;

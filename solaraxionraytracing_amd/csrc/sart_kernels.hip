@@ -1389,6 +1389,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const bool use_prob = !(fl & SART_CF_IGNORE_CONV_PROB) & ((GAS >= 0) ? (GAS == 1) : (__builtin_amdgcn_readfirstlane(Bo.P.stage_gas) != 0));
         const double term1 = Bo.P.gas_term1;
         for (int k = 0; k < hdr.n_masses; ++k) {   // wave-uniform
+          asm volatile("; hot: per-mass loop of the fused scan");
           ScanMass M;
           reload_kernarg(M, offsetof(HistKernArgs, SC) + offsetof(ScanArgs, m) + (size_t)k * sizeof(ScanMass));
           double w = out.weight;
@@ -1767,31 +1768,49 @@ __global__ __launch_bounds__(256) void fold_replicas_kernel(T* __restrict__ acc,
 }
 
 // Fused mass scan: rows of the scan accumulator (include/sart.h: SART_SCAN_*) += the per-workgroup sums of one launch.
-// One thread per (mass, quantity); thread (k, 2) turns the counts into N_PASSED of mass k = rays with a non-zero
-// mass-independent weight factor minus those whose conversion probability for this mass is exactly zero.  `shared_row` (first
-// group of masses of a scan only, else nullptr): the mass-independent counters.  Summation order = workgroup order: fixed
-// for a given grid.  FIXED: integers, the two sums in two limbs like fold_scalars_fixed_kernel.
+// 1024 threads = 128 (mass, quantity) pairs x 8 groups of workgroups; group g sums the partial rows g, g + 8, ... of its pair in
+// that order and the pair's first thread adds the eight group sums in order: the summation tree is fixed for a given grid.
+// Pair (k, 2) turns the counts into N_PASSED of mass k = rays with a non-zero mass-independent weight factor minus those whose
+// conversion probability for this mass is exactly zero.  `shared_row` (first group of masses of a scan only, else nullptr): the
+// mass-independent counters.  FIXED: integers, the two sums in two limbs like fold_scalars_fixed_kernel.
 template <bool FIXED>
-__global__ __launch_bounds__(128) void fold_scan_kernel(double* __restrict__ rows_, double* __restrict__ shared_row_, const double* __restrict__ scal_partials_,
-                                                       const double* __restrict__ scan_partials_, int n_blocks, int n_masses, double n_rays) {
+__global__ __launch_bounds__(1024) void fold_scan_kernel(double* __restrict__ rows_, double* __restrict__ shared_row_, const double* __restrict__ scal_partials_,
+                                                        const double* __restrict__ scan_partials_, int n_blocks, int n_masses, double n_rays) {
   using Sum = std::conditional_t<FIXED, long long, double>;
   constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
+  constexpr int kPairs = kScanMaxMasses * kScanPartialSlots, kGroups = 8;
+  static_assert(kPairs * kGroups == 1024, "one thread per (mass, partial slot, group of workgroups)");
   Sum* const rows = reinterpret_cast<Sum*>(rows_);
   Sum* const shared_row = reinterpret_cast<Sum*>(shared_row_);
   const Sum* const scal = reinterpret_cast<const Sum*>(scal_partials_);
   const Sum* const scan = reinterpret_cast<const Sum*>(scan_partials_);
-  static_assert(kScanMaxMasses * kScanPartialSlots == 128, "one thread per (mass, partial slot)");
-  const int k = threadIdx.x >> 2, j = threadIdx.x & 3;
+  __shared__ Sum red_lo[kGroups][kPairs], red_hi[kGroups][kPairs], red_cnt[kGroups][4];
+  const int pair = threadIdx.x % kPairs, g = threadIdx.x / kPairs;
+  const int k = pair >> 2, j = pair & 3;
+  Sum lo = 0, hi = 0;
   if (k < n_masses && j < 3) {
+    for (int b = g; b < n_blocks; b += kGroups) {
+      Sum p = scan[((size_t)b * kScanMaxMasses + k) * kScanPartialSlots + j];
+      if (j == 2) p = scal[(size_t)b * SART_ACC_COUNT + SART_ACC_N_PASSED] - p;
+      if constexpr (FIXED) { lo += p & kMask; hi += p >> kFixedLimbBits; } else lo += p;
+    }
+  }
+  red_lo[g][pair] = lo;
+  red_hi[g][pair] = hi;
+  if (pair < 4) {   // the four counters that come from the workgroup partials
+    const int src = pair == 0 ? SART_ACC_N_REACHED_TELESCOPE : pair == 1 ? SART_ACC_N_SHELL_SELECTED : pair == 2 ? SART_ACC_N_HIT_NICKEL : SART_ACC_N_PASSED;
+    Sum t = 0;
+    if (shared_row)
+      for (int b = g; b < n_blocks; b += kGroups) t += scal[(size_t)b * SART_ACC_COUNT + src];
+    red_cnt[g][pair] = t;
+  }
+  __syncthreads();
+  if (g != 0) return;
+  if (k < n_masses && j < 3) {
+    lo = 0; hi = 0;
+    for (int i = 0; i < kGroups; ++i) { lo += red_lo[i][pair]; hi += red_hi[i][pair]; }
     Sum* const row = rows + (size_t)k * SART_SCAN_ROW;
     if constexpr (FIXED) {
-      long long lo = 0, hi = 0;
-      for (int b = 0; b < n_blocks; ++b) {
-        long long p = scan[((size_t)b * kScanMaxMasses + k) * kScanPartialSlots + j];
-        if (j == 2) p = scal[(size_t)b * SART_ACC_COUNT + SART_ACC_N_PASSED] - p;
-        lo += p & kMask;
-        hi += p >> kFixedLimbBits;
-      }
       if (j == 2) {
         row[SART_SCAN_N_PASSED] += (hi << kFixedLimbBits) + lo;
       } else {
@@ -1801,23 +1820,15 @@ __global__ __launch_bounds__(128) void fold_scan_kernel(double* __restrict__ row
         row[sh] += hi + (lo >> kFixedLimbBits);
       }
     } else {
-      double t = 0.0;
-      for (int b = 0; b < n_blocks; ++b) {
-        double p = scan[((size_t)b * kScanMaxMasses + k) * kScanPartialSlots + j];
-        if (j == 2) p = scal[(size_t)b * SART_ACC_COUNT + SART_ACC_N_PASSED] - p;
-        t += p;
-      }
-      row[j == 0 ? SART_SCAN_SUM_WEIGHTS : j == 1 ? SART_SCAN_SUM_WEIGHTS_SQ : SART_SCAN_N_PASSED] += t;
+      row[j == 0 ? SART_SCAN_SUM_WEIGHTS : j == 1 ? SART_SCAN_SUM_WEIGHTS_SQ : SART_SCAN_N_PASSED] += lo;
     }
   }
-  if (shared_row && threadIdx.x >= 124) {   // threads (31, 0..3): the four counters that come from the workgroup partials
-    const int c = threadIdx.x - 124;
-    const int src = c == 0 ? SART_ACC_N_REACHED_TELESCOPE : c == 1 ? SART_ACC_N_SHELL_SELECTED : c == 2 ? SART_ACC_N_HIT_NICKEL : SART_ACC_N_PASSED;
-    const int dst = c == 0 ? SART_SCAN_N_REACHED_TELESCOPE : c == 1 ? SART_SCAN_N_SHELL_SELECTED : c == 2 ? SART_SCAN_N_HIT_NICKEL : SART_SCAN_N_ON_DETECTOR;
+  if (shared_row && pair < 4) {
+    const int dst = pair == 0 ? SART_SCAN_N_REACHED_TELESCOPE : pair == 1 ? SART_SCAN_N_SHELL_SELECTED : pair == 2 ? SART_SCAN_N_HIT_NICKEL : SART_SCAN_N_ON_DETECTOR;
     Sum t = 0;
-    for (int b = 0; b < n_blocks; ++b) t += scal[(size_t)b * SART_ACC_COUNT + src];
+    for (int i = 0; i < kGroups; ++i) t += red_cnt[i][pair];
     shared_row[dst] += t;
-    if (c == 0) shared_row[SART_SCAN_N_RAYS] += (Sum)n_rays;
+    if (pair == 0) shared_row[SART_SCAN_N_RAYS] += (Sum)n_rays;
   }
 }
 
@@ -2139,9 +2150,9 @@ bool launch_trace_mass_scan(const HotA& H, const HotB& HB, const DevBlob* blob, 
     default: return false;
   }
   if (fixed)
-    hipLaunchKernelGGL(fold_scan_kernel<true>, dim3(1), dim3(128), 0, stream, rows, shared_row, A.partials, SC.partials, n_blocks, SC.n_masses, (double)A.n_rays);
+    hipLaunchKernelGGL(fold_scan_kernel<true>, dim3(1), dim3(1024), 0, stream, rows, shared_row, A.partials, SC.partials, n_blocks, SC.n_masses, (double)A.n_rays);
   else
-    hipLaunchKernelGGL(fold_scan_kernel<false>, dim3(1), dim3(128), 0, stream, rows, shared_row, A.partials, SC.partials, n_blocks, SC.n_masses, (double)A.n_rays);
+    hipLaunchKernelGGL(fold_scan_kernel<false>, dim3(1), dim3(1024), 0, stream, rows, shared_row, A.partials, SC.partials, n_blocks, SC.n_masses, (double)A.n_rays);
   return true;
 }
 

@@ -127,8 +127,9 @@ def main():
                     rt.set_telescope_angles(float("nan"), float(x))
                 else:
                     rt.set_axion_mass(float(x))
-                acc.zero_()
-                p = rt.trace_params(hi - lo, ray_id_offset=i * n_rays + lo, flags=flags, accumulate=True)
+                # accumulate=False: the launch zeroes the accumulator and - fixed64 - fixes the quanta for THIS point (in the gas
+                # stage the weight bound follows the mass)
+                p = rt.trace_params(hi - lo, ray_id_offset=i * n_rays + lo, flags=flags, accumulate=False)
                 rt.trace_histogram_device(p, acc.data_ptr())
                 red = acc if use_cuda else acc.cpu()
                 D.reduce_accumulator(red, dst=0, fixed64=fixed64)
