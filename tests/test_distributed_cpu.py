@@ -333,9 +333,9 @@ def test_a_rank_stuck_at_the_rendezvous_ends_the_launch_with_a_nonzero_exit(tmp_
                         "raise SystemExit(D.launch_ranks_if_needed(3, %r, [%r, '1']))\n" % (ROOT, str(script), mode))
     t0 = time.time()
     r = subprocess.run([sys.executable, str(launcher)], env=_clean_env(SART_BENCH_BACKEND="gloo", SART_RDZV_TIMEOUT="4", SART_RDZV_MARGIN="2"),
-                       capture_output=True, text=True, timeout=120)
+                       capture_output=True, text=True, timeout=400)
     assert r.returncode != 0, (r.stdout, r.stderr)
-    assert time.time() - t0 < 60
+    assert time.time() - t0 < 300      # (seconds here; the margin is for a cold `import torch` in every rank)
     if mode == "inside":
         assert r.returncode == 3 and "never reported their process group up" in r.stderr and "rank 0: rendezvous" in r.stderr
     else:
@@ -349,3 +349,63 @@ def test_report_stage_is_silent_without_a_launcher(tmp_path, monkeypatch):
     monkeypatch.setenv("RANK", "5")
     D.report_stage("up")
     assert (tmp_path / "rank5").read_text() == "up" and D._rank_stages(str(tmp_path), 6)[5] == "up" and D._rank_stages(str(tmp_path), 6)[0] == "nothing"
+
+
+# ---- the fused mass scan's multi-rank shape: every rank its share of the ray ids for ALL masses, one reduce of (K + 1) rows ----
+
+_SCAN_MASSES = (0.0, 0.008235, 0.02)
+
+
+def _scan_rows(o, full, lo, n, seed):
+    """What sart_trace_mass_scan_device leaves in a rank's scan accumulator for the ray ids [lo, lo + n), rebuilt from the CPU
+    oracle (one oracle run per mass on the same ray ids; the mass-independent counters from the first)."""
+    from solaraxionraytracing_amd import _lib
+    rows = np.zeros((len(_SCAN_MASSES) + 1, _lib.SCAN_ROW))
+    for k, m in enumerate(_SCAN_MASSES):
+        s = full.setup.copy()
+        s.m_axion = m
+        summ = o.trace_histogram(n, seed=seed, ray_id_offset=lo, setup=s, n_threads=2)[1]
+        rows[k, _lib.SCAN["SUM_WEIGHTS"]] = summ["SUM_WEIGHTS"]
+        rows[k, _lib.SCAN["SUM_WEIGHTS_SQ"]] = summ["SUM_WEIGHTS_SQ"]
+        rows[k, _lib.SCAN["N_PASSED"]] = summ["N_PASSED"]
+        if k == 0:
+            for name in ("N_RAYS", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_HIT_NICKEL"):
+                rows[len(_SCAN_MASSES), _lib.SCAN_SHARED[name]] = summ[name]
+    return rows
+
+
+def _scan_worker(rank, world, port, n_total, seed, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from tests.conftest import make_setup
+    from oracle.oracle import Oracle
+    D.init_process_group_from_env("gloo")
+    full = make_setup("babyiaxo_xmm_gas")
+    o = Oracle(full)
+    acc = D.trace_sharded(lambda lo, n: _scan_rows(o, full, lo, n, seed).ravel(), n_total, rank, world, dst=0)
+    if rank == 0:
+        np.save(out_path, acc.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_mass_scan_reduce_equals_single_process(tmp_path):
+    """tools/scan.py mass / bench.py --workload babyiaxo_xmm_gas_scan32 on N ranks: shard the ray ids, trace every mass on the
+    shard, ONE reduce of the (K + 1) x 8 scan accumulator.  Counts exact, sums to 1e-12 of a single process; the curve peaks
+    on the resonance."""
+    import solaraxionraytracing_amd as sa
+    from tests.conftest import make_setup
+    from oracle.oracle import Oracle
+    n_total, seed = 20_001, 79
+    out = str(tmp_path / "scan.npy")
+    mp.spawn(_scan_worker, args=(2, 29617, n_total, seed, out), nprocs=2, join=True)
+    full = make_setup("babyiaxo_xmm_gas")
+    one = _scan_rows(Oracle(full), full, 0, n_total, seed)
+    per_mass, shared = sa.split_mass_scan(np.load(out), len(_SCAN_MASSES))
+    ref_mass, ref_shared = sa.split_mass_scan(one.ravel(), len(_SCAN_MASSES))
+    assert shared == ref_shared and shared["N_RAYS"] == n_total
+    assert np.array_equal(per_mass["N_PASSED"], ref_mass["N_PASSED"]) and per_mass["N_PASSED"].min() > 1000
+    np.testing.assert_allclose(per_mass["SUM_WEIGHTS"], ref_mass["SUM_WEIGHTS"], rtol=1e-12)
+    np.testing.assert_allclose(per_mass["SUM_WEIGHTS_SQ"], ref_mass["SUM_WEIGHTS_SQ"], rtol=1e-12)
+    assert int(np.argmax(per_mass["SUM_WEIGHTS"])) == 1
+    assert sa.mass_scan_len(len(_SCAN_MASSES)) == one.size
