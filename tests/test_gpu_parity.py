@@ -500,7 +500,8 @@ def test_xmm_on_axis_effective_area_matches_published_values():
 
 def test_command_line_full_run_and_angular_scan(tmp_path):
     """`python -m solaraxionraytracing_amd` = the reference's `raytracer` binary: full run writes axion_image_IAXO.csv with
-    the reference's columns; --angularScanMin/Max runs performAngularScan."""
+    the reference's columns; --angularScanMin/Max runs performAngularScan; --massScanMin/Max the fused mass scan."""
+    import os
     import subprocess
     import sys
     out = tmp_path / "out"
@@ -516,6 +517,18 @@ def test_command_line_full_run_and_angular_scan(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     scan = np.loadtxt(out / "angular_scan_telescope_y.csv", delimiter=",", skiprows=1)
     assert scan.shape == (3, 3) and scan[0, 2] == 1.0 and scan[2, 2] < 1.0
+    # the third mode (not in the reference): the fused axion-mass scan on a gas-stage config.toml
+    cfg = tmp_path / "config.toml"
+    sample = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "make_nim_parity_kit.py")).read()
+    template = sample.split('CONFIG_TEMPLATE = """')[1].split('"""')[0]
+    cfg.write_text(template % ("BabyIAXO", "InGridIAXO", "gas", "XMM"))
+    r = subprocess.run([sys.executable, "-m", "solaraxionraytracing_amd", "--rays", "300000", "--outpath", str(out), "--config", str(cfg),
+                        "--massScanMin", "0.004", "--massScanMax", "0.012", "--numMassScanPoints", "9"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ms = np.loadtxt(out / "axion_mass_scan.csv", delimiter=",", skiprows=1)
+    assert ms.shape == (9, 5) and ms[:, 4].max() == 1.0 and int(np.argmax(ms[:, 1])) == 4 and np.all(ms[:, 2] < 0.1 * ms[:, 1])
+    assert "maximum at m_a = 0.008 eV" in r.stdout
 
 
 @pytest.mark.parametrize("name", ["babyiaxo_xmm", "cast_llnl", "babyiaxo_xmm_gas", "babyiaxo_xmm_rot"])
