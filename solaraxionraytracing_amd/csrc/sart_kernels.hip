@@ -271,11 +271,45 @@ struct GasRay {
   double eh2p1;       // 1 + exp(-Gamma L)
   double Lnat;        // L in 1 / eV
 };
+// A value the compiler must keep in a vector register from here on (a polynomial's leading coefficient in front of a loop: with
+// -disable-machine-licm nothing hoists the two v_mov_b32 that materialise an f64 constant out of a loop by itself).
+__device__ __forceinline__ double in_vgpr(double x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+// The leading coefficients of the two residual polynomials of the table-based cosine, in vector registers (GasCos::make() in
+// front of the per-mass loop of the scan); the other five are scalar operands of the Horner steps.
+struct GasCos {
+  double s3, d3;
+  static __device__ __forceinline__ GasCos make() { return GasCos{in_vgpr(SC(-0.5992645293207921)), in_vgpr(SC(-1.3352627688545895))}; }
+};
+// cos_any with every Horner step as v_fma_f64 v, v, v, s (fma_vvs): the same operations in the same order as cos_any /
+// sincos_turns<2> - bit for bit the same cosine - but no coefficient is copied into a vector register per evaluation (LLVM
+// otherwise selects v_fmac_f64 and moves each addend into its destination first: 12 v_mov_b32 per mass in the scan's loop, a
+// quarter of its vector instructions).
+__device__ __forceinline__ double cos_any_vvs(double y, const double* __restrict__ table, const GasCos& C) {
+  const double n = __builtin_rint(y * 0.15915494309189535);
+  double f = fma(y, 0.15915494309189535, -n);        // 1 / (2 pi), high part
+  f = fma(y, -9.839338337591243e-18, f);             // low part
+  const double u = fabs(f);                          // cos is even; |f| <= 0.5 + 1e-16
+  const double kf = __builtin_rint(u * 128.0);
+  const double r = fma(-1.0 / 64.0, kf, u * 2.0);
+  const double2 t = reinterpret_cast<const double2*>(table)[(int)kf];
+  const double x = r * r;
+  const double sr = HORNER(HORNER(HORNER(C.s3, x, 2.5501640398773455), x, -5.16771278004997), x, 3.141592653589793) * r;
+  const double cr = fma(HORNER(HORNER(C.d3, x, 4.0587121264167685), x, -4.934802200544679), x, 1.0);
+  double cs = fma(-t.y, sr, t.x * cr);
+  if (!(fabs(y) < 1e15)) {
+    asm volatile("; rare: cos of a huge or non-finite phase");
+    cs = cos(y);
+  }
+  return cs;
+}
 __device__ __forceinline__ double gas_conversion_prob(double dm2_abs, const GasRay& G, double term1, const double* __restrict__ table,
-                                                      const SinCosCoef& K) {
+                                                      const GasCos& C) {
   const double q = dm2_abs * G.inv_two_e;
   const double term2 = frcp(fma(q, q, G.g2q));
-  const double term3 = fma(G.m2eh, cos_any(q * G.Lnat, table, K), G.eh2p1);
+  const double term3 = fma(G.m2eh, cos_any_vvs(q * G.Lnat, table, C), G.eh2p1);
   return (term1 * term2) * term3;
 }
 
@@ -1029,7 +1063,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
         const double g = en.gamma;
         const double eh = exp_neg(-g * Lnat * 0.5);                    // exp(-Gamma L) = eh^2: one exp for both terms
         out.gas = GasRay{en.inv_two_e_ev, g * g * 0.25, -2.0 * eh, fma(eh, eh, 1.0), Lnat};
-        if (RECORDS) prob = gas_conversion_prob(P.gas_dm2_abs, out.gas, P.gas_term1, L.sincos, sincos_coef());
+        if (RECORDS) prob = gas_conversion_prob(P.gas_dm2_abs, out.gas, P.gas_term1, L.sincos, GasCos::make());
         else prob_deferred = true;
       }
       // intensitySuppression2 (axionMassforMagnet.nim:100-113): exp(-mu_pipe d) exp(-mu_magnet L) as one exponential
@@ -1062,7 +1096,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
   if (!(flags & SART_CF_IGNORE_GAS_ABS)) { asm volatile(""); weight *= en.a_gas; }        // :2190-2192
   if (!(flags & SART_CF_XRAY_TEST)) { asm volatile(""); weight *= P.exposure; }           // :2207-2212
   if (!SCAN && prob_deferred) {
-    const double prob = gas_conversion_prob(P.gas_dm2_abs, out.gas, P.gas_term1, L.sincos, sincos_coef());
+    const double prob = gas_conversion_prob(P.gas_dm2_abs, out.gas, P.gas_term1, L.sincos, GasCos::make());
     weight *= prob;
     out.m_till &= ballot64(prob != 0.0);
   }
@@ -1388,12 +1422,13 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)Ab.flags);
         const bool use_prob = !(fl & SART_CF_IGNORE_CONV_PROB) & ((GAS >= 0) ? (GAS == 1) : (__builtin_amdgcn_readfirstlane(Bo.P.stage_gas) != 0));
         const double term1 = Bo.P.gas_term1;
+        const GasCos cos_lead = GasCos::make();      // (two vector register pairs for the whole loop)
         for (int k = 0; k < hdr.n_masses; ++k) {   // wave-uniform
           asm volatile("; hot: per-mass loop of the fused scan");
-          ScanMass M;
+          ScanMass M;   // (staging the table in LDS and reading it one entry ahead instead of this scalar load: -1.5 %, not kept)
           reload_kernarg(M, offsetof(HistKernArgs, SC) + offsetof(ScanArgs, m) + (size_t)k * sizeof(ScanMass));
           double w = out.weight;
-          if (use_prob) w *= gas_conversion_prob(M.dm2_abs, out.gas, term1, L.sincos, sincos_coef());
+          if (use_prob) w *= gas_conversion_prob(M.dm2_abs, out.gas, term1, L.sincos, cos_lead);
           const uint64_t nz = out.m_passed & ballot64(w != 0.0);
           if (nz != out.m_passed) {
             asm volatile("; rare: a conversion probability of exactly zero");
@@ -2065,6 +2100,7 @@ __global__ void math_eval_kernel(int fn, const double* __restrict__ in, double* 
     case 11: r = fsqrt(x); break;
     case 12: r = exp_neg(x); break;
     case 13: r = cos_any(x, tab, K); break;
+    case 14: r = cos_any_vvs(x, tab, GasCos::make()); break;
     default: break;
   }
   out[i] = r;

@@ -126,3 +126,7 @@ def test_gas_stage_exponential_and_cosine():
     assert _eval(13, -y[:1000])[0].tolist() == got[:1000].tolist()          # even
     huge = _eval(13, np.array([3e15, 1e300]))[0]                            # beyond the fast path: the library
     assert abs(huge[0] - float(mp.cos(mp.mpf(3e15)))) < 1e-15 and abs(huge[1]) <= 1.0
+    # the conversion probability's own form of it (cos_any_vvs: every Horner step with a scalar addend) is the same function
+    # bit for bit - the fused mass scan and the single-mass kernels both call that one
+    both = np.concatenate([y, -y[:1000], np.array([3e15, 1e300])])
+    assert np.array_equal(_eval(14, both)[0].view(np.uint64), _eval(13, both)[0].view(np.uint64))
