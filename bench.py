@@ -13,9 +13,10 @@ traces --rays-per-step rays per step; --scaling strong: --rays-per-step is the t
 by distributed.shard_range (BASELINE configs[4]: "1e10 rays across 8 MI355X" = --scaling strong --rays-per-step 1e9
 --steps 10 on 8 ranks).
 
-Roofline block: the kernel is bound by f64 VALU issue, not by HBM.  PMC counters cannot be read from
+Roofline block: in cycles the kernel is nearest to the f64 VALU issue wall, not HBM; the clock the full chip is
+granted (sclk_mhz, ~2.08 of 2.4 GHz) is what rations the cycles.  PMC counters cannot be read from
 inside this process, so the per-ray counter figures come from the committed separate-pass profile of the SAME build
-and workload (profiles/pmc_current.json -> profiles/r03_*_pmc_summary.json, made by tools/pmc_profile.sh +
+and workload (profiles/pmc_current.json -> profiles/<tag>_*_pmc_summary.json, made by tools/pmc_profile.sh +
 tools/pmc_summary.py, which store sart_build_id() of the profiled library) and are combined with the kernel duration
 measured live here with HIP events on the launch stream.  If the library being timed has another build id than the
 profile, every counter-derived field is null and the note says why.
@@ -39,6 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 F64_VALU_PEAK_TFLOPS = 78.6    # 256 CU x 4 SIMD x 16 f64 lanes / clk x 2 flop x 2.4 GHz
+NOMINAL_SCLK_MHZ = 2400.0
 # algorithmic bytes per ray of the REFERENCE's formulation (f64 tables, 11-probe searches, no cache
 # credit).  Informational only: the redesigned path (stage A0, guide tables, LDS-resident tables) needs far fewer bytes,
 # so this figure does not bound the kernel and is no longer used as `achieved`.
@@ -149,10 +151,13 @@ def roofline_block(workload: str, rays_per_launch: float, avg_kernel_s: float, n
            "valu_issue_utilisation": None, "valu_lane_utilisation": None, "valu_insts_per_64_rays": None, "f64_flop_per_ray": None,
            "l2_hit_rate": None, "build_id": lib_id, "pmc_build_id": None, "pmc_source": None,
            "reference_formulation_bytes_per_ray": ref_bytes_per_ray,
-           "note": "bound: the kernel issues f64 vector instructions in valu_issue_utilisation of the SIMDs' cycles (the wall it is "
-                   "nearest to); frac = achieved / peak of the f64 vector pipe is low by construction (a third of the vector "
-                   "instructions are f64 arithmetic) and hbm_frac is the L2-miss traffic of random 4-32-byte gathers fetched as "
-                   "128-byte lines - neither is a wall by itself (DESIGN.md 3.3).  achieved = f64 flop per ray issued (PMC: (2 FMA + "
+           "note": "bound: in cycles the kernel is nearest to the vector-issue wall (valu_issue_utilisation of the SIMDs' cycles "
+                   "issue a vector instruction); the cycles themselves are rationed: with all 256 CUs in this kernel the power "
+                   "management grants sclk_mhz of 2400 (128 CUs of the same kernel run at 2370, profiles/*_power_cu_mask.txt), so what "
+                   "moves the rate is energy per ray (nj_per_ray), DESIGN.md 4.  frac = achieved / peak of the f64 vector pipe at 2.4 "
+                   "GHz is low by construction (42 % of the vector instructions are f64 arithmetic; frac_at_granted_clock: against "
+                   "the peak at sclk_mhz) and hbm_frac is the L2-miss traffic of random 4-32-byte gathers fetched as 128-byte "
+                   "lines - neither is a wall by itself.  achieved = f64 flop per ray issued (PMC: (2 FMA + "
                    "MUL + ADD + TRANS) x 64 lanes / rays) x rays per launch / live HIP-event kernel duration; *_active_lanes = the "
                    "same x valu_lane_utilisation (lanes switched off by EXEC do no work); traffic = fabric bytes per launch "
                    "(TCC_EA0 read requests by size + WRITE_SIZE, Infinity-Cache hits included: upper bound on HBM bytes); "
@@ -364,6 +369,10 @@ def main():
         if world == 1 and not args.profile_run:
             en = energy_block(step, stream, float(rays_rank))
             out["roofline"].update({"socket_power_w": en["socket_power_w"], "sclk_mhz": en["sclk_mhz"], "nj_per_ray": en["nj_per_ray"]})
+            if en["sclk_mhz"] and out["roofline"]["achieved"] is not None:
+                # the peak is a 2.4 GHz figure; with all 256 CUs in this kernel the power management grants ~2.07 GHz
+                peak_granted = F64_VALU_PEAK_TFLOPS * en["sclk_mhz"] / NOMINAL_SCLK_MHZ
+                out["roofline"].update({"peak_at_granted_clock": peak_granted, "frac_at_granted_clock": out["roofline"]["achieved"] / peak_granted})
             out["energy"] = en
             out["cpu_baseline"] = cpu_baseline(full, int(args.cpu_sample), seed)
             if args.workload == "babyiaxo_xmm":
@@ -381,8 +390,8 @@ def main():
 
 
 def energy_block(step, stream, rays_per_step: float, seconds: float = 5.0):
-    """What the counters do not show: the clock the power manager grants this kernel (2.06 of 2.4 GHz at ~1185 W, DESIGN.md
-    3.3).  Outside the timed region the same steps run for `seconds` while rocm-smi is read a few times from a side
+    """What the counters do not show: the clock the power manager grants this kernel (~2.08 of 2.4 GHz at ~1140 W, DESIGN.md
+    4).  Outside the timed region the same steps run for `seconds` while rocm-smi is read a few times from a side
     thread: socket power, shader clock, and the energy per ray they imply at the rate of that window.  Best effort: null
     fields if rocm-smi is not there or may not be read."""
     import re
@@ -419,7 +428,7 @@ def energy_block(step, stream, rays_per_step: float, seconds: float = 5.0):
     rate = k * rays_per_step / dt
     blk = {"socket_power_w": None, "sclk_mhz": None, "nj_per_ray": None, "rays_per_s_sustained": rate, "seconds": dt,
            "note": "rocm-smi beside %d untimed steps; for scale: the socket draws 336 W with all waves asleep and 970 W with "
-                   "v_fma_f64 alone on every SIMD at 2.4 GHz (tools/microbench/energy_rates.hip, DESIGN.md 3.3)" % k}
+                   "v_fma_f64 alone on every SIMD at 2.4 GHz (tools/microbench/energy_rates.hip, DESIGN.md 4)" % k}
     if samples:
         pw = sum(s[0] for s in samples) / len(samples)
         blk.update({"socket_power_w": pw, "sclk_mhz": sum(s[1] for s in samples) / len(samples), "nj_per_ray": pw / rate * 1e9,

@@ -1316,7 +1316,10 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   const bool early_reject = (SCAN && !PATHC) ? false : H.n_zones > 0;
   // chunks of 256 ids aligned in global-id space; `rel` = id - id_base (fits 32 bits: n_rays < 2^31)
   const uint64_t first_chunk = A.ray_id_offset >> 8;
-  const uint64_t id_base = first_chunk << 8;
+  uint64_t id_base = first_chunk << 8;
+  // a value of its own: computed in place it stays a part of the eight-register tuple the launch arguments were loaded into, and a
+  // phase-A pass that wants it back from the spill lanes reloads all eight
+  asm volatile("" : "+s"(id_base));
   const uint32_t rel_begin = (uint32_t)(A.ray_id_offset & 255u);
   const uint32_t rel_end = rel_begin + (uint32_t)A.n_rays;          // one past the last ray (n_rays < 2^31)
   const uint32_t n_chunks = (rel_end + 255u) >> 8;
@@ -1411,6 +1414,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       const DevBlob& Bo = lds_opaque(B);
       HotB HB;
       reload_kernarg(HB, offsetof(HistKernArgs, HB));
+      // (one round trip beside the ring reads above, not a second one in the middle of the pass)
+      asm volatile("" :: "s"(HB.cdf_hi32), "s"(HB.energy_guide), "s"(HB.energy_tab), "s"(HB.refl), "s"(HB.refl_n_angles), "s"(HB.cdf_stride));
       phase_b<false, FAST, GAS, FAST && !ROT && GAS >= 0, SCAN>(Bo.P, L, HB, lds_opaque(Ab), st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
       if constexpr (SCAN) {
         SART_STAGE_MARK("SCAN");
@@ -1468,6 +1473,11 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       // the launch's image parameters, re-read from the kernel arguments (scalar registers, short-lived)
       TraceArgs Al;
       reload_kernarg(Al, offsetof(HistKernArgs, A));
+      // ONE scalar-memory round trip for everything the accumulation reads: left alone the compiler sinks the loads of the tile and
+      // replica parameters into the nested regions that use them - three dependent waits of a scalar load each per pass
+      asm volatile("" :: "s"(Al.replicas), "s"(Al.replica_mask), "s"(Al.replica_stride), "s"(Al.image_nx), "s"(Al.image_ny),
+                   "s"(Al.image_x_min), "s"(Al.image_y_min), "s"(Al.image_inv_step_x), "s"(Al.image_inv_step_y), "s"(Al.spectra),
+                   "s"(Al.tile_x0), "s"(Al.tile_y0), "s"(Al.tile_n));
       long long w_fx = 0;   // FIXED: this ray's weight in quanta (what the image, the sums and the spectra add)
       if constexpr (FIXED) {
         w_fx = to_fixed(out.weight, Al.fx_scale_w);
@@ -1552,6 +1562,20 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     }
   };
 
+  // Zone bounds of stage A0.  The specialised variants have vector registers to spare (<= 113 of 128) and keep the eight bounds
+  // there, one copy per lane, for the whole kernel: the compares read them as they are.  (Re-read from the kernel arguments
+  // per pass - what the generic variants do - every stage-A0 pass waits for a scalar-memory round trip with nothing to put
+  // in front of it; held in scalar registers they would be spilled through VGPR lanes.)
+  constexpr bool kZonesInVgprs = FAST;
+  uint32_t zone_lo_v[kMaxZones], zone_hi_v[kMaxZones];
+#pragma unroll
+  for (int z = 0; z < kMaxZones; ++z) {
+    zone_lo_v[z] = H.zone_lo[z];
+    zone_hi_v[z] = H.zone_hi[z];
+    if (kZonesInVgprs) asm volatile("" : "+v"(zone_lo_v[z]), "+v"(zone_hi_v[z]));   // opaque: stays in a vector register
+  }
+  uint32_t zone_reached_v = H.zone_reached;   // (one v_readfirstlane per pass: a scalar register held across the loop would push another value out)
+  if (kZonesInVgprs) asm volatile("" : "+v"(zone_reached_v));
   uint32_t chunk = (uint32_t)wave_global;                            // relative to first_chunk (wave-uniform)
   const uint32_t lane4 = 4u * (uint32_t)lane;
   uint32_t pass = 0;                                                 // 0..3: which of its four ids a lane handles now
@@ -1580,15 +1604,17 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       if (early_reject) {
         // ---- stage A0: the word against the zones (lane masks and scalar arithmetic only) ----
         ZoneTable Z;
-        reload_zones(Z);
+        if constexpr (!kZonesInVgprs) reload_zones(Z);
+        const uint32_t zone_reached = kZonesInVgprs ? (uint32_t)__builtin_amdgcn_readfirstlane((int)zone_reached_v) : Z.zone_reached;
         // lane masks of direct compares (v_cmp writes them) and scalar arithmetic on the masks; the final mask becomes the
         // EXEC mask of the ring write as it is (inverse ballot), with no per-lane 0 / 1 in between
         uint64_t dead_m = 0, reached_m = 0;
 #pragma unroll
         for (int z = 0; z < kMaxZones; ++z) {   // unused zones are empty: lo > hi
-          const uint64_t in = ballot64(w >= Z.lo[z]) & ballot64(w <= Z.hi[z]);
+          const uint64_t in = kZonesInVgprs ? (ballot64(w >= zone_lo_v[z]) & ballot64(w <= zone_hi_v[z]))
+                                            : (ballot64(w >= Z.lo[z]) & ballot64(w <= Z.hi[z]));
           dead_m |= in;
-          reached_m |= ((Z.zone_reached >> z) & 1u) ? in : 0ull;      // wave-uniform select
+          reached_m |= ((zone_reached >> z) & 1u) ? in : 0ull;      // wave-uniform select
         }
         // all four ids of every lane lie inside the launch for every chunk but the first and the last (wave-uniform test)
         const uint32_t chunk_lo = chunk << 8;

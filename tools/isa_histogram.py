@@ -166,6 +166,7 @@ def histogram(lines):
         d["rare" if rare else "hot"][classify(mn)] += 1 if rare else w
         if not rare and mn.startswith("v_"):
             d["mnemonics"][mn] += w
+        if not rare:
             dump.append((st, classify(mn), text))
     histogram.hot_lines = dump
     histogram.copies = dict(copies)
