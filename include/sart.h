@@ -306,8 +306,8 @@ int sart_set_solar_tables_device(sart_context* ctx, const double* em_rates_devic
 /*
  * Host copies of the sampling tables the context holds, whichever call set them (any pointer may be NULL):
  * flux_radius_cdf_out[n_radii], diff_flux_cdfs_out[n_radii][n_energies], and the library's guide tables
- * radius_guide_out[2049], energy_guide_out[n_radii][2594] (u16; layout in csrc/sart_device.h: kEnergyGuideEntries - for tests
- * and debugging).
+ * radius_guide_out[3074], energy_guide_out[n_radii][2594] (u16; layouts in csrc/sart_device.h: kRadiusGuideEntries,
+ * kEnergyGuideEntries - for tests and debugging).
  */
 int sart_get_solar_tables(sart_context* ctx, double* flux_radius_cdf_out, double* diff_flux_cdfs_out,
                           uint16_t* radius_guide_out, uint16_t* energy_guide_out);

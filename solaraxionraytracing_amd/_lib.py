@@ -33,6 +33,7 @@ CF_XRAY_TEST = 1 << 4
 CF_READ_MAGNET_CONFIG = 1 << 5
 CF_READ_DET_INSTALL_CONFIG = 1 << 6
 
+RADIUS_GUIDE_ENTRIES = 3074   # csrc/sart_device.h: kRadiusGuideEntries (2049 entries of 1/2048 buckets + 1025 of 1/32768 buckets for u >= 31/32)
 ENERGY_GUIDE_ENTRIES = 2594   # csrc/sart_device.h: kEnergyGuideEntries (992 uniform + 1600 logarithmic buckets, bracketed)
 ACCUM_F64, ACCUM_FIXED64 = 0, 1
 ACC_HI = dict(SUM_WEIGHTS=12, SUM_X=13, SUM_Y=14, SUM_R=15, SUM_WEIGHTS_SQ=16)   # SART_ACC_SUM_*_HI: high limbs of the raw FIXED64 accumulator

@@ -1052,11 +1052,16 @@ int sart_set_solar_tables(sart_context* c, const double* rcdf, const double* ecd
   SART_HIP(hipSetDevice(c->device));
   SART_HIP(hipStreamSynchronize(c->stream));
   // guide tables: g[k] = lowerBound(cdf, k / K); lowerBound(cdf, u) for u in [k/K, (k+1)/K) lies in [g[k], g[k+1]]
-  std::vector<uint16_t> rg(kRadiusGuide + 1);
-  for (int k = 0; k <= kRadiusGuide; ++k)
-    rg[k] = static_cast<uint16_t>(std::min<size_t>(lower_bound_idx(rcdf, nR, static_cast<double>(k) / kRadiusGuide), nR - 1));
-  int span = 0;
-  for (int k = 0; k < kRadiusGuide; ++k) span = std::max(span, static_cast<int>(rg[k + 1]) - static_cast<int>(rg[k]));
+  // (radius guide: 2048 buckets, and 1024 finer ones for u >= 31/32 behind them - sart_device.h)
+  std::vector<uint16_t> rg(kRadiusGuideEntries);
+  for (int k = 0; k < kRadiusGuideEntries; ++k) {
+    const double edge = k <= kRadiusGuide ? static_cast<double>(k) / kRadiusGuide
+                                          : 0.96875 + static_cast<double>(k - (kRadiusGuide + 1)) / 32768.0;   // exact
+    rg[k] = static_cast<uint16_t>(std::min<size_t>(lower_bound_idx(rcdf, nR, edge), nR - 1));
+  }
+  int span = 0;   // the widest bracket a draw can meet: buckets of u < 31/32, and the fine ones above
+  for (int k = 0; k < kRadiusGuideEntries - 1; ++k)
+    if (k < kRadiusGuide * 31 / 32 || k > kRadiusGuide) span = std::max(span, static_cast<int>(rg[k + 1]) - static_cast<int>(rg[k]));
   c->radius_span = span;
   // Energy guide (sart_device.h: kEnergyGuide*): entry k of a row brackets bucket k from below, entry k + 1 from above.
   //   k <= Uniform:   lowerBound(row, k / Div)                        buckets [k / Div, (k + 1) / Div), Uniform = Div * 31/32
@@ -1122,7 +1127,7 @@ int sart_set_solar_tables_device(sart_context* c, const double* em_rates_dev, co
   if (int rc = d_status.resize(2)) return rc;
   if (int rc = c->d_rcdf.resize(nR)) return rc;
   if (int rc = c->d_ecdf.resize(static_cast<size_t>(nR) * (static_cast<size_t>(nE) + kEnergyCdfPad))) return rc;
-  if (int rc = c->d_rguide.resize(kRadiusGuide + 1)) return rc;
+  if (int rc = c->d_rguide.resize(kRadiusGuideEntries)) return rc;
   if (int rc = c->d_eguide.resize(static_cast<size_t>(nR) * kEnergyGuideEntries)) return rc;
   if (int rc = c->d_ecdf_hi32.resize(static_cast<size_t>(nR) * (static_cast<size_t>(nE) + kEnergyCdfPad))) return rc;
   c->have_solar = false;                       // until the new tables are known to be CDFs
@@ -1144,7 +1149,7 @@ int sart_set_solar_tables_device(sart_context* c, const double* em_rates_dev, co
   return 0;
 }
 
-static_assert(kEnergyGuideEntries == 2594, "include/sart.h (sart_get_solar_tables) and _lib.py (ENERGY_GUIDE_ENTRIES) state this number");
+static_assert(kEnergyGuideEntries == 2594 && kRadiusGuideEntries == 3074, "include/sart.h (sart_get_solar_tables) and _lib.py (ENERGY_GUIDE_ENTRIES, RADIUS_GUIDE_ENTRIES) state these numbers");
 // Host copies of the sampling tables the context holds (whichever entry point set them).
 int sart_get_solar_tables(sart_context* c, double* rcdf_out, double* ecdf_out, uint16_t* radius_guide_out, uint16_t* energy_guide_out) {
   if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
@@ -1156,7 +1161,7 @@ int sart_get_solar_tables(sart_context* c, double* rcdf_out, double* ecdf_out, u
   if (ecdf_out)   // drop the pad behind every row
     SART_HIP(hipMemcpy2D(ecdf_out, nE * sizeof(double), c->d_ecdf.p, (nE + kEnergyCdfPad) * sizeof(double), nE * sizeof(double), nR,
                          hipMemcpyDeviceToHost));
-  if (radius_guide_out) SART_HIP(hipMemcpy(radius_guide_out, c->d_rguide.p, (kRadiusGuide + 1) * sizeof(uint16_t), hipMemcpyDeviceToHost));
+  if (radius_guide_out) SART_HIP(hipMemcpy(radius_guide_out, c->d_rguide.p, kRadiusGuideEntries * sizeof(uint16_t), hipMemcpyDeviceToHost));
   if (energy_guide_out) SART_HIP(hipMemcpy(energy_guide_out, c->d_eguide.p, nR * kEnergyGuideEntries * sizeof(uint16_t), hipMemcpyDeviceToHost));
   return 0;
 }

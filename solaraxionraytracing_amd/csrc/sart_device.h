@@ -18,6 +18,13 @@ namespace sart {
 constexpr int kMaxShells = 64;
 constexpr int kMaxStrips = 16;       // half the number of window strips that are looped over
 constexpr int kRadiusGuide = 2048;   // buckets of the guide table in front of fluxRadiusCDF
+// The CDF's entries crowd towards 1 (the outer radii emit next to nothing): uniform buckets of 1/2048 hold up to hundreds of them
+// there, and a wave with ONE such lane walks a binary search.  u >= 31/32 therefore has a second guide of 1024 buckets of 1/32768
+// behind the first: entries 0 .. 2048 = lowerBound(cdf, k / 2048), entries 2049 .. 3073 = lowerBound(cdf, 31/32 + j / 32768).
+// With K = floor(u 2^32) (Uniforms::u2_hi): bucket K >> 21, or 2049 + ((K - kRadiusGuideTopStart) >> 17) for K >= kRadiusGuideTopStart.
+constexpr int kRadiusGuideTop = 1024;
+constexpr uint32_t kRadiusGuideTopStart = 0xF8000000u;   // 31/32 of 2^32
+constexpr int kRadiusGuideEntries = kRadiusGuide + 1 + kRadiusGuideTop + 1;   // 3074
 // Guide table in front of every row of diffFluxCDFs (lowerBound of the energy draw, raytracer.nim:464-468).  Buckets in the
 // uniform u of the draw: width 1/kEnergyGuideDiv below u = 31/32; above, where a solar spectrum's CDF creeps towards 1 over hundreds
 // of energies, buckets of constant RELATIVE width in v = 1 - u (64 per octave of v, read off the bits of the double v) down
@@ -92,7 +99,8 @@ struct DevParams {
   double radius_cb, radius_cb_sq, length_b, length_coldbore;
   double pipe1_len, pipe2_len, pipe1_radius_sq;
   int32_t n_radii, n_energies;
-  int32_t radius_span;        // max entries of fluxRadiusCDF between two guide marks (bounded search length)
+  int32_t radius_span;        // max entries of fluxRadiusCDF between two guide marks a draw can meet (informational: the kernel reads four
+                              // candidates and searches on only in a wider bracket)
   int32_t _pad0;
   // ---- X-ray test source (raytracer.nim:1765-1806) ----
   int32_t test_active, test_parallel;
@@ -255,6 +263,10 @@ constexpr int kScanPartialSlots = 4;
 constexpr double kFixedPositionScale = 4294967296.0;        // 2^32 per mm
 constexpr double kFixedReflectScale = 1099511627776.0;      // 2^40
 constexpr int kFixedLimbBits = 40;                          // two-limb sums: value = hi * 2^40 + lo
-constexpr int kImageTileMax = 45;   // 45 x 45 <= 16 waves x 128 doubles of ring-0 space
+// LDS image tile: 16 waves x 128 doubles of ring space (ring 0, or ring 1's path column) + kTileExtraCells doubles behind the tables
+// (what the radius CDF leaves free in LDS as 32-bit words, and the end of the 160 KB): 56 x 56 <= 2048 + 1090 cells
+constexpr int kTileRingCells = 2048;
+constexpr int kTileExtraCells = 1090;
+constexpr int kImageTileMax = 56;
 
 }  // namespace sart

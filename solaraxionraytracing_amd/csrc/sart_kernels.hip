@@ -411,7 +411,8 @@ __device__ __forceinline__ double normal_z_general(const DevParams& P, const She
 // ------------------------------------------------------------------------------------------------
 struct LdsTables {
   const double* sincos;      // (cos, sin)(pi k / 64), k = 0 .. 128
-  const double* rcdf;        // fluxRadiusCDF
+  const uint32_t* rcdf_hi;   // fluxRadiusCDF as the upper 32 of the 52 bits of floor(cdf 2^52), + 1 (stage_tables)
+  const double* rcdf_f64;    // the f64 table in device memory: decides the ties of the 32-bit compare (one draw in ~1e9)
   const uint16_t* rguide;    // guide table in front of it
   const ShellDev* shells;
   const uint8_t* lut;        // radial look-up table of the shell selection
@@ -575,7 +576,14 @@ __device__ __forceinline__ double spoke_measure(int n, double c) {
 // unrotated specialisation multiplies pathCB^2 by 1 + slope^2 itself and needs no square root here).
 // The six uniforms of a ray in the reference's draw order: solar source u0, u1 -> angles of the solar point
 // (:433-434), u2 -> radius CDF (:436), u3 -> disc radius (:418), u4 -> disc angle (:419), u5 -> energy CDF (:464).
-struct Uniforms { double u0, u1, u2, u3, u4, u5; };
+struct Uniforms {
+  double u0, u1, u2, u3, u4, u5;
+  uint32_t u2_hi;   // floor(u2 2^32): the radius draw's guide bucket, and what it compares with the 32-bit copy of the CDF in LDS
+};
+// u2_hi of a uniform that does not come with its random words (the test entry of the record kernel)
+__device__ __forceinline__ uint32_t upper32_of_uniform(double u) {
+  return (uint32_t)(u * 4294967296.0);   // floor(u 2^32), exact for every u in [0, 1)
+}
 struct LaneMasks { uint64_t ok, reached; };   // phase A's verdicts as wave-wide lane masks (see phase_a_core)
 
 template <bool FAST, int ROT, bool ZEXT, bool NOWALL = false>
@@ -600,17 +608,33 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
     sincos_turns<2>(u0, L.sincos, K, &s1, &c1);
     sincos_turns<1>(u1, L.sincos, K, &s2, &c2);
     {
-      // lowerBound(fluxRadiusCDF, u2) (:437) inside the guide bracket; bounded, branch-free walk
-      const int k = (int)(u2 * (double)kRadiusGuide);
-      int lo = (int)L.rguide[k];
-      const int hi = (int)L.rguide[k + 1];
-      if (H.radius_span <= 4) {
-        // four consecutive candidates in ONE round trip to LDS: the table is sorted and rcdf[hi] >= u2, so entries at or
-        // beyond hi never count (the stage pads the table with four entries of 1.0)
-        const double c0 = L.rcdf[lo], c1 = L.rcdf[lo + 1], c2 = L.rcdf[lo + 2], c3 = L.rcdf[lo + 3];
-        lo += (int)(c0 < u2) + (int)(c1 < u2) + (int)(c2 < u2) + (int)(c3 < u2);
-      } else {
-        lo = lower_bound_bracket(L.rcdf, lo, hi, u2);
+      // lowerBound(fluxRadiusCDF, u2) (:437).  K = floor(u2 2^32) picks the guide bucket (sart_device.h: 2048 buckets, and 1024
+      // finer ones for u2 >= 31/32) whose two entries bracket the index.  The table sits in LDS as T' = floor(cdf 2^32) + 1 (half the
+      // bytes of the f64 table: the other half is image tile):  T' < K => cdf < u2;  T' > K + 1 => cdf > u2;  T' in {K, K + 1}:
+      // undecided, 2^-31 per entry looked at - the f64 table in device memory decides.  (The 1.0 pads read 0xFFFFFFFF.)
+      const uint32_t khi = U.u2_hi;
+      const uint32_t kb = khi >> 21, kt = (khi >> 17) - ((kRadiusGuideTopStart >> 17) - (uint32_t)(kRadiusGuide + 1));
+      const uint32_t k = khi >= kRadiusGuideTopStart ? kt : kb;
+      const int lo0 = (int)L.rguide[k];
+      const int hi0 = (int)L.rguide[k + 1];
+      // four consecutive candidates in ONE round trip to LDS: the table is sorted and rcdf[hi] >= u2, so entries at or beyond hi
+      // never count (the stage pads the table with four entries of 1.0)
+      const uint32_t c0 = L.rcdf_hi[lo0], c1 = L.rcdf_hi[lo0 + 1], c2 = L.rcdf_hi[lo0 + 2], c3 = L.rcdf_hi[lo0 + 3];
+      int lo = lo0 + (int)(c0 < khi) + (int)(c1 < khi) + (int)(c2 < khi) + (int)(c3 < khi);
+      // undecided: an entry in {K, K + 1}, i.e. the smallest of the four differences (unsigned: entries below K wrap to huge) < 2
+      bool tie = min(min(c0 - khi, c1 - khi), min(c2 - khi, c3 - khi)) < 2u;
+      if ((c3 < khi) & (hi0 > lo0 + 4)) {
+        asm volatile("; rare: radius bucket wider than four entries");
+        int hi = hi0;
+        while (lo < hi) {   // first entry that is not certainly below u2
+          const int mid = (lo + hi) >> 1;
+          if (L.rcdf_hi[mid] < khi) lo = mid + 1; else hi = mid;
+        }
+        tie = (L.rcdf_hi[lo] - khi) < 2u;   // that entry is undecided (everything behind it is >= it; the four in front were certain)
+      }
+      if (tie) {
+        asm volatile("; rare: a tie in the upper 32 bits of the radius draw");
+        lo = lower_bound_bracket(as_global(L.rcdf_f64), lo0, hi0, u2);
       }
       st.r_idx = lo;
     }
@@ -840,6 +864,7 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, seed_lo, seed_hi);
   Uniforms U;
   U.u2 = u52(b0.x, b0.y);
+  U.u2_hi = b0.x;   // (hi:lo) >> 12 is u2's 52-bit integer; its upper 32 bits are the word itself
   U.u5 = u52(b0.z, b0.w);
   U.u0 = u52(b1.x, b0.y << 20);
   U.u1 = u52(b1.y, b0.w << 20);
@@ -1139,9 +1164,9 @@ constexpr int kQueue = 128;   // ring capacity per wave: < 64 left over + <= 64 
 
 struct __align__(16) TablesLds {
   double sincos[2 * kSinCosEntries];
-  double rcdf[kMaxRadii + 4];   // + four entries of 1.0 behind the table (four-wide candidate read of the radius draw)
+  uint32_t rcdf_hi[kMaxRadii + 4];   // (floor(fluxRadiusCDF 2^52) >> 20) + 1, saturated; + four entries of 1.0 behind the table (four-wide candidate read)
   ShellDev shells[kMaxShells];
-  uint16_t rguide[kRadiusGuide + 8];
+  uint16_t rguide[kRadiusGuideEntries + 6];
   uint8_t lut[kShellLutMax];
 };
 
@@ -1163,8 +1188,12 @@ struct __align__(16) QueueLds {
 template <int BLOCK>
 __device__ __forceinline__ void stage_tables(TablesLds& S, const DevParams& P, const DevTables& T) {
   for (int i = threadIdx.x; i < 2 * kSinCosEntries; i += BLOCK) S.sincos[i] = as_global(T.sincos_tab)[i];
-  for (int i = threadIdx.x; i < P.n_radii + 4; i += BLOCK) S.rcdf[i] = (i < P.n_radii) ? as_global(T.flux_radius_cdf)[i] : 1.0;
-  for (int i = threadIdx.x; i <= kRadiusGuide; i += BLOCK) S.rguide[i] = as_global(T.radius_guide)[i];
+  for (int i = threadIdx.x; i < P.n_radii + 4; i += BLOCK) {   // (cdf_hi32_kernel's definition, sart_tables.hip)
+    const double c = (i < P.n_radii) ? as_global(T.flux_radius_cdf)[i] : 1.0;
+    const unsigned long long t = (__double2ull_rd(c * 4503599627370496.0) >> 20) + 1ull;   // the product is exact: cdf <= 1
+    S.rcdf_hi[i] = t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
+  }
+  for (int i = threadIdx.x; i < kRadiusGuideEntries; i += BLOCK) S.rguide[i] = as_global(T.radius_guide)[i];
   {
     const auto src = as_global(reinterpret_cast<const uint64_t*>(T.shells));
     uint64_t* dst = reinterpret_cast<uint64_t*>(S.shells);
@@ -1268,6 +1297,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   // (the rings are addressed from a per-wave scalar base anyway).
   struct LdsLayout {
     TablesLds S;
+    double tile_extra[kTileExtraCells];   // cells kTileRingCells .. of the image tile
     DevBlob B;
     TraceArgs Ab;
     QueueLds<BLOCK / 64> Q;
@@ -1279,11 +1309,17 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   static_assert(!SCAN || GAS != 0, "a mass scan needs the gas stage");
   static_assert(!SCAN || kScanMaxMasses * 2 * kScanLanes <= (BLOCK / 64) * kQueue, "the scan accumulators live in the image tile's 128 doubles per wave");
   __shared__ uint32_t scan_zero[kScanMaxMasses];   // SCAN: rays whose weight vanishes for one mass only (conversion probability exactly 0)
-  static_assert(kImageTileMax * kImageTileMax <= (BLOCK / 64) * kQueue,
-                "the LDS image tile (host: kImageTileMax) lives in 128 doubles per wave of this workgroup's rings");
-  // cell t of the LDS image tile: 128 doubles per wave, in the space of ring 0 (stage A0 off) or of ring 1's path column (PATHC)
-  auto tile_cell = [&](uint32_t t) -> double* {
+  static_assert((BLOCK / 64) * kQueue == kTileRingCells && kImageTileMax * kImageTileMax <= kTileRingCells + kTileExtraCells,
+                "the LDS image tile (host: kImageTileMax): 128 doubles per wave of this workgroup's rings + the cells behind the tables");
+  static_assert((offsetof(LdsLayout, Q) % 512) == 0, "the rings are addressed with ds_*2st64 offsets (units of 512 bytes for 64-bit columns)");
+  // cell t < kTileRingCells of the tile space: 128 doubles per wave, in the space of ring 0 (stage A0 off) or of ring 1's path
+  // column (PATHC); the scan's accumulators live there
+  auto tile_cell_lo = [&](uint32_t t) -> double* {
     return PATHC ? &Q.w[t >> 7].path[t & 127u] : reinterpret_cast<double*>(&Q.w[t >> 7].ray[0]) + (t & 127u);
+  };
+  // cell t of the LDS image tile: the ring space first, then the cells behind the tables
+  auto tile_cell = [&](uint32_t t) -> double* {
+    return t < (uint32_t)kTileRingCells ? tile_cell_lo(t) : &lds.tile_extra[t - (uint32_t)kTileRingCells];
   };
   // Only the ~20 scalars phase A needs for every ray travel in the kernel arguments (SGPRs); everything
   // else is read from an LDS copy of the parameter blob (broadcast ds_read).  All of them together do not
@@ -1303,10 +1339,11 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     // zeroed rings: a slot that was never written reads as ray 0 / shell 0 / radius 0 / u = 0 instead of arbitrary bits
     uint64_t* q = reinterpret_cast<uint64_t*>(&Q);
     for (int i = threadIdx.x; i < (int)(sizeof(Q) / 8); i += BLOCK) q[i] = 0ull;
+    for (int i = threadIdx.x; i < kTileExtraCells; i += BLOCK) lds.tile_extra[i] = 0.0;
     if (SCAN && threadIdx.x < kScanMaxMasses) scan_zero[threadIdx.x] = 0u;   // (the barrier of stage_tables orders both before their first use)
   }
   stage_tables<BLOCK>(S, Pb, Tb);
-  const LdsTables L{S.sincos, S.rcdf, S.rguide, S.shells, S.lut};
+  const LdsTables L{S.sincos, S.rcdf_hi, Tb.flux_radius_cdf, S.rguide, S.shells, S.lut};
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // wave-uniform: scalar addressing of the rings
@@ -1444,13 +1481,13 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
             // takes a wave's 64-bit atomics in groups of lanes, the two never meet in one group)
             const uint32_t t = (uint32_t)k * (2u * kScanLanes) + ((uint32_t)lane & (kScanLanes - 1u));
             if constexpr (FIXED) {
-              __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell(t)), (unsigned long long)to_fixed(w, M.fx_scale_w),
+              __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell_lo(t)), (unsigned long long)to_fixed(w, M.fx_scale_w),
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell(t + kScanLanes)), (unsigned long long)to_fixed(w * w, M.fx_scale_w2),
+              __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell_lo(t + kScanLanes)), (unsigned long long)to_fixed(w * w, M.fx_scale_w2),
                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
-              __hip_atomic_fetch_add(tile_cell(t), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_fetch_add(tile_cell(t + kScanLanes), w * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_add(tile_cell_lo(t), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_fetch_add(tile_cell_lo(t + kScanLanes), w * w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
           }
         }
@@ -1527,7 +1564,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const uint32_t tn = (uint32_t)Al.tile_n;
         const uint32_t tx = ix - (uint32_t)Al.tile_x0, ty = iy - (uint32_t)Al.tile_y0;   // unsigned: below the origin wraps to huge
         if ((tx < tn) & (ty < tn)) {
-          const uint32_t t = ty * tn + tx;                                   // < 45 * 45 <= 16 x 128
+          const uint32_t t = ty * tn + tx;                                   // < 58 * 58 <= kTileRingCells + kTileExtraCells
           if constexpr (FIXED)
             __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell(t)), (unsigned long long)w_fx, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);                                             // ds_add_u64
@@ -1682,7 +1719,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     for (int k = wave; k < SCarg.n_masses; k += BLOCK / 64) {
       using Sum = std::conditional_t<FIXED, long long, double>;
       Sum* const dst = reinterpret_cast<Sum*>(SCarg.partials) + ((size_t)blockIdx.x * kScanMaxMasses + (size_t)k) * kScanPartialSlots;
-      const double cell = *tile_cell((uint32_t)k * 64u + (uint32_t)lane);
+      const double cell = *tile_cell_lo((uint32_t)k * 64u + (uint32_t)lane);
       Sum v;
       if constexpr (FIXED) v = __double_as_longlong(cell); else v = cell;
 #pragma unroll
@@ -2039,6 +2076,25 @@ constexpr int kRecBlock = 256;
 // `uniforms` != nullptr (sart_internal_trace_records_uniforms, a test entry): ray i takes its six uniforms from
 // uniforms[6 i .. 6 i + 5] (draw order of SURVEY App. B) instead of from its Philox blocks - physics fixtures keyed by
 // explicit uniforms survive a re-mapping of the random stream.
+// One record to memory as 26 eight-byte words.  The two groups of byte-sized fields are packed by hand: a plain struct copy moves
+// their padding arrays, too, and the compiler then keeps those bytes of the local record in scratch memory.
+__device__ __forceinline__ void store_record(sart_axion_t* dst, const sart_axion_t& r) {
+  static_assert(sizeof(sart_axion_t) == 208 && offsetof(sart_axion_t, pointdataX) == 8 && offsetof(sart_axion_t, kinds) == 128 &&
+                    offsetof(sart_axion_t, transProbWindow) == 136 && offsetof(sart_axion_t, shellNumber) == 176,
+                "layout of include/sart.h");
+  uint64_t* o = reinterpret_cast<uint64_t*>(dst);
+  auto bits = [](double v) { return (uint64_t)__double_as_longlong(v); };
+  o[0] = (uint64_t)r.passed | ((uint64_t)r.passedTillWindow << 8) | ((uint64_t)r.hitNickel << 16);
+  o[1] = bits(r.pointdataX); o[2] = bits(r.pointdataY); o[3] = bits(r.pointdataXBefore); o[4] = bits(r.pointdataYBefore);
+  o[5] = bits(r.pointdataR); o[6] = bits(r.weights); o[7] = bits(r.weightsAll); o[8] = bits(r.transmissionMagnet);
+  o[9] = bits(r.yawAngles); o[10] = bits(r.pixvalsX); o[11] = bits(r.pixvalsY); o[12] = bits(r.radii);
+  o[13] = bits(r.energiesAx); o[14] = bits(r.energiesAxAll); o[15] = bits(r.energiesAxWindow);
+  o[16] = (uint64_t)r.kinds | ((uint64_t)r.kindsWindow << 8);
+  o[17] = bits(r.transProbWindow); o[18] = bits(r.transProbArgon); o[19] = bits(r.transProbDetector); o[20] = bits(r.transProbMagnet);
+  o[21] = bits(r.deviationDet); o[22] = (uint64_t)r.shellNumber; o[23] = bits(r.energiesPre); o[24] = bits(r.emratesPre);
+  o[25] = bits(r.reflect);
+}
+
 __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
                                                                    sart_axion_t* __restrict__ out, HotB HB,
                                                                    const double* __restrict__ uniforms) {
@@ -2052,7 +2108,7 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
   }
   const DevParams& P = B.P;
   stage_tables<kRecBlock>(S, P, B.T);
-  const LdsTables L{S.sincos, S.rcdf, S.rguide, S.shells, S.lut};
+  const LdsTables L{S.sincos, S.rcdf_hi, B.T.flux_radius_cdf, S.rguide, S.shells, S.lut};
 
   const uint64_t stride = (uint64_t)gridDim.x * kRecBlock;
   for (uint64_t i = (uint64_t)blockIdx.x * kRecBlock + threadIdx.x; i < A.n_rays; i += stride) {
@@ -2065,7 +2121,7 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
     bool alive;
     if (uniforms) {   // wave-uniform
       const double* u = uniforms + 6 * i;
-      const Uniforms U{u[0], u[1], u[2], u[3], u[4], u[5]};
+      const Uniforms U{u[0], u[1], u[2], u[3], u[4], u[5], upper32_of_uniform(u[2])};
       alive = phase_a_core<false, -1, false>(H, P, L, U, st, sampled, reached, radial, masks);
     } else {
       const uint32_t u3_hi = word_of(stream_block(ray_id >> 2, A.seed_lo, A.seed_hi), (uint32_t)ray_id & 3u);
@@ -2082,7 +2138,7 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
       if (!sampled) { st.u5 = 0.0; st.r_idx = 0; }
       phase_b<true, false, -1, false>(P, L, HB, A, st, e_idx >= 0 ? e_idx : 0, alive, ro, &rec);
     }
-    out[i] = rec;
+    store_record(&out[i], rec);
   }
 }
 

@@ -91,18 +91,24 @@ __device__ __forceinline__ int upper_bound_dev(const double* a, int n, double ke
   return lo;
 }
 
-// ---- radius guide: g[k] = min(lowerBound(rcdf, k / 2048), nR - 1), k = 0 .. 2048; status[1] = the widest bracket ---------
+// ---- radius guide (sart_device.h): g[k] = min(lowerBound(rcdf, k / 2048), nR - 1), k = 0 .. 2048, then
+//      g[2049 + j] = min(lowerBound(rcdf, 31/32 + j / 32768), nR - 1), j = 0 .. 1024; status[1] = the widest bracket a draw can meet
 __global__ __launch_bounds__(256) void radius_guide_kernel(const double* __restrict__ rcdf, int n_radii, uint16_t* __restrict__ guide,
                                                            uint32_t* __restrict__ status) {
-  __shared__ uint16_t g[kRadiusGuide + 1];
-  for (int k = threadIdx.x; k <= kRadiusGuide; k += 256) {
-    const int i = min(lower_bound_dev(rcdf, n_radii, (double)k / (double)kRadiusGuide), n_radii - 1);
+  __shared__ uint16_t g[kRadiusGuideEntries];
+  for (int k = threadIdx.x; k < kRadiusGuideEntries; k += 256) {
+    const double edge = k <= kRadiusGuide ? (double)k / (double)kRadiusGuide
+                                          : 0.96875 + (double)(k - (kRadiusGuide + 1)) / 32768.0;   // exact: multiples of 2^-15
+    const int i = min(lower_bound_dev(rcdf, n_radii, edge), n_radii - 1);
     g[k] = (uint16_t)i;
     guide[k] = (uint16_t)i;
   }
   __syncthreads();
   uint32_t span = 0;
-  for (int k = threadIdx.x; k < kRadiusGuide; k += 256) span = max(span, (uint32_t)((int)g[k + 1] - (int)g[k]));
+  for (int k = threadIdx.x; k < kRadiusGuideEntries - 1; k += 256) {
+    const bool used = k < kRadiusGuide * 31 / 32 || k > kRadiusGuide;   // buckets of u < 31/32, and the fine ones above
+    if (used) span = max(span, (uint32_t)((int)g[k + 1] - (int)g[k]));
+  }
   atomicMax(status + 1, span);
 }
 

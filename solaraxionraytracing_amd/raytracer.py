@@ -262,11 +262,11 @@ class RayTracer:
 
     def solar_tables(self, guides: bool = False):
         """Host copies of (fluxRadiusCDF, diffFluxCDFs) as the context holds them; with ``guides`` also the library's
-        guide tables (radius guide [2049], energy guide [n_radii][_lib.ENERGY_GUIDE_ENTRIES], u16)."""
+        guide tables (radius guide [_lib.RADIUS_GUIDE_ENTRIES], energy guide [n_radii][_lib.ENERGY_GUIDE_ENTRIES], u16)."""
         n_e = self.full.energies.size
         n_r = self._n_radii()
         rcdf, ecdf = np.empty(n_r), np.empty((n_r, n_e))
-        rg = np.empty(2049, dtype=np.uint16) if guides else None
+        rg = np.empty(_lib.RADIUS_GUIDE_ENTRIES, dtype=np.uint16) if guides else None
         eg = np.empty((n_r, _lib.ENERGY_GUIDE_ENTRIES), dtype=np.uint16) if guides else None
         _lib.check(self.lib.sart_get_solar_tables(self.handle, _lib.as_dp(rcdf), _lib.as_dp(ecdf),
                                                   rg.ctypes.data_as(C.c_void_p) if guides else None,
