@@ -157,3 +157,39 @@ def test_energy_draw_on_the_cdf_entries_themselves():
     want = np.maximum(0.03, energies[want_idx])                 # :470-471
     np.testing.assert_array_equal(rec["energiesPre"], want)
     assert len(np.unique(want_idx)) > 1000                      # the whole energy range, not one corner of it
+
+
+def test_radius_draw_on_the_cdf_entries_themselves():
+    """The radius draw compares 32-bit words in LDS (T' = floor(cdf 2^32) + 1 against K = floor(u2 2^32)) inside a guide bracket -
+    2048 buckets of 1/2048 and 1024 of 1/32768 for u2 >= 31/32 -, searches on in a bracket wider than four entries and lets the
+    f64 table in device memory decide ties (sart_kernels.hip: phase_a_core).  Here the uniforms ARE table entries and their f64
+    neighbours - every draw a tie in the upper bits -, drawn from the whole table: the crowded end near 1 (buckets of hundreds of
+    entries), the first buckets, the bulk.  Fed through the explicit-uniform entry to the GPU and to the CPU oracle: the sampled
+    radius sets where the ray starts on the Sun and which CDF row its energy comes from, so a wrong index moves the ray."""
+    from oracle.oracle import Oracle
+    full = full_setup("babyiaxo_xmm")
+    rcdf = full.fluxRadiusCDF
+    rng = np.random.default_rng(23)
+    n = 40_000
+    idx = np.concatenate([rng.integers(0, rcdf.size, n // 2), rng.integers(rcdf.size - 700, rcdf.size, n // 4), rng.integers(0, 40, n // 4)])
+    entry = rcdf[idx]
+    kind = rng.integers(0, 6, n)
+    u2 = np.choose(kind, [entry, np.nextafter(entry, 0.0), np.nextafter(entry, 1.0), entry * (1 - 2.0 ** -40), entry * (1 + 2.0 ** -40),
+                          entry - 2.0 ** -33])
+    u2 = np.clip(u2, 0.0, np.nextafter(1.0, 0.0))
+    want = np.minimum(np.searchsorted(rcdf, u2, side="left"), rcdf.size - 1)
+    assert len(np.unique(want)) > 1500 and (want > rcdf.size - 600).sum() > 5000 and (want < 20).sum() > 2000
+    u = np.column_stack([rng.random(n), rng.random(n), u2, rng.random(n), rng.random(n), rng.random(n)])
+    with sa.RayTracer(full) as rt:
+        rec = rt.trace_records_uniforms(u)
+    ref = Oracle(full, "f64").trace_records_uniforms(u, n_threads=8)
+    # the energy comes from row `want` of diffFluxCDFs with the same u5 on both sides
+    e_want = np.maximum(0.03, full.energies[[min(np.searchsorted(full.diffFluxCDFs[r], x, side="left"), full.energies.size - 1)
+                                              for r, x in zip(want, u[:, 5])]])
+    np.testing.assert_array_equal(rec["energiesPre"], e_want)
+    np.testing.assert_array_equal(rec["energiesPre"], ref["energiesPre"])
+    for k in ("passed", "passedTillWindow", "hitNickel", "shellNumber"):
+        assert (rec[k] != ref[k]).sum() <= 2, k                      # (the f64 oracle's own rounding noise at a cut edge)
+    both = (rec["passedTillWindow"] != 0) & (ref["passedTillWindow"] != 0)
+    assert both.sum() > 1000
+    np.testing.assert_allclose(rec["pointdataXBefore"][both], ref["pointdataXBefore"][both], atol=2e-3)   # a wrong radius index moves the spot by more
