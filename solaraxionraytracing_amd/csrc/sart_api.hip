@@ -210,6 +210,7 @@ struct sart_context {
     int32_t nx = 0, ny = 0;
     double x_min = 0, x_max = 0, y_min = 0, y_max = 0;
     int32_t x0 = 0, y0 = 0, n = 0;
+    bool ring_cells_free = false;   // which of the two tile sizes n was chosen for
   } tile;
   DevBuf<double> d_pilot;
   DevBuf<double> d_pilot_replicas;   // the pilot's own scratch images: the caller's replica buffer keeps its layout
@@ -553,7 +554,7 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   a.image_y_min = p->image_y_min;
   a.image_inv_step_x = 1.0 / ((p->image_x_max - p->image_x_min) / static_cast<double>(p->image_nx));  // :828-830
   a.image_inv_step_y = 1.0 / ((p->image_y_max - p->image_y_min) / static_cast<double>(p->image_ny));
-  a.tile_x0 = a.tile_y0 = a.tile_n = a._pad_tile = 0;
+  a.tile_x0 = a.tile_y0 = a.tile_n = a.tile_base = 0;
   a.spectra = p->spectra ? 1 : 0;
   a.n_radial_bins = 0;
   a.radial_inv_bin = 0.0;
@@ -1438,13 +1439,16 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
       a.replicas = reps.p;
       a.replica_mask = static_cast<uint32_t>(R - 1);
       // No stage A0 (its ring space in LDS is free) or the constant-path variant (the path column of ring 1 is free):
-      // accumulate the centre of the spot in a per-workgroup LDS tile (CAST / LLNL: 65 % of the hits, BabyIAXO / XMM: 29 %).
+      // accumulate the centre of the spot in a per-workgroup LDS tile (56 x 56: CAST / LLNL 82 % of the hits, BabyIAXO / XMM 34 %;
+      // 33 x 33 behind the tables alone for the variants whose rings are all in use: stage A0 on and the path carried).
       // The tile is centred on the spot's centroid, measured once per setup and image binning by a pilot launch of 2e5 rays
       // into a one-pixel image (only SUM_X / SUM_Y / N_PASSED are read).
-      if ((c->hot.n_zones == 0 || variant == 5 || variant == 6) && !c->knobs.no_image_tile && !c->tile.in_pilot) {
+      const bool ring_cells_free = c->hot.n_zones == 0 || variant == 5 || variant == 6;
+      if (!c->knobs.no_image_tile && !c->tile.in_pilot) {
         sart_context::TileCache& t = c->tile;
         const bool same = t.valid && t.nx == p->image_nx && t.ny == p->image_ny && t.x_min == p->image_x_min &&
-                          t.x_max == p->image_x_max && t.y_min == p->image_y_min && t.y_max == p->image_y_max;
+                          t.x_max == p->image_x_max && t.y_min == p->image_y_min && t.y_max == p->image_y_max &&
+                          t.ring_cells_free == ring_cells_free;
         if (!same) {
           t.valid = false;
           t.n = 0;
@@ -1466,10 +1470,11 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
           SART_HIP(hipStreamSynchronize(c->stream));
           t.nx = p->image_nx; t.ny = p->image_ny;
           t.x_min = p->image_x_min; t.x_max = p->image_x_max; t.y_min = p->image_y_min; t.y_max = p->image_y_max;
+          t.ring_cells_free = ring_cells_free;
           if (sc[SART_ACC_N_PASSED] >= 100.0) {
             const double cx = (sc[SART_ACC_SUM_X] / sc[SART_ACC_N_PASSED] - p->image_x_min) * a.image_inv_step_x;
             const double cy = (sc[SART_ACC_SUM_Y] / sc[SART_ACC_N_PASSED] - p->image_y_min) * a.image_inv_step_y;
-            const int n = std::min({static_cast<int>(kImageTileMax), p->image_nx, p->image_ny});
+            const int n = std::min({static_cast<int>(ring_cells_free ? kImageTileMax : kImageTileExtraMax), p->image_nx, p->image_ny});
             const int x0 = std::clamp(static_cast<int>(std::floor(cx)) - n / 2, 0, p->image_nx - n);
             const int y0 = std::clamp(static_cast<int>(std::floor(cy)) - n / 2, 0, p->image_ny - n);
             t.x0 = x0; t.y0 = y0; t.n = n;
@@ -1477,6 +1482,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
           t.valid = true;
         }
         a.tile_x0 = t.x0; a.tile_y0 = t.y0; a.tile_n = t.n;
+        a.tile_base = ring_cells_free ? 0 : kTileRingCells;
       }
     } else {
       a.replicas = acc_dev;

@@ -233,10 +233,12 @@ struct TraceArgs {
   // optional spectra behind the scalars (include/sart.h: sart_accumulator_len_spectra)
   int32_t spectra, n_radial_bins;
   double radial_inv_bin;
-  // Image tile in LDS (small focal spots, stage A0 off: the space of ring 0 is free): pixels [tile_x0, tile_x0 + tile_n) x
-  // [tile_y0, tile_y0 + tile_n) are accumulated per workgroup with ds_add_f64 and flushed once at the end of the kernel;
-  // everything else goes to global atomics as before.  tile_n = 0: off.
-  int32_t tile_x0, tile_y0, tile_n, _pad_tile;
+  // Image tile in LDS: pixels [tile_x0, tile_x0 + tile_n) x [tile_y0, tile_y0 + tile_n) are accumulated per workgroup with
+  // ds_add_f64 and flushed once at the end of the kernel; everything else goes to global atomics.  tile_n = 0: off.  Pixel
+  // (tx, ty) of the tile is cell tile_base + ty tile_n + tx of the tile space (cells 0 .. kTileRingCells - 1: ring 0, free when stage
+  // A0 is off, or ring 1's path column in the constant-path variants; kTileExtraCells more behind the tables): tile_base = 0 and
+  // tile_n <= kImageTileMax when the ring cells are free, else tile_base = kTileRingCells and tile_n <= kImageTileExtraMax.
+  int32_t tile_x0, tile_y0, tile_n, tile_base;
   // SART_ACCUM_FIXED64 (include/sart.h "accumulation mode"): 1 / quantum of the weights and of the squared weights (powers
   // of two); positions use kFixedPositionScale, the reflectivity spectrum kFixedReflectScale.  Unused by the f64 kernels.
   double fx_scale_w, fx_scale_w2;
@@ -268,5 +270,6 @@ constexpr int kFixedLimbBits = 40;                          // two-limb sums: va
 constexpr int kTileRingCells = 2048;
 constexpr int kTileExtraCells = 1090;
 constexpr int kImageTileMax = 56;
+constexpr int kImageTileExtraMax = 33;   // 33 x 33 <= kTileExtraCells: the tile of the variants whose rings are all in use
 
 }  // namespace sart

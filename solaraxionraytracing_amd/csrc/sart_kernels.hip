@@ -1309,7 +1309,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   static_assert(!SCAN || GAS != 0, "a mass scan needs the gas stage");
   static_assert(!SCAN || kScanMaxMasses * 2 * kScanLanes <= (BLOCK / 64) * kQueue, "the scan accumulators live in the image tile's 128 doubles per wave");
   __shared__ uint32_t scan_zero[kScanMaxMasses];   // SCAN: rays whose weight vanishes for one mass only (conversion probability exactly 0)
-  static_assert((BLOCK / 64) * kQueue == kTileRingCells && kImageTileMax * kImageTileMax <= kTileRingCells + kTileExtraCells,
+  static_assert((BLOCK / 64) * kQueue == kTileRingCells && kImageTileMax * kImageTileMax <= kTileRingCells + kTileExtraCells &&
+                    kImageTileExtraMax * kImageTileExtraMax <= kTileExtraCells,
                 "the LDS image tile (host: kImageTileMax): 128 doubles per wave of this workgroup's rings + the cells behind the tables");
   static_assert((offsetof(LdsLayout, Q) % 512) == 0, "the rings are addressed with ds_*2st64 offsets (units of 512 bytes for 64-bit columns)");
   // cell t < kTileRingCells of the tile space: 128 doubles per wave, in the space of ring 0 (stage A0 off) or of ring 1's path
@@ -1514,7 +1515,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       // replica parameters into the nested regions that use them - three dependent waits of a scalar load each per pass
       asm volatile("" :: "s"(Al.replicas), "s"(Al.replica_mask), "s"(Al.replica_stride), "s"(Al.image_nx), "s"(Al.image_ny),
                    "s"(Al.image_x_min), "s"(Al.image_y_min), "s"(Al.image_inv_step_x), "s"(Al.image_inv_step_y), "s"(Al.spectra),
-                   "s"(Al.tile_x0), "s"(Al.tile_y0), "s"(Al.tile_n));
+                   "s"(Al.tile_x0), "s"(Al.tile_y0), "s"(Al.tile_n), "s"(Al.tile_base));
       long long w_fx = 0;   // FIXED: this ray's weight in quanta (what the image, the sums and the spectra add)
       if constexpr (FIXED) {
         w_fx = to_fixed(out.weight, Al.fx_scale_w);
@@ -1564,7 +1565,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         const uint32_t tn = (uint32_t)Al.tile_n;
         const uint32_t tx = ix - (uint32_t)Al.tile_x0, ty = iy - (uint32_t)Al.tile_y0;   // unsigned: below the origin wraps to huge
         if ((tx < tn) & (ty < tn)) {
-          const uint32_t t = ty * tn + tx;                                   // < 58 * 58 <= kTileRingCells + kTileExtraCells
+          const uint32_t t = ty * tn + tx + (uint32_t)Al.tile_base;          // < kTileRingCells + kTileExtraCells (host: tile size per base)
           if constexpr (FIXED)
             __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(tile_cell(t)), (unsigned long long)w_fx, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);                                             // ds_add_u64
@@ -1734,7 +1735,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     const uint32_t tn = (uint32_t)A.tile_n, n_tile = tn * tn;
     double* const img = A.replicas + (size_t)((uint32_t)wave_global & A.replica_mask) * (size_t)A.replica_stride;
     for (uint32_t t = threadIdx.x; t < n_tile; t += BLOCK) {
-      const double v = *tile_cell(t);
+      const double v = *tile_cell(t + (uint32_t)A.tile_base);
       if (__double_as_longlong(v) != 0ll) {   // FIXED: the cell holds an integer; f64: +0.0 is all zero bits, too
         const uint32_t ty = t / tn, tx = t - ty * tn;
         double* const px = &img[(size_t)((uint32_t)A.tile_y0 + ty) * (size_t)A.image_nx + ((uint32_t)A.tile_x0 + tx)];
