@@ -4,7 +4,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 B=/tmp/sart_dbg_build; mkdir -p $B
-cd $ROOT/solaraxionraytracing_amd/csrc
+cd ${SRC:-$ROOT/solaraxionraytracing_amd/csrc}   # SRC: a scratch copy of the sources (tools/exp_rare_counts.sh)
 for f in sart_api sart_kernels sart_emission sart_tables sart_opacity; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-bitwise-instead-of-logical -DSART_DEBUG_KNOBS $1 -mllvm -disable-machine-licm -c -o $B/$f.o $f.hip &
 done
