@@ -374,7 +374,9 @@ int sart_trace_histogram_spectra(sart_context* ctx, const sart_trace_params_t* p
  *            in the gas stage its bound for the context's axion mass, (g B / 2)^2 min(L^2, 4 / (q^2 + Gamma^2 / 4)) maximised
  *            over the energy table - it follows the mass, so a far-off-resonance point resolves as well as the resonance).
  *            headroom_bits (default 27) = log2 of the number of w_bound-weight rays a slot can take before it wraps: a pixel
- *            holds 2^27 = 1.3e8 of them (a 256 x 256 BabyIAXO image reaches that after ~5e12 traced rays); the resolution of one
+ *            holds 2^27 = 1.3e8 of them (measured on the 256 x 256 BabyIAXO / XMM image: the brightest pixel passes 2^62 - where
+ *            the status check starts to fail - after 1.1e12 traced rays and wraps after 2.1e12; with headroom_bits = 31 it
+ *            stands at 2^59.3 after 2.6e12 rays: profiles/r04_v48_fixed64_long_run.txt); the resolution of one
  *            ray's weight is 2^-36 w_bound, and a pixel that n rays hit carries a rounding error of ~q_w sqrt(n / 12): an
  *            image of 2e7 rays agrees with the f64 image to < 1e-12 of its largest pixel, larger images better.
  *            SUM_WEIGHTS_SQ: q = 2^(2 e' - 39) with w_bound < 2^e' (two limbs; the quantum leaves room for the rays of one

@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     }
   };
 
-  // Zone bounds of stage A0.  The specialised variants have vector registers to spare (<= 113 of 128) and keep the eight bounds
+  // Zone bounds of stage A0.  The specialised variants have vector registers to spare (<= 120 of 128) and keep the eight bounds
   // there, one copy per lane, for the whole kernel: the compares read them as they are.  (Re-read from the kernel arguments
   // per pass - what the generic variants do - every stage-A0 pass waits for a scalar-memory round trip with nothing to put
   // in front of it; held in scalar registers they would be spilled through VGPR lanes.)
