@@ -10,17 +10,26 @@ from oracle.oracle import Oracle
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=float, default=1e9)
 ap.add_argument("--chunk", type=float, default=2.5e8, help="rays per oracle call (progress lines in between)")
-ap.add_argument("--workload", default="babyiaxo_xmm", choices=["babyiaxo_xmm", "cast_llnl_gold"], help="BASELINE configs[2] / configs[1]")
+ap.add_argument("--workload", default="babyiaxo_xmm", choices=["babyiaxo_xmm", "cast_llnl_gold", "babyiaxo_xmm_rot", "babyiaxo_xmm_gas"],
+                help="BASELINE configs[2] / configs[1] / one angle bin of configs[3] (rotated, 100 mm chip, effective-area flags) / configs[4]'s gas stage")
 args = ap.parse_args()
 n, chunk = int(args.rays), int(args.chunk)
+from solaraxionraytracing_amd import _lib as L
+flags = None
 if args.workload == "babyiaxo_xmm":
     full = sa.initFullSetup()
-else:
-    from solaraxionraytracing_amd import _lib as L
+elif args.workload == "cast_llnl_gold":
     full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
+elif args.workload == "babyiaxo_xmm_gas":
+    full = sa.initFullSetup(stage=L.SK_GAS)
+else:
+    full = sa.initFullSetup()
+    full.setup.telescope_turned_x_deg, full.setup.telescope_turned_y_deg = 0.02, 0.1
+    full.setup.chip_x_max = full.setup.chip_y_max = 100.0
+    full.flags = flags = L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS | L.CF_IGNORE_CONV_PROB
 t = time.perf_counter()
 with sa.RayTracer(full) as rt:
-    img, s = rt.trace_histogram(n, seed=299792458)
+    img, s = rt.trace_histogram(n, seed=299792458, flags=flags)
 t_gpu = time.perf_counter() - t
 o = Oracle(full)
 oimg = np.zeros_like(img)
@@ -28,7 +37,7 @@ osum = {}
 t = time.perf_counter()
 for off in range(0, n, chunk):
     m = min(chunk, n - off)
-    im, sm, _ = o.trace_histogram(m, seed=299792458, ray_id_offset=off, n_threads=len(os.sched_getaffinity(0)))
+    im, sm, _ = o.trace_histogram(m, seed=299792458, ray_id_offset=off, flags=flags, n_threads=len(os.sched_getaffinity(0)))
     oimg += im
     for k, v in sm.items():
         osum[k] = osum.get(k, 0.0) + v

@@ -37,6 +37,8 @@ for STEP in "$@"; do
     fullsize)   # BASELINE configs[2] / [1] at full size through the HIP path and the f64 CPU oracle + the throughput table + metric 2
       (cd $ROOT && timeout -k 10 300 python tools/full_size_compare.py > gpurun_out/${TAG}_full_size_compare_1e9.json 2> gpurun_out/${TAG}_fsc.err) || { tail -20 $ROOT/gpurun_out/${TAG}_fsc.err; exit 1; }
       (cd $ROOT && timeout -k 10 200 python tools/full_size_compare.py --workload cast_llnl_gold --rays 1e8 > gpurun_out/${TAG}_full_size_compare_cast_1e8.json 2>> gpurun_out/${TAG}_fsc.err)
+      (cd $ROOT && timeout -k 10 200 python tools/full_size_compare.py --workload babyiaxo_xmm_rot --rays 1e8 > gpurun_out/${TAG}_full_size_compare_rot_1e8.json 2>> gpurun_out/${TAG}_fsc.err)
+      (cd $ROOT && timeout -k 10 200 python tools/full_size_compare.py --workload babyiaxo_xmm_gas --rays 1e8 > gpurun_out/${TAG}_full_size_compare_gas_1e8.json 2>> gpurun_out/${TAG}_fsc.err)
       (cd $ROOT && timeout -k 10 200 python tools/throughput_table.py > gpurun_out/${TAG}_throughput_table.md 2>&1 && cat gpurun_out/${TAG}_throughput_table.md)
       (cd $ROOT && timeout -k 10 200 python tools/effarea_rms.py > gpurun_out/${TAG}_effective_area_rms.json 2>> gpurun_out/${TAG}_fsc.err)
       tail -c 400 $ROOT/gpurun_out/${TAG}_full_size_compare_1e9.json ;;
