@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--accumulation", default="f64", choices=["f64", "fixed64"],
                     help="f64 (default): f64 atomics, as the reference adds on the CPU; fixed64: deterministic integer accumulation "
                          "(SART_ACCUM_FIXED64), int64 reduce - image and sums bitwise independent of the number of GPUs")
+    ap.add_argument("--headroom", type=int, default=0,
+                    help="fixed64: bits of headroom (0 = the library's default, 27: one accumulator then lasts ~1e12 BabyIAXO rays; "
+                         "31 carries 2.6e12, profiles/r04_v48_fixed64_long_run.txt)")
     ap.add_argument("--profile-run", action="store_true", help="no CPU baseline / side workloads (run under rocprofv3)")
     ap.add_argument("--preflight", action="store_true",
                     help="first contact with a multi-GPU node: only bring the process group up (RCCL), reduce one 512 KB buffer "
@@ -253,7 +256,7 @@ def main():
     assert stream.cuda_stream != 0
     rt.set_stream(stream.cuda_stream)
     fixed64 = args.accumulation == "fixed64"
-    rt.set_accumulation_mode(args.accumulation)
+    rt.set_accumulation_mode(args.accumulation, args.headroom)
     import numpy as np
     scan_masses = np.linspace(0.0, 0.02, SCAN_MASSES) if args.workload == "babyiaxo_xmm_gas_scan32" else None
     # 8-byte slots: doubles, or int64 in fixed64 mode.  Image accumulator - or, for the m_a scan, (masses + 1) rows of 8 slots
