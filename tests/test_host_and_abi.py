@@ -331,3 +331,23 @@ def test_build_id_names_the_sources_the_library_was_built_from():
         assert bench.pmc_for_this_build("babyiaxo_xmm")[0] is None
     finally:
         bench.load_pmc = orig
+
+
+def test_python_constants_match_the_device_header():
+    """_lib.py repeats a few sizes of csrc/sart_device.h / include/sart.h (buffers that Python allocates for the library):
+    they must be the header's."""
+    from solaraxionraytracing_amd import _lib
+    dev = open(os.path.join(ROOT, "solaraxionraytracing_amd", "csrc", "sart_device.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "sart.h")).read()
+
+    def const(name, text=dev):
+        m = re.search(r"constexpr\s+\w+\s+%s\s*=\s*([^;]+);" % name, text)
+        assert m, name
+        return m.group(1).strip()
+    k_guide, k_top = int(const("kRadiusGuide")), int(const("kRadiusGuideTop"))
+    assert const("kRadiusGuideEntries").replace(" ", "") == "kRadiusGuide+1+kRadiusGuideTop+1"
+    assert _lib.RADIUS_GUIDE_ENTRIES == k_guide + 1 + k_top + 1 == 3074
+    assert "radius_guide_out[%d]" % _lib.RADIUS_GUIDE_ENTRIES in hdr and "[%d]" % _lib.ENERGY_GUIDE_ENTRIES in hdr
+    assert int(const("kImageTileMax")) ** 2 <= int(const("kTileRingCells")) + int(const("kTileExtraCells"))
+    assert int(const("kImageTileExtraMax")) ** 2 <= int(const("kTileExtraCells"))
+    assert _lib.SART_ACC_COUNT == int(re.search(r"SART_ACC_COUNT\s*=\s*(\d+)", hdr).group(1))
