@@ -40,6 +40,14 @@ __global__ __launch_bounds__(1024) void burn(double* out, const double* table, u
         f0 += v.x; f1 += v.y;
       } else if (KIND == 6) {   // v_mul_f64 x 4
         f0 = f0 * f1; f1 = f1 * f2; f2 = f2 * f3; f3 = f3 * f0;
+      } else if (KIND == 7) {   // v_mul_hi_u32 + v_mul_lo_u32 x 4 (+ 4 xor): the two halves of a Philox product as two instructions
+        uint32_t h0, l0, h1, l1, h2, l2, h3, l3;
+        const uint32_t m0 = 0xD2511F53u, m1 = 0xCD9E8D57u;
+        asm volatile("v_mul_hi_u32 %0, %2, %3\n\tv_mul_lo_u32 %1, %2, %3" : "=&v"(h0), "=&v"(l0) : "v"(a0), "s"(m0));
+        asm volatile("v_mul_hi_u32 %0, %2, %3\n\tv_mul_lo_u32 %1, %2, %3" : "=&v"(h1), "=&v"(l1) : "v"(a1), "s"(m1));
+        asm volatile("v_mul_hi_u32 %0, %2, %3\n\tv_mul_lo_u32 %1, %2, %3" : "=&v"(h2), "=&v"(l2) : "v"(a2), "s"(m0));
+        asm volatile("v_mul_hi_u32 %0, %2, %3\n\tv_mul_lo_u32 %1, %2, %3" : "=&v"(h3), "=&v"(l3) : "v"(a3), "s"(m1));
+        a0 = h0 ^ l1; a1 = h1 ^ l2; a2 = h2 ^ l3; a3 = h3 ^ l0;
       }
     }
   }
@@ -80,6 +88,7 @@ int main() {
   run<1>("v_fma_f64", 4, out, table, n_table - 1, 10000000);
   run<6>("v_mul_f64", 4, out, table, n_table - 1, 10000000);
   run<2>("v_mad_u64_u32 (+ as many v_xor)", 4, out, table, n_table - 1, 5000000);
+  run<7>("v_mul_hi_u32 + v_mul_lo_u32 pairs (+ xor)", 4, out, table, n_table - 1, 5000000);
   run<3>("v_xor_b32 + v_add_u32", 8, out, table, n_table - 1, 10000000);
   run<4>("ds_read_b64 gather (x2 per step)", 2, out, table, n_table - 1, 3500000);
   run<5>("global 16 B gather, 128 MB table", 1, out, table, n_table - 1, 60000);
