@@ -55,8 +55,11 @@ WORKLOADS = {
     "babyiaxo_xmm_small_tables": "diagnostic only: the headline workload on 400 x 300 / 200 x 200 tables that stay in every XCD's L2",
     "babyiaxo_xmm_gas_scan32": "fused m_a scan, 32 masses 0 .. 0.02 eV: BabyIAXO + XMM-Newton shells, gas stage, full AGSS09 emission (all "
                                "terms, tables made on the device) - every ray traced once and weighed for every mass (BASELINE configs[4])",
+    "babyiaxo_xmm_ascan16": "fused angular scan, 16 telescope angles 0 .. 0.3 deg: BabyIAXO magnet + XMM-Newton shells, effective-area flags, "
+                            "chip 100 mm - every ray sampled and cut once, turned through every angle (BASELINE configs[3])",
 }
 SCAN_MASSES = 32   # the m_a scan workload: masses linspace(0, 0.02 eV, 32) around m_gamma = 0.008235 eV
+SCAN_ANGLES = 16   # the angular scan workload: telescope_turned_y linspace(0, 0.3 deg, 16) = one kernel launch per pass over the rays
 
 
 def parse():
@@ -99,10 +102,11 @@ def make_setup(workload: str):
         full = sa.initFullSetup(stage=L.SK_GAS)
     elif workload == "babyiaxo_xmm_gas_scan32":
         full = sa.initFullSetup(stage=L.SK_GAS, emission="agss09-device")
-    elif workload == "babyiaxo_xmm_rot":
+    elif workload in ("babyiaxo_xmm_rot", "babyiaxo_xmm_ascan16"):
         full = sa.initFullSetup()
         full.setup.chip_x_max = full.setup.chip_y_max = 100.0
-        full.setup.telescope_turned_y_deg = 0.1
+        if workload == "babyiaxo_xmm_rot":
+            full.setup.telescope_turned_y_deg = 0.1
         flags = L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS | L.CF_IGNORE_CONV_PROB
     else:
         raise ValueError(workload)
@@ -147,7 +151,7 @@ def roofline_block(workload: str, rays_per_launch: float, avg_kernel_s: float, n
     frac_killed = 1.0 - summ["N_SHELL_SELECTED"] / total_rays
     ref_bytes_per_ray = frac_killed * BYTES_KILLED + frac_mirror * BYTES_MIRROR + frac_det * BYTES_DETECTOR
     blk = {"bound": "f64-valu-issue", "achieved": None, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": None,
-           "traffic": None, "kernel": "trace_histogram_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": n_launch,
+           "traffic": None, "kernel": "trace_angular_scan_kernel" if workload == "babyiaxo_xmm_ascan16" else "trace_histogram_kernel", "avg_kernel_ms": avg_kernel_s * 1e3, "launches": n_launch,
            "rays_per_launch": rays_per_launch,
            "hbm_frac": None, "hbm_achieved_gbs": None, "hbm_peak_gbs": HBM_PEAK_GBS, "fabric_bytes_per_ray": None,
            "achieved_active_lanes": None, "frac_active_lanes": None,
@@ -259,18 +263,22 @@ def main():
     rt.set_accumulation_mode(args.accumulation, args.headroom)
     import numpy as np
     scan_masses = np.linspace(0.0, 0.02, SCAN_MASSES) if args.workload == "babyiaxo_xmm_gas_scan32" else None
-    # 8-byte slots: doubles, or int64 in fixed64 mode.  Image accumulator - or, for the m_a scan, (masses + 1) rows of 8 slots
-    acc = torch.zeros(sa.accumulator_len(256) if scan_masses is None else sa.mass_scan_len(SCAN_MASSES), dtype=torch.float64, device=dev)
+    scan_angles = np.linspace(0.0, 0.3, SCAN_ANGLES) if args.workload == "babyiaxo_xmm_ascan16" else None
+    # 8-byte slots: doubles, or int64 in fixed64 mode.  Image accumulator - or, for the scans, (points + 1) rows of 8 slots
+    acc_len = sa.mass_scan_len(SCAN_MASSES) if scan_masses is not None else sa.angular_scan_len(SCAN_ANGLES) if scan_angles is not None else sa.accumulator_len(256)
+    acc = torch.zeros(acc_len, dtype=torch.float64, device=dev)
     seed = 299792458
 
     def step(k: int):
         # global ray ids: step-major, rank-minor => the union over ranks and steps is a contiguous id range
         offset = k * step_total + lo_in_step
         p = rt.trace_params(rays_rank, seed=seed, ray_id_offset=offset, accumulate=True, flags=flags)
-        if scan_masses is None:
-            rt.trace_histogram_device(p, acc.data_ptr())
-        else:
+        if scan_masses is not None:
             rt.trace_mass_scan_device(p, scan_masses, acc.data_ptr())   # one pass over the rays, every mass
+        elif scan_angles is not None:
+            rt.trace_angular_scan_device(p, scan_angles, acc.data_ptr())   # one pass over the rays, every angle
+        else:
+            rt.trace_histogram_device(p, acc.data_ptr())
 
     def barrier():
         if world > 1:
@@ -292,10 +300,12 @@ def main():
     t_red = time.perf_counter()
     D.reduce_accumulator(acc, dst=0, fixed64=fixed64)     # the single RCCL reduce of the output histograms
     if fixed64 and rank == 0:            # raw integer accumulator -> doubles, in place (part of the timed region)
-        if scan_masses is None:
-            rt.finalize_accumulator_device(rt.trace_params(1), acc.data_ptr())
-        else:
+        if scan_masses is not None:
             rt.finalize_mass_scan_device(rt.trace_params(1, flags=flags), scan_masses, acc.data_ptr())
+        elif scan_angles is not None:
+            rt.finalize_angular_scan_device(rt.trace_params(1, flags=flags), SCAN_ANGLES, acc.data_ptr())
+        else:
+            rt.finalize_accumulator_device(rt.trace_params(1), acc.data_ptr())
     barrier()
     t1 = time.perf_counter()
     rt.synchronize()                     # raises what the FIXED64 finalize found (unresolved weights, a wrapped slot)
@@ -318,7 +328,22 @@ def main():
         n_img = 256 * 256
         total_rays = float(args.steps) * step_total
         scan_block = None
-        if scan_masses is None:
+        ascan_block = None
+        if scan_angles is not None:
+            # the scan's own checks: every ray counted once, every angle got weights, the curve falls off with the angle
+            per_angle, shared = sa.split_angular_scan(host, SCAN_ANGLES)
+            assert shared["N_RAYS"] == total_rays, (shared, total_rays)
+            assert per_angle["N_PASSED"].min() > 0 and per_angle["SUM_WEIGHTS"].min() > 0.0
+            assert int(np.argmax(per_angle["SUM_WEIGHTS"])) <= 1 and per_angle["SUM_WEIGHTS"][-1] < per_angle["SUM_WEIGHTS"][0]
+            summ = {"SUM_WEIGHTS": float(per_angle["SUM_WEIGHTS"][0]), "N_PASSED": float(per_angle["N_PASSED"][0]),
+                    "N_PASSED_TILL_WINDOW": float(per_angle["N_PASSED_TILL_WINDOW"].mean()), "N_SHELL_SELECTED": float(per_angle["N_SHELL_SELECTED"].mean()),
+                    "N_REACHED_TELESCOPE": shared["N_REACHED_TELESCOPE"]}
+            img_sum = summ["SUM_WEIGHTS"]
+            ascan_block = {"angles": SCAN_ANGLES, "turned_y_deg": [round(float(a), 6) for a in scan_angles],
+                           "ray_angle_evaluations_per_s": total_rays * SCAN_ANGLES / elapsed_s,
+                           "relative_flux": [round(float(x), 6) for x in per_angle["SUM_WEIGHTS"] / per_angle["SUM_WEIGHTS"].max()],
+                           "relative_error_on_axis": float(np.sqrt(per_angle["SUM_WEIGHTS_SQ"][0]) / per_angle["SUM_WEIGHTS"][0])}
+        elif scan_masses is None:
             summ = {k: float(host[n_img + i]) for k, i in L.ACC.items()}
             assert summ["N_RAYS"] == total_rays, (summ["N_RAYS"], total_rays)
             img_sum = check_image(host, n_img, summ)
@@ -369,6 +394,8 @@ def main():
         }
         if scan_block is not None:
             out["mass_scan"] = scan_block
+        if ascan_block is not None:
+            out["angular_scan"] = ascan_block
         if world == 1 and not args.profile_run:
             en = energy_block(step, stream, float(rays_rank))
             out["roofline"].update({"socket_power_w": en["socket_power_w"], "sclk_mhz": en["sclk_mhz"], "nj_per_ray": en["nj_per_ray"]})
@@ -381,6 +408,7 @@ def main():
             if args.workload == "babyiaxo_xmm":
                 out["other_workloads"] = [other_workload_rate(w) for w in ("cast_llnl_gold", "babyiaxo_xmm_gas", "babyiaxo_xmm_rot")]
                 out["other_workloads"].append(mass_scan_rate())
+                out["other_workloads"].append(angular_scan_rate())
                 out["other_workloads"].append(emission_table_rate())
                 out["deterministic_accumulation"] = fixed64_block(full, value)
                 out["effective_area_rms"] = effective_area_rms()
@@ -504,6 +532,47 @@ def mass_scan_rate(n: int = 1_000_000_000, host_loop_points: int = 4):
             "roofline": roofline_block("babyiaxo_xmm_gas_scan32", float(n), avg_s, n_launch, summ, float(n))}
 
 
+def angular_scan_rate(n: int = 200_000_000, host_loop_points: int = 4):
+    """BASELINE configs[3] through the fused scan kernel: 16 telescope angles on `n` rays, against the reference-shaped host loop
+    (set the angle, re-trace with a flux-only launch, sum: timed on `host_loop_points` of the angles, same ray ids each).
+    Unit: (ray, angle) evaluations per second."""
+    import numpy as np
+    import solaraxionraytracing_amd as sa
+    full, flags = make_setup("babyiaxo_xmm_ascan16")
+    angles = np.linspace(0.0, 0.3, SCAN_ANGLES)
+    with sa.RayTracer(full) as rt:
+        rt.trace_angular_scan(angles, 20_000_000, seed=2, flags=flags)   # clocks up, tables in cache
+        rt.enable_kernel_timing(True)
+        t0 = time.perf_counter()
+        per_angle, shared = rt.trace_angular_scan(angles, n, seed=1, flags=flags)
+        wall = time.perf_counter() - t0
+        ms, n_launch = rt.kernel_timing()
+        pick = np.linspace(1, SCAN_ANGLES - 1, host_loop_points).astype(int)   # (not angle 0: the unrotated kernel)
+        rt.set_telescope_angles(turned_y_deg=float(angles[pick[0]]))
+        rt.trace_flux(50_000_000, seed=2, flags=flags)
+        rt.kernel_timing()                                         # (resets: the warm-up launch is not timed)
+        loop = []
+        for k in pick:
+            rt.set_telescope_angles(turned_y_deg=float(angles[k]))
+            loop.append(rt.trace_flux(n, seed=1, flags=flags)["SUM_WEIGHTS"])
+        ms_loop, n_loop = rt.kernel_timing()
+        rt.set_telescope_angles(turned_y_deg=0.0)
+        rt.enable_kernel_timing(False)
+    assert shared["N_RAYS"] == n and n_launch == 1 and n_loop == host_loop_points
+    rel = np.abs(per_angle["SUM_WEIGHTS"][pick] / np.array(loop) - 1.0).max()
+    assert rel < 1e-12, rel                                        # the same rays, the same weights
+    fused = n * SCAN_ANGLES / (ms / 1e3)
+    host_loop = n / (ms_loop / 1e3 / n_loop)                       # (ray, angle) evaluations per second of one flux-only re-trace per angle
+    avg_s = ms / 1e3 / n_launch
+    summ = {"N_PASSED_TILL_WINDOW": float(per_angle["N_PASSED_TILL_WINDOW"].mean()), "N_SHELL_SELECTED": float(per_angle["N_SHELL_SELECTED"].mean())}
+    return {"workload": WORKLOADS["babyiaxo_xmm_ascan16"], "ray_angle_evaluations_per_s": fused, "rays_per_s": n / (ms / 1e3),
+            "ms_per_scan": ms, "launches_per_scan": n_launch, "wall_ms_per_scan": wall * 1e3,
+            "host_loop_ray_angle_evaluations_per_s": host_loop, "host_loop_ms_per_angle": ms_loop / n_loop,
+            "speedup_over_host_loop": fused / host_loop, "max_rel_diff_to_host_loop": float(rel),
+            "passed_fraction_per_angle": [round(float(x), 5) for x in per_angle["N_PASSED"] / n],
+            "roofline": roofline_block("babyiaxo_xmm_ascan16", float(n), avg_s, n_launch, summ, float(n))}
+
+
 def fixed64_block(full, f64_rate: float, n: int = 1_000_000_000, launches: int = 10):
     """The deterministic accumulation mode (SART_ACCUM_FIXED64: integer atomics, int64 reduce) on the headline workload:
     its rate beside the f64 rate of the line, the distance between the two images, and a bitwise check (the same rays as
@@ -597,8 +666,20 @@ def effective_area_rms(points: int = 8, rays_per_angle: int = 1_000_000):
                                        n_threads=available_cpus())
         cpu[i] = summ["SUM_WEIGHTS"]
     cpu_rel = cpu / cpu.max()
+    # the same curve through the fused scan kernel (every angle on the ray ids [0, rays_per_angle)), against the oracle on those ids
+    with sa.RayTracer(full) as rt:
+        _, _, fused_rel = sa.performAngularScan(rt, 0, 0, 1, rays_per_angle, flags=flags, angles=angles, fused=True)
+    cpu_f = np.empty(points)
+    for i, a in enumerate(angles):
+        s = full.setup.copy()
+        s.telescope_turned_y_deg = float(a)
+        cpu_f[i] = o.trace_histogram(rays_per_angle, flags=flags, setup=s, n_threads=available_cpus())[1]["SUM_WEIGHTS"]
+    cpu_f_rel = cpu_f / cpu_f.max()
     return {"value": float(np.sqrt(np.mean((gpu_rel - cpu_rel) ** 2))), "points": points, "rays_per_angle": rays_per_angle,
-            "gpu_relative_flux": [round(float(x), 6) for x in gpu_rel], "cpu_relative_flux": [round(float(x), 6) for x in cpu_rel]}
+            "gpu_relative_flux": [round(float(x), 6) for x in gpu_rel], "cpu_relative_flux": [round(float(x), 6) for x in cpu_rel],
+            "fused_scan_value": float(np.sqrt(np.mean((fused_rel - cpu_f_rel) ** 2))),
+            "fused_scan_gpu_relative_flux": [round(float(x), 6) for x in fused_rel],
+            "fused_scan_cpu_relative_flux": [round(float(x), 6) for x in cpu_f_rel]}
 
 
 def available_cpus() -> int:

@@ -25,7 +25,8 @@
 extern "C" {
 #endif
 
-#define SART_ABI_VERSION 2   /* 2: SART_ACC_COUNT 16 -> 24 (SUM_WEIGHTS_SQ_HI), fused mass scan, FIXED64 status */
+#define SART_ABI_VERSION 3   /* 2: SART_ACC_COUNT 16 -> 24 (SUM_WEIGHTS_SQ_HI), fused mass scan, FIXED64 status;
+                                3: SART_ERR_ACCUMULATOR, fused angular scan, flux-only launches, accumulator roll-over */
 #define SART_MAX_SHELLS 64
 #define SART_MAX_COATINGS 8
 
@@ -36,7 +37,10 @@ typedef enum sart_status {
   SART_ERR_NOT_READY = -3,      /* setup or tables missing                       */
   SART_ERR_UNSUPPORTED = -4,    /* e.g. telescope kind the reference asserts on  */
   SART_ERR_OUT_OF_MEMORY = -5,
-  SART_ERR_INTERNAL = -6
+  SART_ERR_INTERNAL = -6,
+  SART_ERR_ACCUMULATOR = -7     /* a raw SART_ACCUM_FIXED64 accumulator no longer means what it should: a slot wrapped (or is
+                                   about to), or its quanta do not resolve the weights ("accumulation mode" below) - the
+                                   arguments of the call that reports it are fine */
 } sart_status;
 
 /* ---- enums: numeric values follow the declaration order of the reference ---- */
@@ -201,7 +205,10 @@ typedef struct sart_trace_params_t {
   uint64_t ray_id_offset;  /* global id of ray 0 of this call: counter = offset + i      */
   uint32_t flags;          /* SART_CF_* bitset                                          */
   int32_t image_nx;        /* columns (x bins) of the focal-plane image, 256 in :2629    */
-  int32_t image_ny;        /* rows    (y bins)                                          */
+  int32_t image_ny;        /* rows    (y bins).  image_nx == image_ny == 0: FLUX-ONLY launch - no image is accumulated (no
+                              pixel atomics, no LDS tile, no pilot launch that places it), the accumulator is the
+                              SART_ACC_COUNT scalars (+ spectra) alone and every passed ray counts as outside the image
+                              (N_OUTSIDE_IMAGE = N_PASSED): what a scan that reads SUM_WEIGHTS alone needs (:2800) */
   int32_t accumulate;      /* histogram mode: 0 = zero the accumulator first, 1 = add    */
   double image_x_min, image_x_max;  /* 0 .. ChipXMax in :2622-2625 */
   double image_y_min, image_y_max;
@@ -275,7 +282,7 @@ int sart_create(int device_ordinal, sart_context** out);
 int sart_destroy(sart_context* ctx);
 /* Use an existing HIP stream (hipStream_t cast to void*) for all launches; NULL = the context's own stream. */
 int sart_set_stream(sart_context* ctx, void* hip_stream);
-/* Waits for the context's stream.  Also the place where problems found asynchronously surface: SART_ERR_INVALID_ARGUMENT if a
+/* Waits for the context's stream.  Also the place where problems found asynchronously surface: SART_ERR_ACCUMULATOR if a
  * FIXED64 finalize queued before it found unresolved weights or a wrapped slot ("accumulation mode" below; reported once). */
 int sart_synchronize(sart_context* ctx);
 
@@ -396,7 +403,7 @@ int sart_trace_histogram_spectra(sart_context* ctx, const sart_trace_params_t* p
  *   checks   integers can stop meaning what they should in two ways, and neither passes silently.  The finalize kernels
  *            (sart_finalize_accumulator_device, sart_finalize_mass_scan_device, and the blocking host-output calls, which
  *            finalize internally) examine the raw accumulator and record what they find in a status word of the context;
- *            the next sart_synchronize - and every blocking host-output call - returns SART_ERR_INVALID_ARGUMENT for it:
+ *            the next sart_synchronize - and every blocking host-output call - returns SART_ERR_ACCUMULATOR for it:
  *              unresolved  the accumulated weights average below 2^12 quanta per passed ray (an outlier in a table inflated
  *                          the bound): use a smaller headroom.  Squared weights that average below 2^6 quanta are not an
  *                          error - SUM_WEIGHTS_SQ (an error estimate; nothing else depends on it) then reads NaN.
@@ -448,7 +455,8 @@ int sart_finalize_accumulator_device(sart_context* ctx, const sart_trace_params_
  *   row n_masses       mass-independent counters SART_SCAN_N_* below
  * Only params->n_rays, seed, ray_id_offset, flags and accumulate are read (no image is accumulated).
  * SART_ERR_INVALID_ARGUMENT unless the setup's stage is SART_SK_GAS (the vacuum probability :363-365 has no m_a in it).
- * Masses are processed in groups of 32 per kernel launch (the per-mass accumulators of a workgroup live in LDS).
+ * Masses are processed in groups of 32 per kernel launch (the per-mass accumulators of a workgroup live in LDS), and every
+ * group traces the rays again: a scan of 40 masses costs two traces, one of 64 masses two as well.
  * FIXED64: the quanta of mass k are a function of (setup, tables, flags, headroom, masses_ev[k]) alone - every rank of a
  * multi-GPU job computes the same ones; a reduce is an int64 sum of the raw scan accumulators;
  * sart_finalize_mass_scan_device (same masses) converts to doubles.
@@ -468,6 +476,47 @@ int sart_trace_mass_scan(sart_context* ctx, const sart_trace_params_t* params, c
  * problems are reported by the next sart_synchronize (see "accumulation mode"). */
 int sart_finalize_mass_scan_device(sart_context* ctx, const sart_trace_params_t* params, const double* masses_ev,
                                    int32_t n_masses, const void* scan_fixed_device, double* out_f64_device);
+
+/* ---- fused angular scan (BASELINE configs[3]) ----------------------------- */
+/*
+ * performAngularScan (raytracer.nim:2778-2802) re-runs calculateFluxFractions per telescope angle: it copies the setup, sets
+ * telescope_turned_y (:2796) and traces NumberOfPointsSun fresh rays.  The angle enters a ray at the transformation into the
+ * telescope's frame (:1878-1899) and nowhere before it: sampling from the solar model, the point on the bore exit, bore,
+ * cold-bore exit and the pipe cuts (:1746-1868) do not depend on it.  These entry points take every ray through that part ONCE
+ * and run telescope frame -> opaque structures -> shell selection -> mirrors -> weight once per angle, accumulating per angle
+ * the flux, its sum of squares and four counters - the same ray ids for every angle (common random numbers: the curve's
+ * point-to-point noise is the noise of the weights' differences, not of two samples).  Per angle the results equal a
+ * sart_trace_histogram launch after sart_set_telescope_angles(ctx, NaN, turned_y_deg[k]) on the same ray ids: bit for bit in
+ * SART_ACCUM_FIXED64 (for an angle that leaves the telescope unrotated - turned x and y both 0 - the single launch runs the
+ * unrotated kernel, whose frame change is exact where the rotation by 0 rounds: equal to ~1e-13 then), up to the summation
+ * order in SART_ACCUM_F64.  turned_x stays what the context's setup says; the setup itself is not changed.
+ *
+ * Scan accumulator: (n_angles + 1) rows of SART_ASCAN_ROW 8-byte slots (f64, or int64 when raw SART_ACCUM_FIXED64):
+ *   row k < n_angles   SART_ASCAN_SUM_WEIGHTS, _SUM_WEIGHTS_SQ, _N_PASSED, _N_SHELL_SELECTED, _N_HIT_NICKEL,
+ *                      _N_PASSED_TILL_WINDOW of turned_y_deg[k] (raw FIXED64: + the high limbs _SUM_WEIGHTS_HI / _SQ_HI,
+ *                      value = (hi 2^40 + lo) quantum)
+ *   row n_angles       angle-independent counters SART_ASCAN_N_RAYS, SART_ASCAN_N_REACHED_TELESCOPE
+ * Only params->n_rays, seed, ray_id_offset, flags and accumulate are read (no image is accumulated).
+ * Angles are processed in groups of up to 16 per kernel launch (balanced: 50 angles = 13 + 13 + 12 + 12); every group traces
+ * the rays again.  FIXED64: the quanta are a function of (setup, tables, flags, headroom) alone, the same for every angle and
+ * every rank of a multi-GPU job; a reduce is an int64 sum of the raw scan accumulators; sart_finalize_angular_scan_device
+ * converts to doubles.
+ */
+enum { SART_ASCAN_SUM_WEIGHTS = 0, SART_ASCAN_SUM_WEIGHTS_SQ = 1, SART_ASCAN_N_PASSED = 2, SART_ASCAN_N_SHELL_SELECTED = 3,
+       SART_ASCAN_SUM_WEIGHTS_HI = 4, SART_ASCAN_SUM_WEIGHTS_SQ_HI = 5, SART_ASCAN_N_HIT_NICKEL = 6,
+       SART_ASCAN_N_PASSED_TILL_WINDOW = 7, SART_ASCAN_ROW = 8 };
+enum { SART_ASCAN_N_RAYS = 0, SART_ASCAN_N_REACHED_TELESCOPE = 1 };
+static inline size_t sart_angular_scan_len(int32_t n_angles) { return ((size_t)n_angles + 1u) * (size_t)SART_ASCAN_ROW; }
+/* scan_acc_device: DEVICE memory of sart_angular_scan_len(n_angles) 8-byte slots; asynchronous on the context's stream. */
+int sart_trace_angular_scan_device(sart_context* ctx, const sart_trace_params_t* params, const double* turned_y_deg,
+                                   int32_t n_angles, double* scan_acc_device);
+/* Blocking form with a HOST output of sart_angular_scan_len(n_angles) doubles (finalized in FIXED64 mode). */
+int sart_trace_angular_scan(sart_context* ctx, const sart_trace_params_t* params, const double* turned_y_deg, int32_t n_angles,
+                            double* scan_out_host);
+/* Raw FIXED64 scan accumulator -> doubles (device pointers; in place allowed); asynchronous.  Resolution / overflow
+ * problems are reported by the next sart_synchronize (see "accumulation mode"). */
+int sart_finalize_angular_scan_device(sart_context* ctx, const sart_trace_params_t* params, int32_t n_angles,
+                                      const void* scan_fixed_device, double* out_f64_device);
 
 /* ---- multi-GPU ---------------------------------------------------------- */
 /*

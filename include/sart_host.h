@@ -65,13 +65,22 @@ int sart_host_detector_tables(const double* energy_ev, const double* t_si3n4, co
 int sart_host_trace_axion_wrapper(sart_context* ctx, sart_axion_t* ax_buf, int64_t buf_len,
                                   uint64_t seed, uint64_t ray_id_offset, uint32_t flags);
 
-/* performAngularScan, raytracer.nim:2778-2802: for each angle set telescope_turned_y, trace
- * n_rays_per_angle rays and sum the weights of the passed rays; fluxes_out[i] holds the raw sums,
- * rel_fluxes_out[i] the max-normalised curve (:2801-2802).  Angle i uses ray ids
- * [ray_id_offset + i*n_rays_per_angle, ...). */
+/* performAngularScan, raytracer.nim:2778-2802, in the reference's shape - a host loop: for each angle set
+ * telescope_turned_y, trace n_rays_per_angle FRESH rays (flux-only launches: no image is accumulated) and sum the weights
+ * of the passed rays; fluxes_out[i] holds the raw sums, rel_fluxes_out[i] the max-normalised curve (:2801-2802).  Angle i
+ * uses ray ids [ray_id_offset + i*n_rays_per_angle, ...): independent samples per angle, like the reference's running
+ * random stream.  The context's setup has its own angle back afterwards (the reference scans a copy, :2794-2797). */
 int sart_host_perform_angular_scan(sart_context* ctx, const double* angles_deg, int32_t n_angles,
                                    uint64_t n_rays_per_angle, uint64_t seed, uint64_t ray_id_offset,
                                    uint32_t flags, double* fluxes_out, double* rel_fluxes_out);
+
+/* The same curve through the fused scan kernel (sart_trace_angular_scan, include/sart.h): ONE pass over the ray ids
+ * [ray_id_offset, ray_id_offset + n_rays) - every ray is sampled and taken through bore and pipes once and turned through
+ * every angle; the same rays for all angles (common random numbers).  flux_sq_out[i] (may be NULL) = sum of the squared
+ * weights (Monte-Carlo error of the flux: sqrt), n_passed_out[i] (may be NULL) the passed rays.  The setup is not touched. */
+int sart_host_angular_scan(sart_context* ctx, const double* angles_deg, int32_t n_angles, uint64_t n_rays, uint64_t seed,
+                           uint64_t ray_id_offset, uint32_t flags, double* fluxes_out, double* rel_fluxes_out,
+                           double* flux_sq_out, double* n_passed_out);
 
 /* Axion-mass scan (BASELINE configs[4]; the reference only has the constant mAxion, raytracer.nim:255).
  * Gas stage: ONE pass over the ray ids [ray_id_offset, ray_id_offset + n_rays) through the fused scan kernel

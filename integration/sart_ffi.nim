@@ -17,6 +17,8 @@ const
   SartMaxCoatings = 8   # SART_MAX_COATINGS
   SartAccCount = 24     # SART_ACC_COUNT (ABI version 2)
   SartScanRow = 8       # SART_SCAN_ROW: 8-byte slots per row of a mass-scan accumulator
+  SartAScanRow = 8      # SART_ASCAN_ROW: the same for the fused angular scan (ABI version 3)
+  SartErrAccumulator* = -7   # SART_ERR_ACCUMULATOR: a raw FIXED64 accumulator wrapped / does not resolve the weights
 
 type
   SartContext* {.importc: "sart_context", header: sartH, incompleteStruct.} = object
@@ -129,6 +131,13 @@ proc sart_trace_mass_scan*(ctx: ptr SartContext, p: ptr SartTraceParams, massesE
                            scanOutHost: ptr cdouble): cint {.importc, header: sartH.}
 proc sart_finalize_mass_scan_device*(ctx: ptr SartContext, p: ptr SartTraceParams, massesEv: ptr cdouble, nMasses: int32,
                                      scanFixedDevice: pointer, outF64Device: ptr cdouble): cint {.importc, header: sartH.}
+## fused angular scan: every ray sampled and cut once, turned through nAngles telescope angles; (nAngles + 1) rows of SartAScanRow slots
+proc sart_trace_angular_scan_device*(ctx: ptr SartContext, p: ptr SartTraceParams, turnedYDeg: ptr cdouble, nAngles: int32,
+                                     scanAccDevice: ptr cdouble): cint {.importc, header: sartH.}
+proc sart_trace_angular_scan*(ctx: ptr SartContext, p: ptr SartTraceParams, turnedYDeg: ptr cdouble, nAngles: int32,
+                              scanOutHost: ptr cdouble): cint {.importc, header: sartH.}
+proc sart_finalize_angular_scan_device*(ctx: ptr SartContext, p: ptr SartTraceParams, nAngles: int32, scanFixedDevice: pointer,
+                                        outF64Device: ptr cdouble): cint {.importc, header: sartH.}
 proc sart_reduce_across_devices*(contexts: ptr ptr SartContext, accumulatorsDevice: ptr ptr cdouble, n: int32, nDoubles: csize_t,
                                  root: int32): cint {.importc, header: sartH.}
 proc sart_enable_kernel_timing*(ctx: ptr SartContext, enable: cint): cint {.importc, header: sartH.}
@@ -292,12 +301,30 @@ proc performAngularScanGpu*(ctx: ptr SartContext, angles: seq[float], nRaysPerAn
   ## performAngularScan (:2778-2802): one full run per angle, flux = sum of weights of the passed rays.
   var setup: SartSetup
   sartCheck sart_get_setup(ctx, addr setup)
-  var image: seq[cdouble]
   for i, a in angles:
     sartCheck sart_set_telescope_angles(ctx, NaN, a)       # tel.telescope_turned_y = angle (:2796)
-    let s = traceHistogramGpu(ctx, nRaysPerAngle, flags, image, rayIdOffset = (i * nRaysPerAngle).uint64)
+    var p = sartParams(nRaysPerAngle, flags, rayIdOffset = (i * nRaysPerAngle).uint64)
+    p.image_nx = 0; p.image_ny = 0                         # flux-only launch: the scan reads the sum of the weights alone (:2800)
+    var s: SartSummary
+    sartCheck sart_trace_histogram(ctx, addr p, nil, addr s)
     result.add s.v[AccSumWeights]
   sartCheck sart_set_telescope_angles(ctx, NaN, setup.telescope_turned_y_deg)   # the reference scans a copy (:2794)
+
+proc performAngularScanFusedGpu*(ctx: ptr SartContext, angles: seq[float], nRays: int, flags: set[ConfigFlags],
+                                 seed = 299792458'u64, rayIdOffset = 0'u64): tuple[flux, fluxSq, nPassed: seq[float]] =
+  ## The same curve in ONE pass over the rays (sart_trace_angular_scan): the telescope's angle enters a ray at the
+  ## transformation into the telescope's frame (:1878-1899) and nowhere before it, so every ray is sampled and taken through
+  ## bore and pipes once and turned through every angle.  All angles see the same rays; the context's setup is not changed.
+  doAssert angles.len > 0
+  var p = sartParams(nRays, flags, seed, rayIdOffset)
+  var a = newSeq[cdouble](angles.len)
+  for i, x in angles: a[i] = x
+  var rows = newSeq[cdouble]((angles.len + 1) * SartAScanRow)
+  sartCheck sart_trace_angular_scan(ctx, addr p, addr a[0], a.len.int32, addr rows[0])
+  for k in 0 ..< angles.len:
+    result.flux.add rows[k * SartAScanRow + 0]       # SART_ASCAN_SUM_WEIGHTS (= fluxes[i] of :2800)
+    result.fluxSq.add rows[k * SartAScanRow + 1]     # SART_ASCAN_SUM_WEIGHTS_SQ
+    result.nPassed.add rows[k * SartAScanRow + 2]    # SART_ASCAN_N_PASSED
 
 proc performAxionMassScanGpu*(ctx: ptr SartContext, massesEv: seq[float], nRays: int, flags: set[ConfigFlags],
                                seed = 299792458'u64, rayIdOffset = 0'u64): tuple[flux, fluxSq, nPassed: seq[float]] =

@@ -5,10 +5,10 @@ Python here is plumbing (ctypes + numpy); the product is libsart.so (hand-writte
 libsart_host.so (C++ host mirror of the reference's setup/driver layer).
 """
 from . import _lib, tables  # noqa: F401
-from .raytracer import (FullRaytraceSetup, RayTracer, accumulator_len, calculateFluxFractions, initFullSetup,  # noqa: F401
-                        mass_scan_len, newFullSetup, performAngularScan, performAxionMassScan, performAxionMassScanHostLoop,
-                        split_mass_scan)
+from .raytracer import (FullRaytraceSetup, RayTracer, accumulator_len, angular_scan_len, calculateFluxFractions,  # noqa: F401
+                        initFullSetup, mass_scan_len, newFullSetup, performAngularScan, performAxionMassScan,
+                        performAxionMassScanHostLoop, split_angular_scan, split_mass_scan)
 
-__all__ = ["FullRaytraceSetup", "RayTracer", "accumulator_len", "calculateFluxFractions", "initFullSetup", "mass_scan_len",
-           "newFullSetup", "performAngularScan", "performAxionMassScan", "performAxionMassScanHostLoop", "split_mass_scan",
-           "tables"]
+__all__ = ["FullRaytraceSetup", "RayTracer", "accumulator_len", "angular_scan_len", "calculateFluxFractions", "initFullSetup",
+           "mass_scan_len", "newFullSetup", "performAngularScan", "performAxionMassScan", "performAxionMassScanHostLoop",
+           "split_angular_scan", "split_mass_scan", "tables"]

@@ -16,7 +16,7 @@ LIBSART_HOST_PATH = os.path.join(_PKG_DIR, "libsart_host.so")
 SART_MAX_SHELLS = 64
 SART_MAX_COATINGS = 8
 SART_ACC_COUNT = 24
-SART_ABI_VERSION = 2
+SART_ABI_VERSION = 3
 
 # enums (values of include/sart.h)
 ES_CAST, ES_BABYIAXO = 0, 1
@@ -42,12 +42,19 @@ SCAN_ROW = 8
 SCAN = dict(SUM_WEIGHTS=0, SUM_WEIGHTS_SQ=1, N_PASSED=2)
 SCAN_HI = dict(SUM_WEIGHTS=4, SUM_WEIGHTS_SQ=5)
 SCAN_SHARED = dict(N_RAYS=0, N_REACHED_TELESCOPE=1, N_SHELL_SELECTED=2, N_HIT_NICKEL=3, N_ON_DETECTOR=4)
+# fused angular scan (include/sart.h: SART_ASCAN_*): (n_angles + 1) rows of ASCAN_ROW slots; the last row holds the counters of ASCAN_SHARED
+ASCAN_ROW = 8
+ASCAN = dict(SUM_WEIGHTS=0, SUM_WEIGHTS_SQ=1, N_PASSED=2, N_SHELL_SELECTED=3, N_HIT_NICKEL=6, N_PASSED_TILL_WINDOW=7)
+ASCAN_HI = dict(SUM_WEIGHTS=4, SUM_WEIGHTS_SQ=5)
+ASCAN_SHARED = dict(N_RAYS=0, N_REACHED_TELESCOPE=1)
+ASCAN_MAX_ANGLES = 16   # csrc/sart_device.h: kAScanMaxAngles (angles per kernel launch)
 FIXED_LIMB_BITS = 40
 
 ACC = dict(SUM_WEIGHTS=0, N_PASSED=1, N_PASSED_TILL_WINDOW=2, N_HIT_NICKEL=3, SUM_X=4, SUM_Y=5, SUM_R=6,
            SUM_WEIGHTS_SQ=7, N_RAYS=8, N_REACHED_TELESCOPE=9, N_SHELL_SELECTED=10, N_OUTSIDE_IMAGE=11)
 
 SART_ERR_INVALID_ARGUMENT, SART_ERR_NO_DEVICE = -1, -2
+SART_ERR_NOT_READY, SART_ERR_UNSUPPORTED, SART_ERR_OUT_OF_MEMORY, SART_ERR_INTERNAL, SART_ERR_ACCUMULATOR = -3, -4, -5, -6, -7
 
 _d = C.c_double
 _i = C.c_int32
@@ -198,6 +205,9 @@ SART_SYMBOLS = {
     "sart_trace_mass_scan_device": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _i, C.c_void_p]),
     "sart_trace_mass_scan": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _i, _dp]),
     "sart_finalize_mass_scan_device": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _i, C.c_void_p, C.c_void_p]),
+    "sart_trace_angular_scan_device": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _i, C.c_void_p]),
+    "sart_trace_angular_scan": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _i, _dp]),
+    "sart_finalize_angular_scan_device": (C.c_int, [C.c_void_p, _P(TraceParams), _i, C.c_void_p, C.c_void_p]),
     "sart_reduce_across_devices": (C.c_int, [_P(C.c_void_p), _P(C.c_void_p), _i, C.c_size_t, _i]),
     "sart_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "sart_get_kernel_timing": (C.c_int, [C.c_void_p, _dp, _P(C.c_int64)]),
@@ -227,6 +237,7 @@ SART_HOST_SYMBOLS = {
     "sart_host_detector_tables": (C.c_int, [_dp, _dp, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _dp, _dp, _dp]),
     "sart_host_perform_axion_mass_scan": (C.c_int, [C.c_void_p, _dp, _i, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _dp]),
     "sart_host_axion_mass_scan": (C.c_int, [C.c_void_p, _dp, _i, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _dp, _dp, _dp]),
+    "sart_host_angular_scan": (C.c_int, [C.c_void_p, _dp, _i, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _dp, _dp, _dp, _dp]),
     "sart_host_h5_reflectivity_info": (C.c_int, [C.c_char_p, _P(_i), _P(_i), _P(_i), _dp, _dp, _dp, _dp]),
     "sart_host_h5_read_reflectivity": (C.c_int, [C.c_char_p, _dp]),
     "sart_host_h5_write_reflectivity": (C.c_int, [C.c_char_p, _i, _i, _i, _dp, _dp, _dp]),

@@ -431,8 +431,7 @@ int sart_host_perform_angular_scan(sart_context* ctx, const double* angles_deg, 
   p.n_rays = n_rays_per_angle;
   p.seed = seed;
   p.flags = flags;
-  p.image_nx = 256; p.image_ny = 256;  // heatmaptable2 :2629, over 0 .. ChipXMax / ChipYMax :2622-2625
-  p.image_x_min = 0.0; p.image_x_max = setup.chip_x_max; p.image_y_min = 0.0; p.image_y_max = setup.chip_y_max;
+  p.image_nx = 0; p.image_ny = 0;  // flux-only launches: the scan reads the sum of the weights alone (:2800), no image, no tile, no pilot
   // The reference scans a copy of fullSetup (`var tel = fullSetup.expSetup.telescope`, :2794-2797): the caller's setup is
   // unchanged afterwards.  Here the context is the setup, so the original angle is put back on every way out.
   int rc_scan = 0;
@@ -454,6 +453,32 @@ int sart_host_perform_angular_scan(sart_context* ctx, const double* angles_deg, 
     for (int32_t i = 1; i < n_angles; ++i) maxFlux = std::max(maxFlux, fluxes_out[i]);
     for (int32_t i = 0; i < n_angles; ++i) rel_fluxes_out[i] = fluxes_out[i] / maxFlux;
   }
+  return 0;
+}
+
+int sart_host_angular_scan(sart_context* ctx, const double* angles_deg, int32_t n_angles, uint64_t n_rays, uint64_t seed,
+                           uint64_t ray_id_offset, uint32_t flags, double* fluxes_out, double* rel_fluxes_out, double* flux_sq_out,
+                           double* n_passed_out) {
+  if (!ctx || !angles_deg || n_angles < 1 || !fluxes_out)
+    return fail(SART_ERR_INVALID_ARGUMENT, "sart_host_angular_scan: bad argument");
+  sart_trace_params_t p;
+  std::memset(&p, 0, sizeof p);
+  p.n_rays = n_rays;
+  p.seed = seed;
+  p.ray_id_offset = ray_id_offset;
+  p.flags = flags;
+  std::vector<double> rows(sart_angular_scan_len(n_angles));
+  if (int rc = sart_trace_angular_scan(ctx, &p, angles_deg, n_angles, rows.data())) { g_err = sart_last_error(); return rc; }
+  double maxFlux = 0.0;
+  for (int32_t i = 0; i < n_angles; ++i) {
+    const double* r = rows.data() + static_cast<size_t>(i) * SART_ASCAN_ROW;
+    fluxes_out[i] = r[SART_ASCAN_SUM_WEIGHTS];   // axions.filterIt(it.passed).mapIt(it.weights).sum() :2800
+    if (flux_sq_out) flux_sq_out[i] = r[SART_ASCAN_SUM_WEIGHTS_SQ];
+    if (n_passed_out) n_passed_out[i] = r[SART_ASCAN_N_PASSED];
+    maxFlux = (i == 0) ? fluxes_out[0] : std::max(maxFlux, fluxes_out[i]);
+  }
+  if (rel_fluxes_out)  // :2801-2802
+    for (int32_t i = 0; i < n_angles; ++i) rel_fluxes_out[i] = fluxes_out[i] / maxFlux;
   return 0;
 }
 

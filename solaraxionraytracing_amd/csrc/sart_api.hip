@@ -33,7 +33,10 @@ size_t fixed_check_bytes();
 bool launch_trace_mass_scan(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, const ScanArgs& SC, double* rows,
                             double* shared_row, int n_blocks, hipStream_t stream, int variant, bool fixed);
 void launch_finalize_scan(const void* in, double* out, int n_masses, const double* q_w, const double* q_w2, int shared_row,
-                          void* check_dev, hipStream_t stream);
+                          void* check_dev, hipStream_t stream, uint32_t counter_slots);
+void launch_trace_angular_scan(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, const AScanArgs& AN, double* rows,
+                               double* shared_row, int n_blocks, hipStream_t stream, bool fast, bool fixed);
+int angular_scan_blocks_per_cu(bool fast);
 int histogram_block_of(int variant);
 void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream, const double* uniforms_dev);
@@ -143,7 +146,7 @@ size_t lower_bound_idx(const double* a, size_t n, double key) {
 struct sart_context {
   int device = 0;
   int n_cu = 0;
-  int blocks_per_cu_hist[7] = {0, 0, 0, 0, 0, 0, 0}, blocks_per_cu_rec = 0;
+  int blocks_per_cu_hist[7] = {0, 0, 0, 0, 0, 0, 0}, blocks_per_cu_rec = 0, blocks_per_cu_ascan[2] = {0, 0};
   // tuning / experiment knobs, read from the environment once when the context is created
   struct Knobs {
 #ifdef SART_DEBUG_KNOBS              // experiment builds only (make DEBUG_KNOBS=1); compiled out of the shipped library
@@ -232,6 +235,7 @@ struct sart_context {
   bool status_pending = false;
   // fused mass scan: per-workgroup per-mass partial sums, scratch accumulators of the blocking call
   DevBuf<double> d_scan_partials, d_scan, d_scan_fin;
+  DevBuf<double> d_ascan_partials;   // fused angular scan: per-workgroup per-angle partial sums
 
   // timing
   bool timing = false;
@@ -531,7 +535,8 @@ int refresh_derived(sart_context* c) {
 
 int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   if (!p) return fail(SART_ERR_INVALID_ARGUMENT, "params is NULL");
-  if (p->image_nx < 1 || p->image_ny < 1 || !(p->image_x_max > p->image_x_min) || !(p->image_y_max > p->image_y_min))
+  const bool no_image = p->image_nx == 0 && p->image_ny == 0;   // flux-only launch (include/sart.h: sart_trace_params_t)
+  if (!no_image && (p->image_nx < 1 || p->image_ny < 1 || !(p->image_x_max > p->image_x_min) || !(p->image_y_max > p->image_y_min)))
     return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
   if (static_cast<int64_t>(p->image_nx) * static_cast<int64_t>(p->image_ny) >= (int64_t(1) << 29))
     return fail(SART_ERR_INVALID_ARGUMENT, "image_nx * image_ny must be below 2^29 (pixel byte offsets are 32-bit on the device)");
@@ -554,6 +559,10 @@ int make_args(sart_context* c, const sart_trace_params_t* p, TraceArgs& a) {
   a.image_y_min = p->image_y_min;
   a.image_inv_step_x = 1.0 / ((p->image_x_max - p->image_x_min) / static_cast<double>(p->image_nx));  // :828-830
   a.image_inv_step_y = 1.0 / ((p->image_y_max - p->image_y_min) / static_cast<double>(p->image_ny));
+  if (no_image) {   // zero columns and rows: the kernel's bounds test `0 <= t < n` fails for every ray - no pixel, no atomic, no tile
+    a.image_x_min = a.image_y_min = 0.0;
+    a.image_inv_step_x = a.image_inv_step_y = 0.0;
+  }
   a.tile_x0 = a.tile_y0 = a.tile_n = a.tile_base = 0;
   a.spectra = p->spectra ? 1 : 0;
   a.n_radial_bins = 0;
@@ -878,7 +887,7 @@ int status_take(sart_context* c) {   // the stream has been synchronised
                       "was zeroed (use a larger headroom, or finalize and start a new accumulator earlier);";
   if (st & 2u) msg += " the accumulated weights average below 2^12 quanta per passed ray (bound " + std::to_string(c->weight_bound) +
                       ": an outlier in a table inflated it) - choose a smaller headroom or SART_ACCUM_F64;";
-  return fail(SART_ERR_INVALID_ARGUMENT, msg);
+  return fail(SART_ERR_ACCUMULATOR, msg);
 }
 
 // Used by the other translation units of libsart.so (sart_emission.hip); not part of the C-ABI.
@@ -1418,6 +1427,7 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
     // Measured on CAST / LLNL (88 % of all rays land within ~30 pixels): 1 replica 12.4 ms per 1e8 rays, 16: 5.5, 64: 4.4,
     // 128: 4.4, 512: 4.6 (3.99 ms with the atomics switched off).
     int R = spot_px > 96.0 ? 8 : 64;
+    if (p->image_nx == 0) R = 1;      // flux-only launch: no image, so no scratch copies, no LDS tile, no pilot launch
     if (static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny) > (1u << 20)) R = std::min(R, 1);   // heat maps of millions of pixels: no scratch copies
     if (s.test_active) R = 64;
     if (c->knobs.image_replicas > 0) R = std::min(kMaxImageReplicas, c->knobs.image_replicas);
@@ -1516,7 +1526,7 @@ int sart_trace_histogram_spectra(sart_context* c, const sart_trace_params_t* p, 
                                  double* spectra_out) {
   if (!c || !p) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
   SART_HIP(hipSetDevice(c->device));
-  if (p->image_nx < 1 || p->image_ny < 1) return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
+  if ((p->image_nx < 1 || p->image_ny < 1) && !(p->image_nx == 0 && p->image_ny == 0)) return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
   if (p->spectra && (p->n_radial_bins < 1 || !c->have_solar)) return fail(SART_ERR_INVALID_ARGUMENT, "invalid spectra specification");
   const size_t len = acc_len_of(c, p);
   const bool fresh = (c->d_acc.n != len) || !c->d_acc.p || c->d_acc_stale;
@@ -1532,7 +1542,7 @@ int sart_trace_histogram_spectra(sart_context* c, const sart_trace_params_t* p, 
     if (int rc = sart_finalize_accumulator_device(c, p, c->d_acc.p, c->d_fin.p)) return rc;
     src = c->d_fin.p;
   }
-  if (image_out) SART_HIP(hipMemcpyAsync(image_out, src, nimg * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (image_out && nimg) SART_HIP(hipMemcpyAsync(image_out, src, nimg * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (summary)
     SART_HIP(hipMemcpyAsync(summary->v, src + nimg, SART_ACC_COUNT * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (spectra_out && p->spectra)
@@ -1578,7 +1588,7 @@ int sart_get_fixed_quanta(sart_context* c, sart_fixed_quanta_t* out) {
 
 int sart_finalize_accumulator_device(sart_context* c, const sart_trace_params_t* p, const void* acc_fixed_dev, double* out_dev) {
   if (!c || !p || !acc_fixed_dev || !out_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
-  if (p->image_nx < 1 || p->image_ny < 1 || (p->spectra && p->n_radial_bins < 1))
+  if (((p->image_nx < 1 || p->image_ny < 1) && !(p->image_nx == 0 && p->image_ny == 0)) || (p->spectra && p->n_radial_bins < 1))
     return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
   if (!c->quanta_frozen) return fail(SART_ERR_NOT_READY, "no FIXED64 launch has fixed the quanta yet");
   SART_HIP(hipSetDevice(c->device));
@@ -1699,7 +1709,7 @@ int sart_finalize_mass_scan_device(sart_context* c, const sart_trace_params_t* p
     }
     const size_t off = static_cast<size_t>(k0) * SART_SCAN_ROW;
     launch_finalize_scan(static_cast<const long long*>(raw_dev) + off, out_dev + off, n, q_w, q_w2,
-                         (k0 + n == n_masses) ? n : -1, c->d_status.p, c->stream);   // the counter row sits behind the last group
+                         (k0 + n == n_masses) ? n : -1, c->d_status.p, c->stream, 1u << SART_SCAN_N_PASSED);   // the counter row sits behind the last group
     SART_HIP(hipGetLastError());
   }
   return status_enqueue_copy(c);
@@ -1718,6 +1728,160 @@ int sart_trace_mass_scan(sart_context* c, const sart_trace_params_t* p, const do
   if (c->accum_mode == SART_ACCUM_FIXED64) {
     if (int rc = c->d_scan_fin.resize(len)) return rc;
     if (int rc = sart_finalize_mass_scan_device(c, p, masses, n_masses, c->d_scan.p, c->d_scan_fin.p)) return rc;
+    src = c->d_scan_fin.p;
+  }
+  SART_HIP(hipMemcpyAsync(out_host, src, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  return status_take(c);
+}
+
+// ---- fused angular scan (include/sart.h) ---------------------------------------------------------------------------------------
+namespace {
+
+int ascan_check(sart_context* c, const sart_trace_params_t* p, int32_t n) {
+  if (!c || !p) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (n < 1 || n > 65536) return fail(SART_ERR_INVALID_ARGUMENT, "n_angles must be in [1, 65536]");
+  return 0;
+}
+
+// The rotation and the bounds that follow it for telescope_turned_y = angle_y_deg, with the expressions of hoist_setup() /
+// sync_blob() (a single-angle launch after sart_set_telescope_angles computes the same bits).
+AScanAngle ascan_angle_of(const sart_context* c, double angle_y_deg) {
+  const sart_setup_t& s = c->setup;
+  AScanAngle a;
+  std::memset(&a, 0, sizeof a);
+  const double turnedX = deg2rad(s.telescope_turned_x_deg), turnedY = deg2rad(angle_y_deg);
+  a.rx_c = std::cos(turnedX); a.rx_s = std::sin(turnedX);
+  a.ry_c = std::cos(turnedY); a.ry_s = std::sin(turnedY);
+  a.half_length_telescope = c->params.half_length_telescope;
+  DevParams P = c->params;   // what shell0_miss_radius_of reads of the rotation
+  P.rotated = (s.telescope_turned_x_deg != 0.0 || angle_y_deg != 0.0) ? 1 : 0;
+  P.rx_c = a.rx_c; P.rx_s = a.rx_s; P.ry_c = a.ry_c; P.ry_s = a.ry_s;
+  a.shell0_miss_radius = (c->knobs.no_sure_miss || c->knobs.no_early_reject) ? -1.0 : shell0_miss_radius_of(s, P, c->n_radii);
+  a.mx = a.rx_s;
+  a.my = -a.rx_c * a.ry_s;
+  a.mz = a.rx_c * a.ry_c;
+  return a;
+}
+
+}  // namespace
+
+int sart_trace_angular_scan_device(sart_context* c, const sart_trace_params_t* p, const double* turned_y_deg, int32_t n_angles,
+                                   double* scan_dev) {
+  if (int rc = ascan_check(c, p, n_angles)) return rc;
+  if (!turned_y_deg || !scan_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  for (int32_t k = 0; k < n_angles; ++k)
+    if (!std::isfinite(turned_y_deg[k]) || std::fabs(turned_y_deg[k]) > 45.0)
+      return fail(SART_ERR_INVALID_ARGUMENT, "telescope angles must be finite and within +-45 degrees");
+  SART_HIP(hipSetDevice(c->device));
+  if (int rc = refresh_derived(c)) return rc;
+  if (int rc = sync_blob(c)) return rc;
+  sart_trace_params_t q = *p;   // a scan accumulates no image: whatever the caller left in the image fields is not read
+  q.image_nx = q.image_ny = 1;
+  q.image_x_min = q.image_y_min = 0.0;
+  q.image_x_max = q.image_y_max = 1.0;
+  q.spectra = 0;
+  TraceArgs a;
+  if (int rc = make_args(c, &q, a)) return rc;
+  a.fx_scale_w = a.fx_scale_w2 = 0.0;
+  const bool fixed = c->accum_mode == SART_ACCUM_FIXED64;
+  if (fixed) {   // a pure function of setup, tables, flags and headroom (the bound does not depend on the angle)
+    QuantaExp qe;
+    if (int rc = quanta_exp_of(c, weight_bound_of(c, p->flags, c->params.gas_dm2_abs), qe)) return rc;
+    a.fx_scale_w = std::ldexp(1.0, -qe.w);
+    a.fx_scale_w2 = std::ldexp(1.0, -qe.w2);
+  }
+  if (!p->accumulate) SART_HIP(hipMemsetAsync(scan_dev, 0, sart_angular_scan_len(n_angles) * sizeof(double), c->stream));
+  if (p->n_rays == 0) return 0;
+  const DevParams& P = c->params;
+  const bool fast = !P.test_active && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) && !c->knobs.force_generic && !P.stage_gas;
+  // Stage A0 for a telescope that is (or may be) rotated: the zones that need the telescope on the magnet's axis do not hold;
+  // what is left - the bore-exit radius alone proves the ray dead at one of the three cuts behind the field - is independent
+  // of the angle, so the zones of the launch are the intersection over its angles by construction.
+  HotA hot = c->hot;
+  hot.rotated = 1;
+  if (!c->knobs.no_early_reject) {
+    DevParams Pz = P;
+    Pz.rotated = 1;
+    build_zones(c->setup, Pz, c->n_radii, hot);
+  }
+  int& bpc = c->blocks_per_cu_ascan[fast ? 1 : 0];
+  if (bpc == 0) {
+    bpc = std::max(1, angular_scan_blocks_per_cu(fast));
+    if (c->knobs.hist_blocks_per_cu > 0) bpc = c->knobs.hist_blocks_per_cu;
+  }
+  const int32_t n_groups = (n_angles + kAScanMaxAngles - 1) / kAScanMaxAngles;
+  for (uint64_t done = 0; done < p->n_rays;) {   // ray indices inside one launch are 32-bit: pieces of at most 2^31 rays
+    const uint64_t n = std::min<uint64_t>(p->n_rays - done, 1ull << 31);
+    a.n_rays = n;
+    a.ray_id_offset = p->ray_id_offset + done;
+    const int n_blocks = grid_for(n, c->n_cu, bpc, 1024);
+    const size_t need = static_cast<size_t>(n_blocks) * kAScanMaxAngles * kAScanPartialSlots;
+    if (c->d_ascan_partials.n < need) {
+      SART_HIP(hipStreamSynchronize(c->stream));
+      const size_t rows = std::max<size_t>(static_cast<size_t>(n_blocks), static_cast<size_t>(c->n_cu) * 4);
+      if (int rc = c->d_ascan_partials.resize(rows * kAScanMaxAngles * kAScanPartialSlots)) return rc;
+    }
+    a.partials = nullptr;
+    for (int32_t g = 0, k0 = 0; g < n_groups; ++g) {   // balanced groups: sizes differ by at most one
+      AScanArgs an;
+      std::memset(&an, 0, sizeof an);
+      an.n_angles = n_angles / n_groups + (g < n_angles % n_groups ? 1 : 0);
+      an.partials = c->d_ascan_partials.p;
+      for (int k = 0; k < an.n_angles; ++k) an.a[k] = ascan_angle_of(c, turned_y_deg[k0 + k]);
+      double* const rows = scan_dev + static_cast<size_t>(k0) * SART_ASCAN_ROW;
+      double* const shared = (k0 == 0) ? scan_dev + static_cast<size_t>(n_angles) * SART_ASCAN_ROW : nullptr;   // counters: once per piece
+      {
+        TimedLaunch tl(c);
+        launch_trace_angular_scan(hot, c->hotb, c->d_blob.p, a, an, rows, shared, n_blocks, c->stream, fast, fixed);
+      }
+      SART_HIP(hipGetLastError());
+      k0 += an.n_angles;
+    }
+    done += n;
+  }
+  return 0;
+}
+
+int sart_finalize_angular_scan_device(sart_context* c, const sart_trace_params_t* p, int32_t n_angles, const void* raw_dev, double* out_dev) {
+  if (int rc = ascan_check(c, p, n_angles)) return rc;
+  if (!raw_dev || !out_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  SART_HIP(hipSetDevice(c->device));
+  if (int rc = refresh_derived(c)) return rc;
+  if (int rc = sync_blob(c)) return rc;
+  if (int rc = status_ensure(c)) return rc;
+  QuantaExp qe;
+  if (int rc = quanta_exp_of(c, weight_bound_of(c, p->flags, c->params.gas_dm2_abs), qe)) return rc;
+  double q_w[kScanMaxMasses], q_w2[kScanMaxMasses];
+  for (int k = 0; k < kScanMaxMasses; ++k) { q_w[k] = std::ldexp(1.0, qe.w); q_w2[k] = std::ldexp(1.0, qe.w2); }
+  constexpr uint32_t kCounters = (1u << SART_ASCAN_N_PASSED) | (1u << SART_ASCAN_N_SHELL_SELECTED) | (1u << SART_ASCAN_N_HIT_NICKEL) |
+                                 (1u << SART_ASCAN_N_PASSED_TILL_WINDOW);
+  static_assert(SART_ASCAN_ROW == SART_SCAN_ROW && SART_ASCAN_SUM_WEIGHTS == SART_SCAN_SUM_WEIGHTS && SART_ASCAN_SUM_WEIGHTS_SQ == SART_SCAN_SUM_WEIGHTS_SQ &&
+                    SART_ASCAN_SUM_WEIGHTS_HI == SART_SCAN_SUM_WEIGHTS_HI && SART_ASCAN_SUM_WEIGHTS_SQ_HI == SART_SCAN_SUM_WEIGHTS_SQ_HI &&
+                    SART_ASCAN_N_PASSED == SART_SCAN_N_PASSED, "the two scans share the row layout of their sums and the finalize kernel");
+  for (int32_t k0 = 0; k0 < n_angles; k0 += kScanMaxMasses) {
+    const int n = std::min<int32_t>(kScanMaxMasses, n_angles - k0);
+    const size_t off = static_cast<size_t>(k0) * SART_ASCAN_ROW;
+    launch_finalize_scan(static_cast<const long long*>(raw_dev) + off, out_dev + off, n, q_w, q_w2, (k0 + n == n_angles) ? n : -1,
+                         c->d_status.p, c->stream, kCounters);
+    SART_HIP(hipGetLastError());
+  }
+  return status_enqueue_copy(c);
+}
+
+int sart_trace_angular_scan(sart_context* c, const sart_trace_params_t* p, const double* turned_y_deg, int32_t n_angles, double* out_host) {
+  if (int rc = ascan_check(c, p, n_angles)) return rc;
+  if (!turned_y_deg || !out_host) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  SART_HIP(hipSetDevice(c->device));
+  const size_t len = sart_angular_scan_len(n_angles);
+  if (int rc = c->d_scan.resize(len)) return rc;
+  sart_trace_params_t q = *p;
+  q.accumulate = 0;   // the blocking form has no accumulator the caller could add into
+  if (int rc = sart_trace_angular_scan_device(c, &q, turned_y_deg, n_angles, c->d_scan.p)) return rc;
+  const double* src = c->d_scan.p;
+  if (c->accum_mode == SART_ACCUM_FIXED64) {
+    if (int rc = c->d_scan_fin.resize(len)) return rc;
+    if (int rc = sart_finalize_angular_scan_device(c, p, n_angles, c->d_scan.p, c->d_scan_fin.p)) return rc;
     src = c->d_scan_fin.p;
   }
   SART_HIP(hipMemcpyAsync(out_host, src, len * sizeof(double), hipMemcpyDeviceToHost, c->stream));

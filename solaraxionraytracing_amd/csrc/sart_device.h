@@ -262,6 +262,32 @@ struct ScanArgs {
 static_assert(sizeof(ScanMass) == 32 && sizeof(ScanArgs) == 16 + 32 * kScanMaxMasses, "the kernel re-reads ScanArgs with scalar loads at these offsets");
 constexpr int kScanPartialSlots = 4;
 
+// Fused angular scan (include/sart.h: sart_trace_angular_scan): the telescope's angles enter a ray at the transformation into the
+// telescope's frame (raytracer.nim:1878-1899) and nowhere before it, so trace_angular_scan_kernel samples a ray and takes it through
+// bore and pipes ONCE and runs telescope frame -> opaque structures -> shell selection -> mirrors -> weight once per angle of this
+// table.  One launch takes up to kAScanMaxAngles angles: per angle a workgroup keeps [sum of w, sum of w^2][kScanLanes] f64 / int64
+// cells (the scan accumulates no image: the cells live where the histogram kernels keep the image tile behind the tables) and four
+// counters in LDS.
+constexpr int kAScanMaxAngles = 16;
+struct AScanAngle {
+  // rotateInY(rotateInX(., turnedX), turnedY) about (0, 0, lT/2) as hoist_setup() evaluates it for this angle (TelRot)
+  double rx_c, rx_s, ry_c, ry_s, half_length_telescope;
+  double shell0_miss_radius;      // DevParams::shell0_miss_radius of this angle (the bound follows the tilt)
+  // third column of the rotation: mx = rx_s, my = -(rx_c ry_s), mz = rx_c ry_c - what phase B needs to find z of pointExitCB in
+  // the rotated frame (staged into LDS: a phase-B pass holds rays of several angles)
+  double mx, my, mz;
+  double _pad;
+};
+struct AScanArgs {
+  int32_t n_angles, _pad;         // angles of this launch (1 .. kAScanMaxAngles)
+  double* partials;               // [n_blocks][kAScanMaxAngles][kAScanPartialSlots] per-workgroup sums (plain stores; fold_ascan_kernel adds them)
+  AScanAngle a[kAScanMaxAngles];
+};
+static_assert(sizeof(AScanAngle) == 80 && sizeof(AScanArgs) == 16 + 80 * kAScanMaxAngles, "the kernel re-reads AScanArgs with scalar loads at these offsets");
+// per-workgroup partial row of one angle: sum w, sum w^2, N_PASSED, N_HIT_NICKEL, N_PASSED_TILL_WINDOW, N_SHELL_SELECTED,
+// (angle 0 only) N_REACHED_TELESCOPE of the workgroup, unused
+constexpr int kAScanPartialSlots = 8;
+
 constexpr double kFixedPositionScale = 4294967296.0;        // 2^32 per mm
 constexpr double kFixedReflectScale = 1099511627776.0;      // 2^40
 constexpr int kFixedLimbBits = 40;                          // two-limb sums: value = hi * 2^40 + lo

@@ -586,16 +586,35 @@ struct Uniforms {
 __device__ __forceinline__ uint32_t upper32_of_uniform(double u) {
   return (uint32_t)(u * 4294967296.0);   // floor(u 2^32), exact for every u in [0, 1)
 }
-struct LaneMasks { uint64_t ok, reached; };   // phase A's verdicts as wave-wide lane masks (see phase_a_core)
+struct LaneMasks { uint64_t ok, reached; };   // phase A's verdicts as wave-wide lane masks (see phase_a_bore)
 
-template <bool FAST, int ROT, bool ZEXT, bool NOWALL = false>
-__device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, const LdsTables& L, const Uniforms& U, RayState& st,
-                                             bool& sampled, bool& reached, double& radial_out, LaneMasks& M) {
-  static_assert(!ZEXT || (FAST && ROT == 0), "the z-extent form needs the magnet-frame slopes in phase B");
-  static_assert(!NOWALL || ZEXT, "the constant-path form is a specialisation of the vacuum, unrotated one");
+// Phase A is written in two halves that meet where the magnet's pipes end and the telescope begins (:1868 | :1878): everything
+// in the first half - sampling, bore, cold-bore exit, pipe cuts - is independent of the telescope's angles, everything in the
+// second half depends on them.  The histogram and record kernels run them back to back (phase_a_core); the fused angular scan
+// (trace_angular_scan_kernel) runs the first half once per ray and the second half once per ray and angle.
+// What the first half hands to the second:
+struct BoreRay {
+  double x1, y1;     // the ray at the cold-bore exit (z = -Lp in the telescope's frame before its rotation)
+  double x3, y3;     // ... and at the end of the second pipe (z = 0 there)
+  double sx, sy;     // slopes dx/dz, dy/dz in the magnet frame
+  bool ok;           // alive so far (= `reached`)
+  uint64_t okm;      // the same as a lane mask
+};
+// The rotation of the telescope about (0, 0, lT/2) (:1888-1894) as hoist_setup() evaluates it (DevParams holds the same five
+// values in the same order: phase_a_core takes them from there; the angular scan has one set per angle in its kernel arguments).
+struct TelRot {
+  double rx_c, rx_s, ry_c, ry_s, half_length_telescope;
+};
+static_assert(offsetof(DevParams, rx_s) == offsetof(DevParams, rx_c) + 8 && offsetof(DevParams, ry_c) == offsetof(DevParams, rx_c) + 16 &&
+                  offsetof(DevParams, ry_s) == offsetof(DevParams, rx_c) + 24 && offsetof(DevParams, half_length_telescope) == offsetof(DevParams, rx_c) + 32,
+              "TelRot mirrors these five fields of DevParams");
+__device__ __forceinline__ const TelRot& tel_rot_of(const DevParams& P) { return *reinterpret_cast<const TelRot*>(&P.rx_c); }
+
+// ---- first half: sample -> bore -> cold-bore exit -> pipes (:1746-1868) ----
+template <bool FAST, bool ZEXT, bool NOWALL = false>
+__device__ __forceinline__ void phase_a_bore(const HotA& H, const DevParams& P, const LdsTables& L, const Uniforms& U, RayState& st,
+                                             bool& sampled, bool& reached, BoreRay& br, LaneMasks& M) {
   const bool cfg_test = FAST ? false : (H.test_active != 0);
-  const bool cfg_rotated = (ROT < 0) ? (H.rotated != 0) : (ROT != 0);
-  const bool cfg_holes = FAST ? false : (H.telescope_kind == SART_TK_XMM && H.inner_blocks < 0);
   const double u0 = U.u0, u1 = U.u1, u2 = U.u2, u3 = U.u3, u4 = U.u4;
   st.u5 = U.u5;
   st.r_idx = 0;
@@ -727,6 +746,21 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
   okm &= ballot64(in1) & ballot64(in2) & ballot64(in3);
   reached = ok;
   M.reached = okm;
+  br.x1 = x1; br.y1 = y1; br.x3 = x3; br.y3 = y3; br.sx = sx; br.sy = sy;
+  br.ok = ok;
+  br.okm = okm;
+}
+
+// ---- second half: telescope frame -> opaque structures -> shell selection (:1878-1957) ----
+// `R`: the telescope's rotation; `shell0`-style shortcuts stay with the caller.  Returns true if the ray goes on to the mirrors.
+template <bool FAST, int ROT>
+__device__ __forceinline__ bool phase_a_telescope(const HotA& H, const DevParams& P, const TelRot& R, const LdsTables& L, const BoreRay& br,
+                                                  RayState& st, double& radial_out, LaneMasks& M) {
+  const bool cfg_rotated = (ROT < 0) ? (H.rotated != 0) : (ROT != 0);
+  const bool cfg_holes = FAST ? false : (H.telescope_kind == SART_TK_XMM && H.inner_blocks < 0);
+  const double x1 = br.x1, y1 = br.y1, x3 = br.x3, y3 = br.y3, sx = br.sx, sy = br.sy;
+  bool ok = br.ok;
+  uint64_t okm = br.okm;
 
   // ---- telescope frame (:1878-1899) ----
   // pointExitCB' (z = -Lp before rotation) and pointExitPipeVT3XRT' (z = 0 before rotation)
@@ -741,12 +775,12 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
   } else {
     // rotateInY(rotateInX(p, turnedX, lT/2), turnedY, lT/2) applied to both points (:1888-1894)
     auto rot = [&](double px, double py, double pz, double& qx, double& qy, double& qz) {
-      const double zz = pz - P.half_length_telescope;
-      const double ax = fma(px, P.rx_c, zz * P.rx_s);
-      const double az = fma(zz, P.rx_c, -px * P.rx_s);   // rotateInX adds lT/2 back, rotateInY removes it again
+      const double zz = pz - R.half_length_telescope;
+      const double ax = fma(px, R.rx_c, zz * R.rx_s);
+      const double az = fma(zz, R.rx_c, -px * R.rx_s);   // rotateInX adds lT/2 back, rotateInY removes it again
       qx = ax;
-      qy = fma(py, P.ry_c, -az * P.ry_s);
-      qz = fma(az, P.ry_c, py * P.ry_s) + P.half_length_telescope;
+      qy = fma(py, R.ry_c, -az * R.ry_s);
+      qz = fma(az, R.ry_c, py * R.ry_s) + R.half_length_telescope;
     };
     double ax, ay, az, bx, by, bz;
     rot(x1, y1, -Lp, ax, ay, az);
@@ -853,14 +887,22 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
   return ok;
 }
 
+// Both halves back to back (histogram and record kernels).
+template <bool FAST, int ROT, bool ZEXT, bool NOWALL = false>
+__device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, const LdsTables& L, const Uniforms& U, RayState& st,
+                                             bool& sampled, bool& reached, double& radial_out, LaneMasks& M) {
+  static_assert(!ZEXT || (FAST && ROT == 0), "the z-extent form needs the magnet-frame slopes in phase B");
+  static_assert(!NOWALL || ZEXT, "the constant-path form is a specialisation of the vacuum, unrotated one");
+  BoreRay br;
+  phase_a_bore<FAST, ZEXT, NOWALL>(H, P, L, U, st, sampled, reached, br, M);
+  return phase_a_telescope<FAST, ROT>(H, P, tel_rot_of(P), L, br, st, radial_out, M);
+}
+
 // Phase A of the ray with global id `ray_id`: its six uniforms from TWO Philox counter blocks (256 bits) + its word of the
 // shared stream (sart_oracle_uniforms): the two CDF draws (u2, u5) and the disc angle (u4) have 52 random mantissa bits, the
 // two angles of the solar point (u0, u1) and the disc radius (u3) 44: a high word of their own + the 12 bits the 52-bit fills
 // leave over in a word.  u3_hi = word ray_id of the shared stream.
-template <bool FAST, int ROT, bool ZEXT, bool NOWALL = false>
-__device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const LdsTables& L, uint32_t seed_lo,
-                                        uint32_t seed_hi, uint64_t ray_id, uint32_t u3_hi, RayState& st, bool& sampled,
-                                        bool& reached, double& radial, LaneMasks& M) {
+__device__ __forceinline__ Uniforms uniforms_of(uint32_t seed_lo, uint32_t seed_hi, uint64_t ray_id, uint32_t u3_hi) {
   const uint32_t id_lo = (uint32_t)ray_id, id_hi = (uint32_t)(ray_id >> 32);
   const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, seed_lo, seed_hi);
   const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, seed_lo, seed_hi);
@@ -872,7 +914,21 @@ __device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const
   U.u1 = u52(b1.y, b0.w << 20);
   U.u4 = u52(b1.z, b1.w);
   U.u3 = u52(u3_hi, b1.w << 20);
-  return phase_a_core<FAST, ROT, ZEXT, NOWALL>(H, P, L, U, st, sampled, reached, radial, M);
+  return U;
+}
+template <bool FAST, int ROT, bool ZEXT, bool NOWALL = false>
+__device__ __forceinline__ bool phase_a(const HotA& H, const DevParams& P, const LdsTables& L, uint32_t seed_lo,
+                                        uint32_t seed_hi, uint64_t ray_id, uint32_t u3_hi, RayState& st, bool& sampled,
+                                        bool& reached, double& radial, LaneMasks& M) {
+  return phase_a_core<FAST, ROT, ZEXT, NOWALL>(H, P, L, uniforms_of(seed_lo, seed_hi, ray_id, u3_hi), st, sampled, reached, radial, M);
+}
+
+// z of pointExitCB in the rotated telescope frame (z0 of :2051) from the ray as phase B knows it: the point of the ray whose z
+// *before* the rotation (rotateInY(rotateInX(.)) about (0, 0, lT/2), :1888-1894) is -Lp.  With m = third column of that rotation
+// and q(Z) = (qx + tsx Z, qy + tsy Z, Z), qx / qy = X0 / Y0 + entrance offset:  m . (q - c) + lT/2 = -Lp, linear in Z.
+__device__ __forceinline__ double zcb_rotated(double mx, double my, double mz, double h, double qx, double qy, double tsx, double tsy, double Lp) {
+  const double num = -Lp - h - fma(mx, qx, fma(my, qy, -mz * h));
+  return num * frcp(fma(mx, tsx, fma(my, tsy, mz)));
 }
 
 // Results of phase B for one ray (record mode needs all of them; histogram mode a few).
@@ -1440,13 +1496,9 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       if (!ROT) {
         st.zcb = -(H.dz3 - H.dz1);
       } else {
-        // z of pointExitCB in the rotated telescope frame (z0 of :2051): the point of the ray whose z *before* the rotation
-        // (rotateInY(rotateInX(.)) about (0, 0, lT/2), :1888-1894) is -Lp.  With m = third column of that rotation and
-        // q(Z) = (X0 + entrance_x + tsx Z, Y0 + entrance_y + tsy Z, Z):  m . (q - c) + lT/2 = -Lp, linear in Z.
-        const double mx = Pb.rx_s, my = -Pb.rx_c * Pb.ry_s, mz = Pb.rx_c * Pb.ry_c, h = Pb.half_length_telescope;
-        const double qx = st.X0 + Pb.entrance_x, qy = st.Y0 + Pb.entrance_y;
-        const double num = -(H.dz3 - H.dz1) - h - fma(mx, qx, fma(my, qy, -mz * h));
-        st.zcb = num * frcp(fma(mx, st.tsx, fma(my, st.tsy, mz)));
+        // z of pointExitCB in the rotated frame, recomputed from the ray instead of carried through ring 1 (zcb_rotated)
+        st.zcb = zcb_rotated(Pb.rx_s, -Pb.rx_c * Pb.ry_s, Pb.rx_c * Pb.ry_c, Pb.half_length_telescope, st.X0 + Pb.entrance_x,
+                             st.Y0 + Pb.entrance_y, st.tsx, st.tsy, H.dz3 - H.dz1);
       }
       const int packed = Q.w[wave].idx[slot];
       st.r_idx = packed & 0xFFFF;
@@ -1794,6 +1846,369 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fused angular scan (include/sart.h: sart_trace_angular_scan; BASELINE configs[3])
+// ------------------------------------------------------------------------------------------------
+// performAngularScan (:2778-2802) re-runs the whole trace per telescope angle.  The angle enters a ray at the transformation
+// into the telescope's frame (:1878-1899) and nowhere before it: sampling, the three sincos, the radius draw, bore, cold-bore
+// exit and pipe cuts (phase_a_bore: ~215 of phase A's ~365 vector instructions in the rotated variant, and all of stage A0) do
+// not depend on it.  This kernel therefore takes every ray through stage A0 and the first half of phase A ONCE and keeps the
+// full wave of rays that come out of it in registers (the "stash": 13 values per lane - x1, y1, x3, y3, path, u5, radius index);
+// a wave-uniform walk over the launch's angles runs the second half of phase A (phase_a_telescope with that angle's rotation,
+// read from the kernel arguments with scalar loads) on the stash, compacts the survivors into ring 1 with their angle index, and
+// phase B runs on full waves of ring 1 as in the histogram kernel - a pass usually holds rays of two or three angles, so what
+// phase B needs of the angle (the third column of the rotation, for z of pointExitCB) comes from a small LDS table per lane and
+// the sums go to per-angle LDS cells (ds_add_f64 / ds_add_u64) and counters (ds_add_u32).  No image, no position sums.
+// One loop iteration runs at most one pass of each stage (one call site each: the instruction footprint of the histogram kernel):
+//   no stash (ka == n_angles):  A0 pass -> ring 0;  ring 0 holds a full wave (or the input is exhausted) -> A1a -> stash, ka = 0
+//   stash (ka < n_angles):      A1b for angle ka -> ring 1, ++ka
+//   ring 1 holds a full wave (or everything before it has drained) -> B
+// Same rays for every angle (common random numbers), the ray ids and uniforms of the histogram kernels: per angle the sums
+// equal a sart_trace_histogram launch with that angle set on the same ray ids - bit for bit in SART_ACCUM_FIXED64.
+// FAST / GAS as in trace_histogram_kernel (the telescope is always "rotated" here: angle 0 runs through the same arithmetic
+// with cos = 1, sin = 0).
+struct AScanKernArgs {
+  HotA H;
+  const DevBlob* blob;
+  TraceArgs A;
+  double* unused;      // (keeps the argument offsets of trace_histogram_kernel: the reload_* helpers are shared)
+  HotB HB;
+  AScanArgs AN;
+};
+static_assert(offsetof(AScanKernArgs, A) == offsetof(HistKernArgs, A) && offsetof(AScanKernArgs, HB) == offsetof(HistKernArgs, HB) &&
+                  offsetof(AScanKernArgs, AN) == offsetof(HistKernArgs, SC) && sizeof(AScanAngle) % 8 == 0,
+              "the angular-scan kernel re-reads its arguments at the offsets of the histogram kernel's");
+constexpr int kAScanCells = kAScanMaxAngles * 2 * kScanLanes;          // [angle][sum w, sum w^2][kScanLanes]
+constexpr int kAScanMTable = kAScanCells;                              // [angle][mx, my, mz] behind the cells
+static_assert(kAScanCells + 3 * kAScanMaxAngles <= kTileExtraCells, "cells + rotation columns live where the histogram kernels keep the image tile behind the tables");
+static_assert(2 * kScanLanes == 64, "one cell per lane in the epilogue");
+
+template <int BLOCK, bool FAST, int GAS, bool FIXED>
+__global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const DevBlob* __restrict__ blob, TraceArgs A,
+                                                                   double* __restrict__ unused, HotB HBarg, AScanArgs ANarg) {
+  struct LdsLayout {   // the layout of trace_histogram_kernel (tables first: ds_ offsets)
+    TablesLds S;
+    double cells[kTileExtraCells];
+    DevBlob B;
+    TraceArgs Ab;
+    QueueLds<BLOCK / 64> Q;
+  };
+  __shared__ LdsLayout lds;
+  // per angle: N_PASSED, N_HIT_NICKEL, N_PASSED_TILL_WINDOW, N_SHELL_SELECTED of this workgroup; [4 kAScanMaxAngles]: N_REACHED_TELESCOPE
+  __shared__ uint32_t cnt[4 * kAScanMaxAngles + 4];
+  static_assert((offsetof(LdsLayout, Q) % 512) == 0, "the rings are addressed with ds_*2st64 offsets");
+  static_assert(BLOCK / 64 >= kAScanMaxAngles, "the epilogue gives every angle a wave");
+  TablesLds& S = lds.S;
+  QueueLds<BLOCK / 64>& Q = lds.Q;
+  DevBlob& B = lds.B;
+  TraceArgs& Ab = lds.Ab;
+  (void)unused; (void)HBarg;
+  {
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(blob);
+    uint64_t* dst = reinterpret_cast<uint64_t*>(&B);
+    for (int i = threadIdx.x; i < (int)(sizeof(DevBlob) / 8); i += BLOCK) dst[i] = src[i];
+    if (threadIdx.x == 0) Ab = A;
+    uint64_t* q = reinterpret_cast<uint64_t*>(&Q);
+    for (int i = threadIdx.x; i < (int)(sizeof(Q) / 8); i += BLOCK) q[i] = 0ull;
+    for (int i = threadIdx.x; i < kAScanCells; i += BLOCK) lds.cells[i] = 0.0;
+    if (threadIdx.x < 4 * kAScanMaxAngles + 4) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x < 3 * kAScanMaxAngles) {
+      // third column of every angle's rotation, from the kernel arguments (a per-thread read of the argument segment)
+      typedef const __attribute__((address_space(4))) double* kernarg_f64;
+      const kernarg_f64 a0 = (kernarg_f64)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                           offsetof(AScanKernArgs, AN) + offsetof(AScanArgs, a) + offsetof(AScanAngle, mx));
+      const int k = threadIdx.x / 3, j = threadIdx.x - 3 * k;
+      lds.cells[kAScanMTable + threadIdx.x] = a0[k * (int)(sizeof(AScanAngle) / 8) + j];
+    }
+    __syncthreads();
+  }
+  const DevParams& Pb = B.P;
+  const DevTables& Tb = B.T;
+  stage_tables<BLOCK>(S, Pb, Tb);
+  const LdsTables L{S.sincos, S.rcdf_hi, Tb.flux_radius_cdf, S.rguide, S.shells, S.lut};
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint64_t waves_total = (uint64_t)gridDim.x * (BLOCK / 64);
+  const uint64_t wave_global = (uint64_t)blockIdx.x * (BLOCK / 64) + wave;
+  const bool early_reject = H.n_zones > 0;   // wave-uniform; no zones for the X-ray test source
+  const uint64_t first_chunk = A.ray_id_offset >> 8;
+  uint64_t id_base = first_chunk << 8;
+  asm volatile("" : "+s"(id_base));
+  const uint32_t rel_begin = (uint32_t)(A.ray_id_offset & 255u);
+  const uint32_t rel_end = rel_begin + (uint32_t)A.n_rays;
+  const uint32_t n_chunks = (rel_end + 255u) >> 8;
+  const int n_angles = ANarg.n_angles;
+
+  uint32_t n_reached = 0;
+  uint32_t h0 = 0, t0 = 0, h1 = 0, t1 = 0;
+  auto ring_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto prefix_of = [](uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  };
+
+  // the stash: the wave of rays whose angles are being worked through (registers)
+  double st_x1 = 0.0, st_y1 = 0.0, st_x3 = 0.0, st_y3 = 0.0, st_path = 0.0, st_u5 = 0.0;
+  int st_ridx = 0;
+  uint64_t stash_m = 0;   // its lanes that hold a ray of this launch that reached the telescope
+  int ka = n_angles;      // next angle of the stash; n_angles: no stash
+
+  // stage A1a: sample -> bore -> pipes for the ray with id id_base + rel
+  auto run_bore = [&](uint32_t rel, bool valid, uint32_t u3_hi) {
+    SART_STAGE_MARK("A1a");
+    RayState st;
+    bool sampled = false, reached = false;
+    HotA Hl;
+    reload_hot(Hl);
+    BoreRay br;
+    LaneMasks M;
+    phase_a_bore<FAST, false>(Hl, Pb, L, uniforms_of(A.seed_lo, A.seed_hi, id_base + (uint64_t)rel, u3_hi), st, sampled, reached, br, M);
+    stash_m = ballot64(valid) & M.reached;
+    n_reached += (uint32_t)__popcll(stash_m);
+    st_x1 = br.x1; st_y1 = br.y1; st_x3 = br.x3; st_y3 = br.y3;
+    st_path = st.path_cb; st_u5 = st.u5; st_ridx = st.r_idx;
+    ka = stash_m ? 0 : n_angles;   // (a wave none of whose rays reached the telescope has no angles to walk)
+  };
+
+  // stage A1b: the stash through telescope frame, opaque structures and shell selection for angle k (wave-uniform)
+  auto run_telescope = [&](int k) {
+    SART_STAGE_MARK("A1b");
+    HotA Hl;
+    reload_hot(Hl);
+    struct { TelRot R; double shell0_miss_radius; } ang;   // the head of AScanAngle
+    static_assert(offsetof(AScanAngle, rx_c) == 0 && offsetof(AScanAngle, shell0_miss_radius) == sizeof(TelRot), "the head of AScanAngle");
+    reload_kernarg(ang, offsetof(AScanKernArgs, AN) + offsetof(AScanArgs, a) + (size_t)k * sizeof(AScanAngle));
+    BoreRay br;
+    br.x1 = st_x1; br.y1 = st_y1; br.x3 = st_x3; br.y3 = st_y3;
+    br.sx = 0.0; br.sy = 0.0;   // (read by the unrotated form only)
+    br.ok = __builtin_amdgcn_inverse_ballot_w64(stash_m);
+    br.okm = stash_m;
+    RayState st;
+    st.path_cb = st_path; st.u5 = st_u5; st.r_idx = st_ridx;
+    double radial;
+    LaneMasks M;
+    (void)phase_a_telescope<FAST, 1>(Hl, Pb, ang.R, L, br, st, radial, M);
+    const uint64_t selected = M.ok;   // (starts from stash_m: valid, reached)
+    if (lane == 0) atomicAdd(&cnt[4 * k + 3], (uint32_t)__popcll(selected));
+    // rays that provably miss the first mirror of the innermost shell end here, as in the histogram kernel (this angle's bound)
+    const uint64_t mask = selected & ~ballot64(radial < ang.shell0_miss_radius);
+    if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
+      asm volatile("; hot: ring 1 write");
+      const uint32_t slot = (t1 + prefix_of(mask)) % kQueue;
+      Q.w[wave].X0[slot] = st.X0; Q.w[wave].Y0[slot] = st.Y0;
+      Q.w[wave].tsx[slot] = st.tsx; Q.w[wave].tsy[slot] = st.tsy;
+      Q.w[wave].path[slot] = st.path_cb;
+      Q.w[wave].u5[slot] = st.u5;
+      Q.w[wave].idx[slot] = st.r_idx | (st.shell << 16) | (k << 24);
+    }
+    t1 += (uint32_t)__popcll(mask);
+  };
+
+  // stage B: mirrors -> weight on a wave of ring 1 (rays of several angles), accumulated per angle
+  auto run_mirrors = [&](uint32_t n_valid) {
+    SART_STAGE_MARK("B");
+    RayState st;
+    const bool valid = (uint32_t)lane < n_valid;
+    const uint32_t slot = (h1 + (uint32_t)lane) % kQueue;
+    st.X0 = Q.w[wave].X0[slot]; st.Y0 = Q.w[wave].Y0[slot];
+    st.tsx = Q.w[wave].tsx[slot]; st.tsy = Q.w[wave].tsy[slot];
+    st.path_cb = Q.w[wave].path[slot];
+    st.u5 = Q.w[wave].u5[slot];
+    const int packed = Q.w[wave].idx[slot];   // (slots beyond n_valid hold earlier rays or zeros: a real ray's indices, angle < n_angles)
+    st.r_idx = packed & 0xFFFF;
+    st.shell = (packed >> 16) & 0xFF;
+    const uint32_t kl = (uint32_t)packed >> 24;
+    {
+      const double* const m = &lds.cells[kAScanMTable + 3 * kl];
+      st.zcb = zcb_rotated(m[0], m[1], m[2], Pb.half_length_telescope, st.X0 + Pb.entrance_x, st.Y0 + Pb.entrance_y, st.tsx, st.tsy,
+                           H.dz3 - H.dz1);
+    }
+    h1 += n_valid;
+    const DevBlob& Bo = lds_opaque(B);
+    HotB HB;
+    reload_kernarg(HB, offsetof(AScanKernArgs, HB));
+    asm volatile("" :: "s"(HB.cdf_hi32), "s"(HB.energy_guide), "s"(HB.energy_tab), "s"(HB.refl), "s"(HB.refl_n_angles), "s"(HB.cdf_stride));
+    RayOut out;
+    phase_b<false, FAST, GAS, false>(Bo.P, L, HB, lds_opaque(Ab), st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
+    SART_STAGE_MARK("ACC");
+    if (__builtin_amdgcn_inverse_ballot_w64(out.m_nickel)) atomicAdd(&cnt[4 * kl + 1], 1u);
+    if (__builtin_amdgcn_inverse_ballot_w64(out.m_till)) atomicAdd(&cnt[4 * kl + 2], 1u);
+    if (out.passed) {
+      atomicAdd(&cnt[4 * kl], 1u);
+      // cell [kl][0][lane % 32]; [kl][1][.] is kScanLanes further on (lanes l and l + 32 share a cell, as in the mass scan)
+      double* const cell = &lds.cells[kl * (2u * kScanLanes) + ((uint32_t)lane & (kScanLanes - 1u))];
+      if constexpr (FIXED) {
+        double fx_w, fx_w2;
+        { const TraceArgs& Al = lds_opaque(Ab); fx_w = Al.fx_scale_w; fx_w2 = Al.fx_scale_w2; }
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cell), (unsigned long long)to_fixed(out.weight, fx_w), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(cell + kScanLanes), (unsigned long long)to_fixed(out.weight * out.weight, fx_w2),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        __hip_atomic_fetch_add(cell, out.weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(cell + kScanLanes, out.weight * out.weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+  };
+
+  // zone bounds of stage A0 (see trace_histogram_kernel)
+  constexpr bool kZonesInVgprs = FAST;
+  uint32_t zone_lo_v[kMaxZones], zone_hi_v[kMaxZones];
+#pragma unroll
+  for (int z = 0; z < kMaxZones; ++z) {
+    zone_lo_v[z] = H.zone_lo[z];
+    zone_hi_v[z] = H.zone_hi[z];
+    if (kZonesInVgprs) asm volatile("" : "+v"(zone_lo_v[z]), "+v"(zone_hi_v[z]));
+  }
+  uint32_t zone_reached_v = H.zone_reached;
+  if (kZonesInVgprs) asm volatile("" : "+v"(zone_reached_v));
+  uint32_t chunk = (uint32_t)wave_global;
+  const uint32_t lane4 = 4u * (uint32_t)lane;
+  uint32_t pass = 0;
+  U4 stream = U4{0u, 0u, 0u, 0u};
+  for (;;) {
+    const bool have_new = chunk < n_chunks;   // wave-uniform
+    SART_STAGE_MARK("LOOP");
+    if (ka == n_angles) {   // no stash: take rays in until a full wave of them has passed stage A0
+      if (have_new) {
+        SART_STAGE_MARK("A0");
+        if (pass == 0u) stream = stream_block(((first_chunk + (uint64_t)chunk) << 6) + (uint64_t)lane, A.seed_lo, A.seed_hi);
+        const uint32_t w = word_of(stream, pass);
+        const uint32_t rel = ((chunk << 8) + pass) + lane4;
+        pass = (pass + 1u) & 3u;
+        if (pass == 0u) chunk += (uint32_t)waves_total;
+        if (early_reject) {
+          ZoneTable Z;
+          if constexpr (!kZonesInVgprs) reload_zones(Z);
+          const uint32_t zone_reached = kZonesInVgprs ? (uint32_t)__builtin_amdgcn_readfirstlane((int)zone_reached_v) : Z.zone_reached;
+          uint64_t dead_m = 0, reached_m = 0;
+#pragma unroll
+          for (int z = 0; z < kMaxZones; ++z) {
+            const uint64_t in = kZonesInVgprs ? (ballot64(w >= zone_lo_v[z]) & ballot64(w <= zone_hi_v[z]))
+                                              : (ballot64(w >= Z.lo[z]) & ballot64(w <= Z.hi[z]));
+            dead_m |= in;
+            reached_m |= ((zone_reached >> z) & 1u) ? in : 0ull;
+          }
+          const uint64_t valid_m = ballot64(rel >= rel_begin) & ballot64(rel < rel_end);
+          n_reached += (uint32_t)__popcll(valid_m & reached_m);
+          const uint64_t mask = valid_m & ~dead_m;
+          if (__builtin_amdgcn_inverse_ballot_w64(mask)) {
+            asm volatile("; hot: ring 0 write");
+            const uint32_t slot = (t0 + prefix_of(mask)) % kQueue;
+            Q.w[wave].ray[slot] = rel;
+            Q.w[wave].u3hi[slot] = w;
+          }
+          t0 += (uint32_t)__popcll(mask);
+          ring_sync();
+        } else {
+          run_bore(rel, (rel >= rel_begin) & (rel < rel_end), w);   // no early-rejection stage for this configuration
+        }
+      }
+      SART_STAGE_MARK("LOOP");
+      if (early_reject) {
+        const uint32_t n0 = t0 - h0;
+        if ((n0 >= 64u) | (!have_new & (n0 > 0u))) {
+          const uint32_t m = min(n0, 64u);
+          const uint32_t slot = (h0 + (uint32_t)lane) % kQueue;
+          const uint32_t rel = Q.w[wave].ray[slot];
+          const uint32_t w = Q.w[wave].u3hi[slot];
+          h0 += m;
+          run_bore(rel, (uint32_t)lane < m, w);
+        }
+      }
+    }
+    SART_STAGE_MARK("LOOP");
+    if (ka < n_angles) {
+      run_telescope(ka);
+      ++ka;
+      ring_sync();
+    }
+    SART_STAGE_MARK("LOOP");
+    const uint32_t n1 = t1 - h1;
+    const bool draining = !have_new & (t0 == h0) & (ka == n_angles);
+    if ((n1 >= 64u) | (draining & (n1 > 0u))) {
+      run_mirrors(min(n1, 64u));
+      ring_sync();
+    }
+    if (draining & (t1 == h1)) break;
+  }
+
+  SART_STAGE_MARK("EPILOGUE");
+  // per angle: a wave adds up the angle's cells (lanes 0 .. 31: sum of w, lanes 32 .. 63: sum of w^2; fixed order) -> plain stores
+  // into this workgroup's partial row, folded by fold_ascan_kernel
+  if (lane == 0) atomicAdd(&cnt[4 * kAScanMaxAngles], n_reached);
+  __syncthreads();   // every wave has left the loop
+  using Sum = std::conditional_t<FIXED, long long, double>;
+  for (int k = wave; k < n_angles; k += BLOCK / 64) {
+    Sum* const dst = reinterpret_cast<Sum*>(ANarg.partials) + ((size_t)blockIdx.x * kAScanMaxAngles + (size_t)k) * kAScanPartialSlots;
+    const double cell = lds.cells[k * 64 + lane];
+    Sum v;
+    if constexpr (FIXED) v = __double_as_longlong(cell); else v = cell;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);   // within each half of the wave
+    if (lane == 0) dst[0] = v;
+    if (lane == 32) dst[1] = v;
+    if (lane < 4) dst[2 + lane] = (Sum)cnt[4 * k + lane];
+    if (lane == 4) dst[6] = (k == 0) ? (Sum)cnt[4 * kAScanMaxAngles] : (Sum)0;
+    if (lane == 5) dst[7] = (Sum)0;
+  }
+}
+
+// Fused angular scan: rows of the scan accumulator (include/sart.h: SART_ASCAN_*) += the per-workgroup sums of one launch.
+// 1024 threads = 128 (angle, partial slot) pairs x 8 groups of workgroups, the summation tree of fold_scan_kernel.  `shared_row`
+// (first group of angles of a scan only, else nullptr): the angle-independent counters.
+template <bool FIXED>
+__global__ __launch_bounds__(1024) void fold_ascan_kernel(double* __restrict__ rows_, double* __restrict__ shared_row_, const double* __restrict__ partials_,
+                                                         int n_blocks, int n_angles, double n_rays) {
+  using Sum = std::conditional_t<FIXED, long long, double>;
+  constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
+  constexpr int kPairs = kAScanMaxAngles * kAScanPartialSlots, kGroups = 8;
+  static_assert(kPairs * kGroups == 1024, "one thread per (angle, partial slot, group of workgroups)");
+  Sum* const rows = reinterpret_cast<Sum*>(rows_);
+  Sum* const shared_row = reinterpret_cast<Sum*>(shared_row_);
+  const Sum* const part = reinterpret_cast<const Sum*>(partials_);
+  __shared__ Sum red_lo[kGroups][kPairs], red_hi[kGroups][kPairs];
+  const int pair = threadIdx.x % kPairs, g = threadIdx.x / kPairs;
+  const int k = pair / kAScanPartialSlots, j = pair % kAScanPartialSlots;
+  Sum lo = 0, hi = 0;
+  if (k < n_angles && j < 7) {
+    for (int b = g; b < n_blocks; b += kGroups) {
+      const Sum p = part[((size_t)b * kAScanMaxAngles + k) * kAScanPartialSlots + j];
+      if constexpr (FIXED) { lo += p & kMask; hi += p >> kFixedLimbBits; } else lo += p;
+    }
+  }
+  red_lo[g][pair] = lo;
+  red_hi[g][pair] = hi;
+  __syncthreads();
+  if (g != 0) return;
+  lo = 0; hi = 0;
+  for (int i = 0; i < kGroups; ++i) { lo += red_lo[i][pair]; hi += red_hi[i][pair]; }
+  if (k < n_angles && j < 6) {
+    Sum* const row = rows + (size_t)k * SART_ASCAN_ROW;
+    if (j < 2) {
+      const int s = j == 0 ? SART_ASCAN_SUM_WEIGHTS : SART_ASCAN_SUM_WEIGHTS_SQ, sh = j == 0 ? SART_ASCAN_SUM_WEIGHTS_HI : SART_ASCAN_SUM_WEIGHTS_SQ_HI;
+      if constexpr (FIXED) {
+        lo += row[s];
+        row[s] = lo & kMask;
+        row[sh] += hi + (lo >> kFixedLimbBits);
+      } else {
+        row[s] += lo;
+      }
+    } else {
+      const int dst = j == 2 ? SART_ASCAN_N_PASSED : j == 3 ? SART_ASCAN_N_HIT_NICKEL : j == 4 ? SART_ASCAN_N_PASSED_TILL_WINDOW : SART_ASCAN_N_SHELL_SELECTED;
+      if constexpr (FIXED) row[dst] += (hi << kFixedLimbBits) + lo; else row[dst] += lo;
+    }
+  }
+  if (shared_row && k == 0 && j == 6) {
+    if constexpr (FIXED) shared_row[SART_ASCAN_N_REACHED_TELESCOPE] += (hi << kFixedLimbBits) + lo; else shared_row[SART_ASCAN_N_REACHED_TELESCOPE] += lo;
+  }
+  if (shared_row && pair == 7) shared_row[SART_ASCAN_N_RAYS] += (Sum)n_rays;
+}
+
 // acc scalars += sum over workgroups of the partials; N_RAYS += n_rays.  256 threads: 8 groups x 32 quantity slots (24 used).
 __global__ __launch_bounds__(256) void fold_scalars_kernel(double* __restrict__ scalars, const double* __restrict__ partials,
                                                            int n_blocks, double n_rays) {
@@ -2051,6 +2466,7 @@ __global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in
 // travel in the kernel arguments) and, if `shared_row`, the counter row behind the whole scan.  One thread per row.
 struct FinalizeScanArgs {
   int32_t n_masses, shared_row;    // shared_row: row index of the counters relative to `in`, or -1
+  uint32_t counter_slots, _pad;    // bit j: slot j of a row is a plain counter (mass scan: N_PASSED; angular scan: its four counters)
   double q_w[kScanMaxMasses], q_w2[kScanMaxMasses];
 };
 __global__ __launch_bounds__(64) void finalize_scan_kernel(const long long* in, double* out, FinalizeScanArgs F, FixedCheck* C) {
@@ -2067,7 +2483,8 @@ __global__ __launch_bounds__(64) void finalize_scan_kernel(const long long* in, 
     for (int j = 0; j < SART_SCAN_ROW; ++j) o[j] = 0.0;
     o[SART_SCAN_SUM_WEIGHTS] = sw * F.q_w[k];
     o[SART_SCAN_SUM_WEIGHTS_SQ] = sq_ok ? sw2 * F.q_w2[k] : __builtin_nan("");
-    o[SART_SCAN_N_PASSED] = (double)v[SART_SCAN_N_PASSED];
+    for (int j = 0; j < SART_SCAN_ROW; ++j)
+      if ((F.counter_slots >> j) & 1u) o[j] = (double)v[j];
   } else if (k == 63 && F.shared_row >= 0) {
     for (int j = 0; j < SART_SCAN_ROW; ++j) { v[j] = in[(size_t)F.shared_row * SART_SCAN_ROW + j]; fixed_status_check_slot(v[j], status); }
     for (int j = 0; j < SART_SCAN_ROW; ++j) out[(size_t)F.shared_row * SART_SCAN_ROW + j] = (double)v[j];
@@ -2149,7 +2566,8 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
 // (reload_hot / reload_zones / reload_kernarg).  Not part of the C-ABI: tests/test_host_and_abi.py compares them with the
 // argument offsets in the code object's metadata, so that a compiler that lays arguments out differently fails a CPU test
 // instead of faulting on the GPU.
-extern "C" __attribute__((visibility("default"))) void sart_internal_kernarg_layout(int32_t out[7]) {
+extern "C" __attribute__((visibility("default"))) void sart_internal_kernarg_layout(int32_t out[8]) {
+  out[7] = (int32_t)sizeof(AScanKernArgs);   // (the angular-scan kernel: same offsets, its own last argument)
   out[0] = (int32_t)offsetof(HistKernArgs, H);
   out[1] = (int32_t)offsetof(HistKernArgs, blob);
   out[2] = (int32_t)offsetof(HistKernArgs, A);
@@ -2277,6 +2695,30 @@ bool launch_trace_mass_scan(const HotA& H, const HotB& HB, const DevBlob* blob, 
   return true;
 }
 
+// One group of AN.n_angles <= kAScanMaxAngles telescope angles over the rays of A: trace + per-angle accumulation, then the fold
+// into `rows` (the group's first row of the scan accumulator) and, if `shared_row`, into the scan's counter row.  `fast`: the
+// specialised instantiation (solar source, no hole loop, vacuum), else the one that reads those switches at run time.
+int angular_scan_blocks_per_cu(bool fast) {
+  int n = 0;
+  const hipError_t e = fast ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_angular_scan_kernel<1024, true, 0, false>, 1024, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, trace_angular_scan_kernel<1024, false, -1, false>, 1024, 0);
+  return (e == hipSuccess && n > 0) ? n : 1;
+}
+void launch_trace_angular_scan(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, const AScanArgs& AN, double* rows,
+                               double* shared_row, int n_blocks, hipStream_t stream, bool fast, bool fixed) {
+  double* const no_acc = nullptr;
+  switch ((fast ? 2 : 0) + (fixed ? 1 : 0)) {
+    case 0: hipLaunchKernelGGL((trace_angular_scan_kernel<1024, false, -1, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, no_acc, HB, AN); break;
+    case 1: hipLaunchKernelGGL((trace_angular_scan_kernel<1024, false, -1, true>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, no_acc, HB, AN); break;
+    case 2: hipLaunchKernelGGL((trace_angular_scan_kernel<1024, true, 0, false>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, no_acc, HB, AN); break;
+    default: hipLaunchKernelGGL((trace_angular_scan_kernel<1024, true, 0, true>), dim3(n_blocks), dim3(1024), 0, stream, H, blob, A, no_acc, HB, AN); break;
+  }
+  if (fixed)
+    hipLaunchKernelGGL(fold_ascan_kernel<true>, dim3(1), dim3(1024), 0, stream, rows, shared_row, AN.partials, n_blocks, AN.n_angles, (double)A.n_rays);
+  else
+    hipLaunchKernelGGL(fold_ascan_kernel<false>, dim3(1), dim3(1024), 0, stream, rows, shared_row, AN.partials, n_blocks, AN.n_angles, (double)A.n_rays);
+}
+
 size_t fixed_check_bytes() { return sizeof(FixedCheck); }
 void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectra, int n_radial_bins, int n_energies1, double q_w,
                            double q_w2, double q_pos, double q_refl, void* check_dev, hipStream_t stream) {
@@ -2290,11 +2732,12 @@ void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectr
 }
 // rows [0, n_masses) of in / out with the quanta q_w[k], q_w2[k]; shared_row >= 0: that row (relative to `in`) holds the counters
 void launch_finalize_scan(const void* in, double* out, int n_masses, const double* q_w, const double* q_w2, int shared_row,
-                          void* check_dev, hipStream_t stream) {
+                          void* check_dev, hipStream_t stream, uint32_t counter_slots) {
   FinalizeScanArgs F;
   memset(&F, 0, sizeof F);
   F.n_masses = n_masses;
   F.shared_row = shared_row;
+  F.counter_slots = counter_slots;
   for (int k = 0; k < n_masses; ++k) { F.q_w[k] = q_w[k]; F.q_w2[k] = q_w2[k]; }
   hipLaunchKernelGGL(finalize_scan_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const long long*>(in), out, F, static_cast<FixedCheck*>(check_dev));
 }

@@ -385,6 +385,35 @@ class RayTracer:
         _lib.check(self.lib.sart_finalize_mass_scan_device(self.handle, C.byref(params), _lib.as_dp(masses), masses.size,
                                                            C.c_void_p(raw_ptr), C.c_void_p(out_ptr if out_ptr is not None else raw_ptr)))
 
+    # -- fused angular scan (include/sart.h "fused angular scan") -------------------------------
+    def trace_angular_scan(self, turned_y_deg, n_rays: int, seed: int = 299792458, ray_id_offset: int = 0, flags: int | None = None):
+        """Every ray of [ray_id_offset, ray_id_offset + n_rays) sampled and taken through bore and pipes ONCE and turned through
+        every telescope angle.  Returns (per-angle dict of arrays SUM_WEIGHTS / SUM_WEIGHTS_SQ / N_PASSED / N_SHELL_SELECTED /
+        N_HIT_NICKEL / N_PASSED_TILL_WINDOW, dict of the angle-independent counters)."""
+        angles = np.ascontiguousarray(turned_y_deg, dtype=np.float64)
+        p = self.trace_params(n_rays, seed, ray_id_offset, flags)
+        out = np.empty(angular_scan_len(angles.size))
+        _lib.check(self.lib.sart_trace_angular_scan(self.handle, C.byref(p), _lib.as_dp(angles), angles.size, _lib.as_dp(out)))
+        return split_angular_scan(out, angles.size)
+
+    def trace_angular_scan_device(self, params: TraceParams, turned_y_deg, scan_acc_ptr: int):
+        """Asynchronous form: adds into a device scan accumulator of angular_scan_len(n) 8-byte slots (raw int64 in fixed64 mode)."""
+        angles = np.ascontiguousarray(turned_y_deg, dtype=np.float64)
+        _lib.check(self.lib.sart_trace_angular_scan_device(self.handle, C.byref(params), _lib.as_dp(angles), angles.size,
+                                                           C.c_void_p(scan_acc_ptr)))
+
+    def finalize_angular_scan_device(self, params: TraceParams, n_angles: int, raw_ptr: int, out_ptr: int | None = None):
+        """Raw FIXED64 scan accumulator (device) -> doubles (device; in place by default).  Asynchronous."""
+        _lib.check(self.lib.sart_finalize_angular_scan_device(self.handle, C.byref(params), int(n_angles), C.c_void_p(raw_ptr),
+                                                              C.c_void_p(out_ptr if out_ptr is not None else raw_ptr)))
+
+    def trace_flux(self, n_rays: int, seed: int = 299792458, ray_id_offset: int = 0, flags: int | None = None):
+        """Flux-only launch (image_nx = image_ny = 0, include/sart.h): the summary of trace_histogram without an image."""
+        p = self.trace_params(n_rays, seed, ray_id_offset, flags, 0, False)
+        summ = Summary()
+        _lib.check(self.lib.sart_trace_histogram(self.handle, C.byref(p), None, C.byref(summ)))
+        return {k: summ.v[i] for k, i in _lib.ACC.items()}
+
     # -- measurement --------------------------------------------------------------------------
     def enable_kernel_timing(self, enable: bool = True):
         _lib.check(self.lib.sart_enable_kernel_timing(self.handle, 1 if enable else 0))
@@ -450,6 +479,19 @@ def split_mass_scan(acc: np.ndarray, n_masses: int):
     return per_mass, shared
 
 
+def angular_scan_len(n_angles: int) -> int:
+    """sart_angular_scan_len: 8-byte slots of an angular-scan accumulator."""
+    return (int(n_angles) + 1) * _lib.ASCAN_ROW
+
+
+def split_angular_scan(acc: np.ndarray, n_angles: int):
+    """(per-angle dict of arrays, shared-counter dict) from a finalized angular-scan accumulator."""
+    rows = np.asarray(acc, dtype=np.float64).reshape(n_angles + 1, _lib.ASCAN_ROW)
+    per_angle = {k: rows[:n_angles, i].copy() for k, i in _lib.ASCAN.items()}
+    shared = {k: float(rows[n_angles, i]) for k, i in _lib.ASCAN_SHARED.items()}
+    return per_angle, shared
+
+
 def calculateFluxFractions(tracer: RayTracer, n_rays: int = 1_000_000, seed: int = 299792458,
                            ray_id_offset: int = 0):
     """calculateFluxFractions (raytracer.nim:2755-2776) in histogram form: NumberOfPointsSun rays ->
@@ -491,15 +533,24 @@ def performAxionMassScanHostLoop(tracer: RayTracer, masses_ev, n_rays_per_mass: 
 
 def performAngularScan(tracer: RayTracer, angularScanMin: float, angularScanMax: float, numAngularScanPoints: int = 50,
                        n_rays_per_angle: int = 1_000_000, seed: int = 299792458, flags: int | None = None,
-                       angles=None, ray_id_offset: int = 0):
+                       angles=None, ray_id_offset: int = 0, fused: bool = False, errors: bool = False):
     """performAngularScan (raytracer.nim:2778-2802) through the C++ host driver: returns (angles, fluxes,
-    relative fluxes).  ``angles`` overrides the linspace (used when angle bins are sharded over GPUs)."""
+    relative fluxes).  ``angles`` overrides the linspace (used when angle bins are sharded over GPUs).
+    ``fused = False``: the reference's shape - a host loop, angle i on its own block of fresh ray ids (flux-only launches).
+    ``fused = True``: the fused scan kernel - every ray of [ray_id_offset, ray_id_offset + n_rays_per_angle) is sampled once
+    and turned through every angle (common random numbers); with ``errors`` also sqrt(sum of squared weights) and the
+    passed-ray counts."""
     host = _lib.load_host()
     angles = np.linspace(angularScanMin, angularScanMax, numAngularScanPoints) if angles is None else \
         np.ascontiguousarray(angles, dtype=np.float64)
     fluxes = np.empty_like(angles)
     rel = np.empty_like(angles)
     fl = tracer.full.flags if flags is None else flags
+    if fused:
+        sq, n_pass = np.empty_like(angles), np.empty_like(angles)
+        _lib.check(host.sart_host_angular_scan(tracer.handle, _lib.as_dp(angles), angles.size, n_rays_per_angle, seed, ray_id_offset,
+                                               fl, _lib.as_dp(fluxes), _lib.as_dp(rel), _lib.as_dp(sq), _lib.as_dp(n_pass)), host=True)
+        return (angles, fluxes, rel, np.sqrt(sq), n_pass) if errors else (angles, fluxes, rel)
     _lib.check(host.sart_host_perform_angular_scan(tracer.handle, _lib.as_dp(angles), angles.size, n_rays_per_angle,
                                                    seed, ray_id_offset, fl, _lib.as_dp(fluxes), _lib.as_dp(rel)), host=True)
     return angles, fluxes, rel

@@ -1,0 +1,313 @@
+"""Fused angular scan (include/sart.h: sart_trace_angular_scan; BASELINE configs[3]) on the MI355X box.
+
+performAngularScan (raytracer.nim:2778-2802) re-runs the whole trace per telescope angle.  The angle enters a ray at the
+transformation into the telescope's frame (:1878-1899) and nowhere before it, so the scan kernel samples every ray and takes it
+through bore and pipes once and turns it through K angles.  Demanded here, per angle:
+  * SART_ACCUM_FIXED64: the raw integers and all counters equal those of a single-angle launch (sart_set_telescope_angles +
+    trace) on the same ray ids - bit for bit, for both kernel instantiations, for any split of the rays and of the angles;
+  * SART_ACCUM_F64: the flux equals the single-angle launch to 1e-12 (summation order);
+  * the flux equals the CPU oracle (80-bit build) with that angle to 1e-6, on small and on full-size tables;
+and for the flux-only launches (image_nx = image_ny = 0) the host-loop scan uses: the scalars of an ordinary launch, bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+import solaraxionraytracing_amd as sa
+from solaraxionraytracing_amd import _lib as L
+
+from tests.conftest import make_setup
+
+pytestmark = pytest.mark.gpu
+
+N_IMG = 256 * 256
+
+
+def angles(k, top=0.4):
+    """k telescope angles in degrees, none of them zero (a single launch at angle 0 runs the unrotated kernel)."""
+    return np.ascontiguousarray(np.linspace(0.02, top, k))
+
+
+class env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def raw_single(rt, torch, angle, n, seed, off=0, flags=None):
+    """Scalars of the raw FIXED64 accumulator of one single-angle launch."""
+    acc = torch.zeros(sa.accumulator_len(256), dtype=torch.int64, device="cuda")
+    rt.set_telescope_angles(turned_y_deg=float(angle))
+    p = rt.trace_params(n, seed=seed, ray_id_offset=off, flags=flags, accumulate=False)
+    rt.trace_histogram_device(p, acc.data_ptr())
+    rt.synchronize()
+    return acc.cpu().numpy()[N_IMG:]
+
+
+def raw_scan(rt, torch, an, pieces, seed, flags=None):
+    acc = torch.zeros(sa.angular_scan_len(len(an)), dtype=torch.int64, device="cuda")
+    for lo, hi in pieces:
+        p = rt.trace_params(hi - lo, seed=seed, ray_id_offset=lo, flags=flags, accumulate=True)
+        rt.trace_angular_scan_device(p, an, acc.data_ptr())
+    rt.synchronize()
+    return acc.cpu().numpy().reshape(len(an) + 1, L.ASCAN_ROW)
+
+
+VARIANTS = {
+    # specialised instantiation: solar source, vacuum, no hole loop (the single launches run histogram variant 4)
+    "babyiaxo_xmm": ("babyiaxo_xmm", {}, None),
+    # the same with a fixed tilt about x under the scanned angle
+    "babyiaxo_xmm_turned_x": ("babyiaxo_xmm", {}, "turned_x"),
+    # generic instantiation (switches read at run time; single launches: histogram variant 2)
+    "generic": ("babyiaxo_xmm", {"SART_FORCE_GENERIC": "1"}, None),
+    # gas stage: rotated + gas has no specialised kernel on either side
+    "gas": ("babyiaxo_xmm_gas", {}, None),
+    # X-ray test source: no stage A0 (no zones), one energy row
+    "xray_test_source": ("babyiaxo_xmm_xray", {}, None),
+    # cone optics, four coatings, a 43 mm bore that rays do enter through the wall
+    "cast_llnl": ("cast_llnl", {}, None),
+    # CAST + Abrixas (27 Wolter shells, six spokes)
+    "cast_abrixas": ("cast_abrixas", {}, None),
+    # stage A0 switched off: phase A runs on the rays as they come
+    "no_early_reject": ("babyiaxo_xmm", {"SART_NO_EARLY_REJECT": "1"}, None),
+}
+
+
+def variant_setup(name):
+    setup_name, knobs, tweak = VARIANTS[name]
+    full = make_setup(setup_name)
+    if tweak == "turned_x":
+        full.setup.telescope_turned_x_deg = 0.03
+    return full, knobs, (full.flags if setup_name.endswith("xray") else None)
+
+
+def check_rows_equal_singles(scan, an, singles, n, label):
+    shared = scan[len(an)]
+    assert shared[L.ASCAN_SHARED["N_RAYS"]] == n
+    for k, s in enumerate(singles):
+        row = scan[k]
+        for key in ("SUM_WEIGHTS", "SUM_WEIGHTS_SQ"):
+            assert row[L.ASCAN[key]] == s[L.ACC[key]] and row[L.ASCAN_HI[key]] == s[L.ACC_HI[key]], (label, k, key, row, s)
+        for key in ("N_PASSED", "N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW"):
+            assert row[L.ASCAN[key]] == s[L.ACC[key]], (label, k, key, row[L.ASCAN[key]], s[L.ACC[key]])
+        assert shared[L.ASCAN_SHARED["N_REACHED_TELESCOPE"]] == s[L.ACC["N_REACHED_TELESCOPE"]], (label, k)
+        assert 0 <= row[L.ASCAN["SUM_WEIGHTS"]] < 2 ** L.FIXED_LIMB_BITS
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_fixed64_scan_equals_single_angle_launches_bit_for_bit(name):
+    import torch
+    full, knobs, flags = variant_setup(name)
+    an = angles(19, top=1.2 if name.startswith("cast") else 0.4)   # two groups of angles: 10 + 9
+    n, seed = 2_000_000, 17
+    with env(**knobs):
+        with sa.RayTracer(full) as rt:
+            rt.set_accumulation_mode("fixed64")
+            scan = raw_scan(rt, torch, an, [(0, n)], seed, flags)
+            split = raw_scan(rt, torch, an, [(0, 700_001), (700_001, n)], seed, flags)   # rays in two accumulating calls
+            y0 = rt.full.setup.telescope_turned_y_deg
+            singles = [raw_single(rt, torch, a, n, seed, flags=flags) for a in an]
+            rt.set_telescope_angles(turned_y_deg=y0)
+    assert np.array_equal(scan, split)
+    assert scan[:len(an), L.ASCAN["N_PASSED"]].max() > 1000
+    check_rows_equal_singles(scan, an, singles, n, name)
+
+
+def test_fixed64_scan_is_independent_of_the_grouping_of_the_angles():
+    """16 angles per launch: 33 angles run as 11 + 11 + 11; every row equals the row of a scan of that angle alone."""
+    import torch
+    full = make_setup("babyiaxo_xmm")
+    an = angles(33)
+    n, seed = 1_000_000, 29
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode("fixed64")
+        scan = raw_scan(rt, torch, an, [(0, n)], seed)
+        for k in (0, 10, 11, 21, 22, 32):
+            one = raw_scan(rt, torch, an[k:k + 1], [(0, n)], seed)
+            assert np.array_equal(one[0], scan[k]), k
+            assert np.array_equal(one[1], scan[len(an)])
+
+
+@pytest.mark.parametrize("flags", [L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS, L.CF_IGNORE_REFLECTION,
+                                   L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_REFLECTION | L.CF_IGNORE_GAS_ABS | L.CF_IGNORE_CONV_PROB])
+def test_fixed64_scan_equals_single_angle_launches_under_the_ignore_flags(flags):
+    import torch
+    full = make_setup("babyiaxo_xmm")
+    an = angles(5)
+    n, seed = 1_000_000, 23
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode("fixed64")
+        scan = raw_scan(rt, torch, an, [(0, n)], seed, flags)
+        singles = [raw_single(rt, torch, a, n, seed, flags=flags) for a in an]
+    check_rows_equal_singles(scan, an, singles, n, flags)
+
+
+def test_fixed64_scan_finalize_equals_finalized_single_launches():
+    """The quanta are a function of (setup, tables, flags, headroom): finalize of the raw scan gives the very doubles the
+    blocking single-angle call returns, and the blocking scan call returns them, too."""
+    full = make_setup("babyiaxo_xmm")
+    an = angles(7)
+    n, seed = 2_000_000, 3
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode("fixed64")
+        per_angle, shared = rt.trace_angular_scan(an, n, seed=seed)
+        for k, a in enumerate(an):
+            rt.set_telescope_angles(turned_y_deg=float(a))
+            s = rt.trace_histogram(n, seed=seed)[1]
+            for key in ("SUM_WEIGHTS", "SUM_WEIGHTS_SQ", "N_PASSED", "N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW"):
+                assert np.float64(per_angle[key][k]).view(np.uint64) == np.float64(s[key]).view(np.uint64), (k, key, per_angle[key][k], s[key])
+        assert shared["N_RAYS"] == n
+        assert np.all(np.isfinite(per_angle["SUM_WEIGHTS_SQ"]))
+
+
+@pytest.mark.parametrize("name", ["babyiaxo_xmm", "generic", "gas", "cast_llnl"])
+def test_f64_scan_equals_single_angle_launches(name):
+    full, knobs, flags = variant_setup(name)
+    an = np.concatenate([[0.0], angles(17, top=1.2 if name.startswith("cast") else 0.4)])   # with angle 0: the unrotated kernel on the other side
+    n, seed = 2_000_000, 5
+    with env(**knobs):
+        with sa.RayTracer(full) as rt:
+            per_angle, shared = rt.trace_angular_scan(an, n, seed=seed, flags=flags)
+            for k, a in enumerate(an):
+                rt.set_telescope_angles(turned_y_deg=float(a))
+                s = rt.trace_histogram(n, seed=seed, flags=flags)[1]
+                # (angle 0: the unrotated kernel's frame change is exact, the rotation by 0 rounds - a ray within 1e-13 mm of a cut may differ)
+                slack = 2 if a == 0.0 else 0
+                for key in ("N_PASSED", "N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW"):
+                    assert abs(per_angle[key][k] - s[key]) <= slack, (name, k, key)
+                assert shared["N_REACHED_TELESCOPE"] == s["N_REACHED_TELESCOPE"]
+                if per_angle["N_PASSED"][k] == s["N_PASSED"]:
+                    assert per_angle["SUM_WEIGHTS"][k] == pytest.approx(s["SUM_WEIGHTS"], rel=1e-12), (name, k)
+                    assert per_angle["SUM_WEIGHTS_SQ"][k] == pytest.approx(s["SUM_WEIGHTS_SQ"], rel=1e-11), (name, k)
+
+
+@pytest.mark.parametrize("name", ["babyiaxo_xmm", "xray_test_source", "cast_llnl", "gas"])
+def test_scan_matches_the_oracle_per_angle(name):
+    from oracle.oracle import Oracle
+    full, knobs, flags = variant_setup(name)
+    an = np.concatenate([[0.0], angles(6, top=1.0 if name.startswith("cast") else 0.3)])
+    n, seed = 100_000, 4
+    with sa.RayTracer(full) as rt:
+        per_angle, shared = rt.trace_angular_scan(an, n, seed=seed, flags=flags)
+    o = Oracle(full, "ld")
+    for k, a in enumerate(an):
+        s = full.setup.copy()
+        s.telescope_turned_y_deg = float(a)
+        want = o.trace_histogram(n, seed=seed, setup=s, flags=flags)[1]
+        # (a ray within rounding of a cut may fall on the other side in the 80-bit oracle: then the flux differs by that ray)
+        same_rays = per_angle["N_PASSED"][k] == want["N_PASSED"]
+        assert abs(per_angle["N_PASSED"][k] - want["N_PASSED"]) <= 2
+        assert per_angle["SUM_WEIGHTS"][k] == pytest.approx(want["SUM_WEIGHTS"], rel=1e-6 if same_rays else 1e-3), (name, k, a)
+        for key in ("N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW"):
+            assert abs(per_angle[key][k] - want[key]) <= 2, (name, k, key)
+        assert abs(shared["N_REACHED_TELESCOPE"] - want["N_REACHED_TELESCOPE"]) <= 2
+
+
+def test_scan_on_full_size_tables_matches_the_oracle_and_the_host_loop():
+    """BASELINE configs[3] at its table sizes (1968 x 1500 CDFs, 1000 x 1000 reflectivity): 50 angles of the XMM off-axis curve
+    through the C++ host driver (four launches of 13 / 13 / 12 / 12 angles), three of them against the 80-bit oracle and the
+    single-angle launches."""
+    from oracle.oracle import Oracle
+    full = sa.initFullSetup()
+    full.setup.chip_x_max = full.setup.chip_y_max = 100.0          # ChipXMax = 100 mm (raytracer.nim:262-264): the spot walks 65 mm at 0.5 deg
+    flags = L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS | L.CF_IGNORE_CONV_PROB   # the effective-area flags (cf. :2315)
+    an = np.linspace(0.0, 0.5, 50)
+    n, seed = 4_000_000, 11
+    with sa.RayTracer(full) as rt:
+        a_out, flux, rel, err, n_pass = sa.performAngularScan(rt, 0.0, 0.5, 50, n_rays_per_angle=n, seed=seed, flags=flags, fused=True, errors=True)
+        assert np.array_equal(a_out, an) and rel.max() == 1.0 and int(np.argmax(flux)) <= 2
+        assert np.all(err > 0) and np.all(err < 0.05 * flux)
+        for k in (7, 24, 49):
+            rt.set_telescope_angles(turned_y_deg=float(an[k]))
+            s = rt.trace_histogram(n, seed=seed, flags=flags)[1]
+            assert flux[k] == pytest.approx(s["SUM_WEIGHTS"], rel=1e-12) and n_pass[k] == s["N_PASSED"], k
+        rt.set_telescope_angles(turned_y_deg=0.0)
+        n_o = 400_000
+        per_angle, _ = rt.trace_angular_scan(an[[7, 24, 49]], n_o, seed=seed, flags=flags)
+    o = Oracle(full, "ld")
+    for j, k in enumerate((7, 24, 49)):
+        s = full.setup.copy()
+        s.telescope_turned_y_deg = float(an[k])
+        want = o.trace_histogram(n_o, seed=seed, setup=s, flags=flags)[1]
+        assert abs(per_angle["N_PASSED"][j] - want["N_PASSED"]) <= 2
+        assert per_angle["SUM_WEIGHTS"][j] == pytest.approx(want["SUM_WEIGHTS"], rel=1e-6 if per_angle["N_PASSED"][j] == want["N_PASSED"] else 1e-4), k
+    # the curve falls off with the angle (XMM's vignetting): what the reference plots against the McXtrace / XMM curves (:2803-2815)
+    assert rel[49] < 0.6 * rel[0]
+
+
+def test_scan_accumulation_errors_and_zero_rays():
+    full = make_setup("babyiaxo_xmm")
+    an = angles(5)
+    with sa.RayTracer(full) as rt:
+        pa, sh = rt.trace_angular_scan(an, 0, seed=2)
+        assert not pa["SUM_WEIGHTS"].any() and sh["N_RAYS"] == 0
+        for bad in (np.array([0.1, np.nan]), np.array([90.0]), np.array([])):
+            with pytest.raises(L.SartError) as e:
+                rt.trace_angular_scan(bad, 1000)
+            assert e.value.code == L.SART_ERR_INVALID_ARGUMENT
+        # the context's own angle is untouched by a scan, and a histogram launch afterwards runs the unrotated kernel as before
+        before = rt.trace_histogram(300_000, seed=2)[1]
+        rt.trace_angular_scan(an, 300_000, seed=2)
+        after = rt.trace_histogram(300_000, seed=2)[1]
+        assert before == after
+
+
+@pytest.mark.parametrize("name", ["babyiaxo_xmm", "babyiaxo_xmm_rot", "cast_llnl", "babyiaxo_xmm_gas"])
+@pytest.mark.parametrize("mode", ["f64", "fixed64"])
+def test_flux_only_launch_equals_the_scalars_of_an_image_launch(name, mode):
+    """image_nx = image_ny = 0: no image, no LDS tile, no pilot launch - and the very same scalars (every passed ray counts as
+    outside the image: N_OUTSIDE_IMAGE = N_PASSED)."""
+    full = make_setup(name)
+    n, seed = 1_500_000, 8
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode(mode)
+        img, want = rt.trace_histogram(n, seed=seed)
+        got = rt.trace_flux(n, seed=seed)
+    assert got["N_OUTSIDE_IMAGE"] == got["N_PASSED"] == want["N_PASSED"] > 1000
+    for key in ("N_RAYS", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW"):
+        assert got[key] == want[key], key
+    for key in ("SUM_WEIGHTS", "SUM_WEIGHTS_SQ", "SUM_X", "SUM_Y", "SUM_R"):
+        if mode == "fixed64":
+            assert np.float64(got[key]).view(np.uint64) == np.float64(want[key]).view(np.uint64), key
+        else:
+            assert got[key] == pytest.approx(want[key], rel=1e-12), key
+
+
+def test_host_loop_scan_uses_fresh_rays_per_angle_and_restores_the_setup():
+    """sart_host_perform_angular_scan keeps the reference's shape (raytracer.nim:2791-2800): angle i on ray ids
+    [offset + i n, offset + (i + 1) n), flux-only launches, the setup's own angle back afterwards."""
+    full = make_setup("babyiaxo_xmm")
+    an = angles(4)
+    n, seed = 500_000, 6
+    with sa.RayTracer(full) as rt:
+        a_out, flux, rel = sa.performAngularScan(rt, 0, 0, angles=an, n_rays_per_angle=n, seed=seed, ray_id_offset=1000)
+        assert rt.trace_flux(n, seed=seed) == rt.trace_flux(n, seed=seed)
+        for i, a in enumerate(an):
+            rt.set_telescope_angles(turned_y_deg=float(a))
+            want = rt.trace_histogram(n, seed=seed, ray_id_offset=1000 + i * n)[1]["SUM_WEIGHTS"]
+            assert flux[i] == pytest.approx(want, rel=1e-12)
+    assert rel.max() == 1.0
+
+
+def test_scan_cli_fused_writes_the_curve(tmp_path):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "angle.csv")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "scan.py"), "angular", "--numAngularScanPoints", "9", "--rays", "1e6", "--angularScanMin", "0",
+                        "--angularScanMax", "0.4", "--fused", "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = [l.split(",") for l in open(out).read().splitlines()]
+    assert len(rows) == 10
+    rel = np.array([float(x[2]) for x in rows[1:]])
+    assert rel.max() == 1.0 and rel[-1] < rel[0]

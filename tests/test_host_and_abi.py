@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(sart_[a-z0-9_]+)\s*\(", txt)) - {"sart_accumulator_len", "sart_accumulator_len_spectra", "sart_mass_scan_len"})  # static inline helpers
+    return sorted(set(re.findall(r"\b(sart_[a-z0-9_]+)\s*\(", txt)) - {"sart_accumulator_len", "sart_accumulator_len_spectra", "sart_mass_scan_len", "sart_angular_scan_len"})  # static inline helpers
 
 
 def test_libsart_exports_every_declared_symbol():
@@ -25,7 +25,7 @@ def test_libsart_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(L.SART_SYMBOLS) == names          # the ctypes table binds exactly the header
-    assert lib.sart_abi_version() == L.SART_ABI_VERSION == 2
+    assert lib.sart_abi_version() == L.SART_ABI_VERSION == 3
 
 
 def test_libsart_host_exports_every_declared_symbol():
@@ -42,7 +42,7 @@ def test_kernel_argument_layout_matches_the_code_object(tmp_path):
     import shutil
     import subprocess
     lib = L.load_sart()
-    want = (C.c_int32 * 7)()
+    want = (C.c_int32 * 8)()
     lib.sart_internal_kernarg_layout(want)
     obj = tmp_path / "sart_kernels.o"
     shutil.copy(os.path.join(ROOT, "solaraxionraytracing_amd", "csrc", "build", "sart_kernels.o"), obj)
@@ -57,16 +57,17 @@ def test_kernel_argument_layout_matches_the_code_object(tmp_path):
     seen = 0
     for k in kernels:
         m = re.search(r"\.name:\s+(\S+)", k)
-        if not m or "trace_histogram_kernel" not in m.group(1):
+        if not m or not ("trace_histogram_kernel" in m.group(1) or "trace_angular_scan_kernel" in m.group(1)):
             continue
         args = re.findall(r"\.offset:\s+(\d+)\s+\.size:\s+(\d+)\s+\.value_kind:\s+(\w+)", k)
         explicit = [(int(o), int(sz)) for o, sz, kind in args if not kind.startswith("hidden")]
         assert [o for o, _ in explicit] == list(want[:6]), (m.group(1), explicit, list(want))
-        assert explicit[-1][0] + explicit[-1][1] <= want[6]
+        assert explicit[-1][0] + explicit[-1][1] <= want[7 if "angular_scan" in m.group(1) else 6]
         seen += 1
     # {specialised (vacuum and gas, each with and without the constant path; rotated), generic, generic rotated} x {f64, FIXED64}
     # + the fused mass scan for the four variants that can run the gas stage x {f64, FIXED64}
-    assert seen == 14 + 8
+    # + the fused angular scan (same argument offsets: it shares the reload helpers) {specialised, generic} x {f64, FIXED64}
+    assert seen == 14 + 8 + 4
 
 
 def test_code_object_keeps_what_the_design_counts_on(tmp_path):
@@ -92,10 +93,10 @@ def test_code_object_keeps_what_the_design_counts_on(tmp_path):
         g = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, k).group(1))
         assert g("private_segment_fixed_size") == 0 and g("vgpr_spill_count") == 0, m.group(1)
         assert g("vgpr_count") <= 128, (m.group(1), g("vgpr_count"))
-        if "trace_histogram_kernel" in m.group(1):
+        if "trace_histogram_kernel" in m.group(1) or "trace_angular_scan_kernel" in m.group(1):
             assert 160 * 1024 - 4096 < g("group_segment_fixed_size") <= 160 * 1024, g("group_segment_fixed_size")
         seen += 1
-    assert seen == 23   # fourteen histogram + eight mass-scan instantiations + the record kernel
+    assert seen == 27   # fourteen histogram + eight mass-scan + four angular-scan instantiations + the record kernel
     asm = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--mcpu=gfx950", str(tmp_path / dev[0])], capture_output=True,
                          text=True, check=True).stdout
     body = asm.split("<_ZN4sart22trace_histogram_kernelILi1024ELb1ELb0ELi0ELb1ELb0ELb0EEEvNS_4HotAEPKNS_7DevBlobENS_9TraceArgsEPdNS_4HotBENS_8ScanArgsE>:")

@@ -2,9 +2,14 @@
 """Scan drivers of the hot path, one process per GPU:
 
   angular   performAngularScan (raytracer.nim:2778-2815; CLI --angularScanMin/Max --numAngularScanPoints, :2817-2862):
-            effective-area style scan of telescope_turned_y, angle bins sharded over the ranks (BASELINE config 4).
+            effective-area style scan of telescope_turned_y, angle bins sharded over the ranks (BASELINE configs[3]).
             Writes a CSV (the reference only makes a PDF) and compares with the two curves the reference overlays
             (xmm_newton_angular_effective_area.csv, McXtrace_angular_xmm.csv; :2805-2813).
+            Default: the reference's shape, a flux-only re-trace per angle on fresh rays.  --fused: the FUSED scan kernel
+            (sart_trace_angular_scan): every ray is sampled and taken through bore and pipes once and turned through every
+            angle of the rank's group (--shard bins: the angles are dealt out to the ranks, every rank traces all ray ids
+            for its angles; --shard rays: every rank traces its share of the ray ids for all angles, one reduce of the scan
+            accumulator) - all angles see the same rays, the curve does not depend on the number of ranks.
   mass      gas-stage axion-mass scan on the full AGSS09 emission table (BASELINE configs[4]) through the FUSED scan kernel
             (sart_trace_mass_scan): every rank traces its share of the ray ids ONCE and weighs each ray for every mass; one
             reduce of the scan accumulator (8 (points + 1) slots) over the ranks closes the scan ("1e10 rays across 8 MI355X
@@ -39,6 +44,7 @@ def main():
                     help="angular scan, mass --host-loop: bins = every scan point is a full run on one rank (BASELINE config 4); "
                          "rays = every rank traces its share of the ray ids of every point and the accumulators are reduced once per "
                          "point.  The fused mass scan always shards the rays")
+    ap.add_argument("--fused", action="store_true", help="angular: the fused scan kernel (same rays for every angle) instead of a re-trace per angle")
     ap.add_argument("--host-loop", action="store_true",
                     help="mass: one re-trace per mass point (what the fused scan replaces; independent ray blocks per point)")
     ap.add_argument("--emission", default=None, choices=["agss09-device", "agss09", "primakoff", "legacy", "flat"],
@@ -80,7 +86,36 @@ def main():
         xs = np.linspace(args.massMin, args.massMax, args.points)
     fused = args.mode == "mass" and not args.host_loop
     errs = None
-    if fused:
+    if args.mode == "angular" and args.fused and args.shard == "rays":
+        # Fused angular scan, rays sharded: rank r turns ray ids [lo_r, hi_r) through ALL angles into a device scan accumulator;
+        # ONE reduce of 8 (points + 1) slots over the ranks (int64 when fixed64).
+        use_cuda = not (world > 1 and torch.distributed.get_backend() != "nccl")
+        fixed64 = args.accumulation == "fixed64"
+        acc = torch.zeros(sa.angular_scan_len(len(xs)), dtype=torch.float64, device=torch.device("cuda", local_rank))
+        lo, hi = D.shard_range(n_rays, rank, world)
+        with sa.RayTracer(full, device=local_rank) as rt:
+            stream = torch.cuda.Stream(device=acc.device)
+            torch.cuda.set_stream(stream)
+            rt.set_stream(stream.cuda_stream)
+            rt.set_accumulation_mode(args.accumulation)
+            p = rt.trace_params(hi - lo, ray_id_offset=lo, flags=flags, accumulate=True)
+            rt.trace_angular_scan_device(p, xs, acc.data_ptr())
+            red = acc if use_cuda else acc.cpu()
+            D.reduce_accumulator(red, dst=0, fixed64=fixed64)
+            if fixed64:
+                if not use_cuda:
+                    acc.copy_(red)
+                rt.finalize_angular_scan_device(p, len(xs), acc.data_ptr())
+                rt.synchronize()
+                red = acc
+            red = red.cpu()
+        per_angle, shared = sa.split_angular_scan(red.numpy(), len(xs))
+        curve = per_angle["SUM_WEIGHTS"]
+        errs = np.sqrt(per_angle["SUM_WEIGHTS_SQ"])
+        if rank == 0:
+            assert shared["N_RAYS"] == n_rays, (shared, n_rays)
+        mine = None
+    elif fused:
         # Fused scan: rank r traces ray ids [lo_r, hi_r) ONCE for all masses into a device scan accumulator; ONE reduce of
         # 8 (points + 1) slots over the ranks (int64 when fixed64: the curve then does not depend on the number of ranks).
         use_cuda = not (world > 1 and torch.distributed.get_backend() != "nccl")
@@ -149,6 +184,9 @@ def main():
     with sa.RayTracer(full, device=local_rank) if mine is not None else _Null() as rt:
         if mine is None:
             pass
+        elif args.mode == "angular" and args.fused:
+            # this rank's group of angles through the fused kernel, on the ray ids [0, n_rays) like every other rank's group
+            vals = list(sa.performAngularScan(rt, 0, 0, 1, n_rays, flags=flags, angles=xs[mine], fused=True)[1]) if len(mine) else []
         elif args.mode == "angular":
             # every bin keeps its own ray-id block so that the result does not depend on the number of ranks
             vals = [sa.performAngularScan(rt, 0, 0, 1, n_rays, flags=flags, angles=[xs[i]], ray_id_offset=i * n_rays)[1][0] for i in mine]
@@ -169,7 +207,7 @@ def main():
                 mcx = np.interp(xs, ref["mcxtrace_angle_deg"], ref["mcxtrace_rel_flux"])
                 f.write("Angle [deg],flux,relative flux,XMM theory,McXtrace\n")
                 for a, c, r, t, m in zip(xs, curve, rel, xmm, mcx):
-                    f.write("%.6g,%.10g,%.8f,%.6f,%.6f\n" % (a, c, r, t, m))
+                    f.write("%.6g,%.17g,%.8f,%.6f,%.6f\n" % (a, c, r, t, m))
                 print("angular scan: relative flux", np.round(rel, 4).tolist())
                 print("XMM theory          :", np.round(xmm, 4).tolist())
                 print("McXtrace            :", np.round(mcx, 4).tolist())
