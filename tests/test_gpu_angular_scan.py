@@ -311,3 +311,25 @@ def test_scan_cli_fused_writes_the_curve(tmp_path):
     assert len(rows) == 10
     rel = np.array([float(x[2]) for x in rows[1:]])
     assert rel.max() == 1.0 and rel[-1] < rel[0]
+
+
+@pytest.mark.parametrize("shard", ["bins", "rays"])
+def test_fused_scan_driver_sharded_over_two_ranks_equals_one_process(tmp_path, shard):
+    """tools/scan.py angular --fused (BASELINE configs[3]: angle bins over the GPUs): two gloo ranks on this one GPU - the
+    angles dealt out to the ranks (--shard bins: every rank turns all ray ids through its group of angles), or the ray ids
+    (--shard rays: one reduce of the scan accumulator) - give the curve of the single process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a, b = str(tmp_path / "one.csv"), str(tmp_path / "two.csv")
+    common = ["angular", "--fused", "--numAngularScanPoints", "7", "--rays", "500000", "--angularScanMax", "0.3"]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "scan.py")] + common + ["--out", a], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    env2 = dict(os.environ, SART_BENCH_BACKEND="gloo", SART_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29573", os.path.join(root, "tools", "scan.py")] + common + ["--shard", shard, "--out", b],
+                       env=env2, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ca, cb = np.loadtxt(a, delimiter=",", skiprows=1, usecols=(0, 1, 2)), np.loadtxt(b, delimiter=",", skiprows=1, usecols=(0, 1, 2))
+    np.testing.assert_allclose(cb[:, 1], ca[:, 1], rtol=1e-12)
+    assert ca[:, 1].min() > 0 and ca[0, 1] > ca[-1, 1]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One measurement round on the GPU box:  bash tools/gpu_round.sh <tag> [tests] [bench] [stats] [pmc] [pmc_side] [pmc_scan] [pmc_emission] [sq] [fullsize] [sustained]
+# One measurement round on the GPU box:  bash tools/gpu_round.sh <tag> [tests] [bench] [stats] [pmc] [pmc_side] [pmc_scan] [pmc_ascan] [pmc_emission] [sq] [fullsize] [sustained]
 #   tests     pytest -m gpu                                  -> gpurun_out/pytest_gpu_<tag>.log
 #   bench     python bench.py                                -> gpurun_out/bench_<tag>.json
 #   stats     rocprofv3 --kernel-trace --stats on bench.py   -> gpurun_out/prof_<tag>/
@@ -31,6 +31,8 @@ for STEP in "$@"; do
       (cd $ROOT && PMC_PROGRAM=tools/emission_bench.py PMC_PASSES="1 2 3 9" timeout -k 10 600 bash tools/pmc_profile.sh ${TAG}_emission_table --no-cpu) ;;
     pmc_scan)   # the fused 32-mass scan workload (1e9-ray launches)
       (cd $ROOT && timeout -k 10 900 bash tools/pmc_profile.sh ${TAG}_babyiaxo_xmm_gas_scan32 --workload babyiaxo_xmm_gas_scan32) ;;
+    pmc_ascan)  # the fused 16-angle scan workload (2e8-ray launches)
+      (cd $ROOT && timeout -k 10 900 bash tools/pmc_profile.sh ${TAG}_babyiaxo_xmm_ascan16 --workload babyiaxo_xmm_ascan16 --rays-per-step 2e8) ;;
     sq)         # sequencer-side counters of the headline kernel (scalar unit, instruction fetch, FIFO stalls)
       (cd $ROOT && timeout -k 10 600 bash tools/pmc_sq.sh ${TAG}_babyiaxo_xmm > gpurun_out/${TAG}_pmc_sq.txt 2>&1) || { tail -20 $ROOT/gpurun_out/${TAG}_pmc_sq.txt; exit 1; }
       tail -3 $ROOT/gpurun_out/${TAG}_pmc_sq.txt ;;
