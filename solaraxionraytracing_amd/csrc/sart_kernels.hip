@@ -1421,7 +1421,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   const uint32_t n_chunks = (rel_end + 255u) >> 8;
 
   // wave-uniform counters (ballot + popcount) and per-lane sums
-  uint32_t n_reached = 0, n_shell = 0, n_nickel = 0, n_till = 0, n_passed = 0, n_outside = 0;
+  uint32_t n_reached = 0, n_shell = 0, n_nickel = 0, n_till = 0, n_passed = 0;
+  uint32_t n_outside = 0;    // per lane: passed rays outside the image
   using Sum = std::conditional_t<FIXED, long long, double>;   // per-lane sums: quanta (FIXED) or f64
   Sum sum_w = 0, sum_w2 = 0, sum_x = 0, sum_y = 0, sum_r = 0;
   long long sum_wo = 0;      // FIXED: weights of the passed rays outside the image (the finalize kernel's conservation check)
@@ -1592,8 +1593,10 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       const int nx = Al.image_nx, ny = Al.image_ny;
       // (lane masks of the four compares combined on the scalar unit; ballots in here see the passed lanes only)
       const uint64_t inside_m = ballot64(fx >= 0.0) & ballot64(fx < (double)nx) & ballot64(fy >= 0.0) & ballot64(fy < (double)ny);
-      n_outside += (uint32_t)__popcll(out.m_passed & ~inside_m);
       const bool inside = __builtin_amdgcn_inverse_ballot_w64(inside_m);
+      // per lane: this region runs under the lane mask of the passed rays, and a wave-uniform count added in here lands in a
+      // vector register whose lane 0 - the one the epilogue reads - only sees the passes in which its own ray passed
+      n_outside += inside ? 0u : 1u;
       if constexpr (FIXED) {
         if (out.m_passed & ~inside_m) {   // wave-uniform: no ray of a wave is outside for images that cover the chip
           asm volatile("; rare: passed rays outside the image");
@@ -1814,6 +1817,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     sw = wave_sum(sum_w); sw2 = wave_sum(sum_w2); sxx = wave_sum(sum_x); syy = wave_sum(sum_y); srr = wave_sum(sum_r);
   }
   const long long swo = FIXED ? wave_sum_i64(sum_wo) : 0ll;
+  const long long n_out = wave_sum_i64((long long)n_outside);   // (a per-lane count, see the accumulation)
   if (lane == 0) {
     Sum* r = red[wave];
     for (int k = 0; k < SART_ACC_COUNT; ++k) r[k] = 0;
@@ -1827,7 +1831,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     r[SART_ACC_N_HIT_NICKEL] = (Sum)n_nickel;
     r[SART_ACC_N_REACHED_TELESCOPE] = (Sum)n_reached;
     r[SART_ACC_N_SHELL_SELECTED] = (Sum)n_shell;
-    r[SART_ACC_N_OUTSIDE_IMAGE] = (Sum)n_outside;
+    r[SART_ACC_N_OUTSIDE_IMAGE] = (Sum)n_out;
     if constexpr (FIXED) r[SART_ACC_SUM_WEIGHTS_OUTSIDE] = swo;
 #ifdef SART_STAGE_TIMING
     r[12] = (Sum)cyc_a0; r[13] = (Sum)cyc_a1; r[14] = (Sum)cyc_b;

@@ -226,7 +226,7 @@ def test_scan_on_full_size_tables_matches_the_oracle_and_the_host_loop():
     with sa.RayTracer(full) as rt:
         a_out, flux, rel, err, n_pass = sa.performAngularScan(rt, 0.0, 0.5, 50, n_rays_per_angle=n, seed=seed, flags=flags, fused=True, errors=True)
         assert np.array_equal(a_out, an) and rel.max() == 1.0 and int(np.argmax(flux)) <= 2
-        assert np.all(err > 0) and np.all(err < 0.05 * flux)
+        assert np.all(err > 0) and np.all(err[:25] < 0.01 * flux[:25]) and np.all(err < 0.2 * flux)   # (few rays pass at 0.5 deg)
         for k in (7, 24, 49):
             rt.set_telescope_angles(turned_y_deg=float(an[k]))
             s = rt.trace_histogram(n, seed=seed, flags=flags)[1]

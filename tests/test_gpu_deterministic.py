@@ -326,7 +326,7 @@ def test_fixed64_says_when_the_quantum_does_not_resolve_the_weights():
         rt.set_accumulation_mode("fixed64")
         with pytest.raises(L.SartError) as e:
             rt.trace_histogram(2_000_000, seed=3)
-        assert e.value.code == -1 and "quanta" in str(e.value)
+        assert e.value.code == L.SART_ERR_ACCUMULATOR and "quanta" in str(e.value)   # (not an argument error: round 5)
         rt.set_accumulation_mode("fixed64", headroom_bits=16)
         img_x, s_x = rt.trace_histogram(2_000_000, seed=3)
     assert s_x["N_PASSED"] == s_f["N_PASSED"]
@@ -391,7 +391,7 @@ def test_fixed64_unresolved_weights_fail_on_the_device_path_too():
         rt.set_accumulation_mode("fixed64")
         with pytest.raises(L.SartError) as e:
             _device_fixed_run(rt, torch, 2_000_000, seed=3)
-        assert e.value.code == -1 and "quanta" in str(e.value)
+        assert e.value.code == L.SART_ERR_ACCUMULATOR and "quanta" in str(e.value)   # (not an argument error: round 5)
         rt.synchronize()                                         # reported once
         rt.set_accumulation_mode("fixed64", headroom_bits=16)
         host = _device_fixed_run(rt, torch, 2_000_000, seed=3)   # resolves with 47 fractional bits ...
@@ -414,7 +414,7 @@ def test_fixed64_reports_a_slot_that_wrapped():
         assert host[0] == pytest.approx(host[1 + L.ACC["SUM_WEIGHTS"]], rel=1e-12) and host[0] > 0
         with pytest.raises(L.SartError) as e:
             _device_fixed_run(rt, torch, n, seed=2, image_n=1, launches=5)
-        assert e.value.code == -1 and "wrapped" in str(e.value)
+        assert e.value.code == L.SART_ERR_ACCUMULATOR and "wrapped" in str(e.value)
         with pytest.raises(L.SartError) as e:                     # the blocking call reports it, too
             for k in range(5):
                 rt.trace_histogram(n, seed=2, ray_id_offset=k * n, image_n=1, accumulate=(k > 0))

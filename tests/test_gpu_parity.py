@@ -913,3 +913,28 @@ def test_constant_path_variant_equals_the_carried_path(tables, monkeypatch):
     assert ok.sum() > 10_000
     tm = rec["transmissionMagnet"][ok] / np.cos(rec["yawAngles"][ok])
     assert tm.max() / tm.min() < 1.0 + 1e-4          # (1 + slope^2) varies by < 3e-5; a wall entry would shorten the path by per cents
+
+
+@pytest.mark.parametrize("mode", ["f64", "fixed64"])
+def test_rays_outside_a_small_image_are_counted_like_the_oracles_records_say(mode):
+    """N_OUTSIDE_IMAGE for an image that covers a part of the focal spot only (prepareHeatmap drops such rays, :838-842): the
+    count of passed rays whose position lies outside, from the oracle's records of the same ray ids.  (Round 5: the count used
+    to be added as a wave-uniform number inside the region that runs under the passed lanes' mask, and was short by the passes
+    in which lane 0's own ray had not passed - invisible while every test's image covered the chip.)"""
+    from oracle.oracle import Oracle
+    full = make_setup("babyiaxo_xmm")
+    n, seed = 300_000, 12
+    x_range, y_range = (6.2, 7.4), (6.9, 7.9)
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode(mode)
+        img, s = rt.trace_image(n, 24, 20, x_range=x_range, y_range=y_range, seed=seed)
+        whole = rt.trace_histogram(n, seed=seed)[1]
+    rec = Oracle(full, "q").trace_records(n, seed=seed)
+    p = rec["passed"] == 1
+    x, y = rec["pointdataX"][p], rec["pointdataY"][p]
+    inside = (x >= x_range[0]) & (x < x_range[1]) & (y >= y_range[0]) & (y < y_range[1])
+    assert s["N_PASSED"] == whole["N_PASSED"] == p.sum()
+    assert 0.05 * p.sum() < (~inside).sum() < 0.95 * p.sum()
+    assert abs(s["N_OUTSIDE_IMAGE"] - (~inside).sum()) <= 2          # (a ray within 1e-10 mm of the image's edge)
+    assert img.sum() == pytest.approx(rec["weights"][p][inside].sum(), rel=1e-6)
+    assert whole["N_OUTSIDE_IMAGE"] == 0
