@@ -309,6 +309,11 @@ def main():
     barrier()
     t1 = time.perf_counter()
     rt.synchronize()                     # raises what the FIXED64 finalize found (unresolved weights, a wrapped slot)
+    # Only rank 0 finalizes, so only rank 0 can raise here - the other ranks walk into the all_reduce below and wait for it.  Under
+    # the self-launcher that ends well (it sees rank 0's exit code, names the rank and ends the others: distributed.py).  The knob
+    # rehearses exactly that on the gloo backend (tests/test_distributed_cpu.py, tests/test_gpu_parity.py); never honoured on RCCL.
+    if rank == 0 and os.environ.get("SART_BENCH_FAIL_RANK0_AFTER_REDUCE") and os.environ.get("SART_BENCH_BACKEND") == "gloo":
+        raise RuntimeError("SART_BENCH_FAIL_RANK0_AFTER_REDUCE: rank 0 fails behind the reduce (rehearsal)")
     # MAX over ranks of the whole timed region; of the reduce (its wait for the slowest rank included) rank 0's figure
     times = torch.tensor([t1 - t0, t_red - t0], dtype=torch.float64, device=dev)
     rays_all = torch.zeros(world, dtype=torch.float64, device=dev)

@@ -95,7 +95,8 @@ def free_port() -> int:
 
 START_TIMEOUT_S = 600         # from the launch to the rendezvous of every rank: interpreter + `import torch` on a fresh box (SART_START_TIMEOUT)
 RDZV_TIMEOUT_S = 120          # torch.distributed rendezvous + communicator bring-up of one rank (SART_RDZV_TIMEOUT overrides)
-LAUNCH_TIMEOUT_S = 1500       # wall-clock limit of a self-launched multi-rank run (SART_LAUNCH_TIMEOUT overrides)
+LAUNCH_TIMEOUT_S = 0          # wall-clock limit of a self-launched multi-rank run: none unless SART_LAUNCH_TIMEOUT asks for one
+TERM_GRACE_S = 10             # between SIGTERM and SIGKILL for ranks that are being ended (SART_TERM_GRACE)
 STAGES = ("started", "rendezvous", "up", "done")
 
 
@@ -151,9 +152,11 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list, need_devices: 
       that fails ends the others (exact PIDs).  Clocks guard a first contact with an 8-GPU node: every rank must reach the
       rendezvous within SART_START_TIMEOUT (default 600 s: the first `import torch` on a fresh box takes minutes), every rank
       must report its process group up (report_stage) within SART_RDZV_TIMEOUT + 60 s of the first rank reaching the
-      rendezvous, and the whole run must end within SART_LAUNCH_TIMEOUT (default 1500 s); past any of them the ranks are
-      ended and the exit code is 3, with one line per rank saying what it last reported - a hang becomes a diagnosable
-      failure instead of the driver's own limit.
+      rendezvous; past either the ranks are ended and the exit code is 3, with one line per rank saying what it last
+      reported - a hang becomes a diagnosable failure instead of the driver's own limit.  A limit on the whole run is opt-in
+      (SART_LAUNCH_TIMEOUT=<seconds>; unset or 0 = none: a long production run is not a hang).  Ending ranks means SIGTERM by
+      exact PID, then - for ranks still alive SART_TERM_GRACE (10 s) later, e.g. blocked in a driver call - SIGKILL, with their
+      numbers on stderr: the launcher itself always returns.
 
     Environment: SART_BENCH_BACKEND (nccl = RCCL by default, gloo for rehearsals), SART_BENCH_DEVICE (all ranks share that
     device: rehearsal of the multi-rank path on a one-GPU box).  need_devices=False (a gloo preflight: nothing will touch a
@@ -218,7 +221,9 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list, need_devices: 
     alive = list(procs)
     t_start = time.monotonic()
     t_rdzv = None       # when the first rank reached the rendezvous
+    t_term = None       # when the remaining ranks were told to end (SIGTERM)
     all_up = False
+    grace = float(os.environ.get("SART_TERM_GRACE", TERM_GRACE_S))
     try:
         while alive:
             for p in list(alive):
@@ -228,8 +233,19 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list, need_devices: 
                 alive.remove(p)
                 if code != 0 and rc == 0:
                     rc = code if code > 0 else 1
+                    others = [procs.index(q) for q in alive]
+                    print("launcher: rank %d exited with code %d%s" % (procs.index(p), code, "; ending rank(s) %s, which would wait for it in the "
+                          "next collective" % ", ".join(map(str, others)) if others else ""), file=sys.stderr)
                     for q in alive:          # a dead rank leaves the others waiting in a collective: end them
                         q.terminate()
+                    t_term = time.monotonic()
+            if alive and t_term is not None and time.monotonic() - t_term > grace:
+                # SIGTERM was not enough (a rank blocked in a driver call does not see it): SIGKILL, by exact PID, and say which
+                print("launcher: rank(s) %s still alive %.0f s after SIGTERM: killed" % (", ".join(str(procs.index(q)) for q in alive), grace),
+                      file=sys.stderr)
+                for q in alive:
+                    q.kill()
+                t_term = time.monotonic() + 1e9   # (once)
             elapsed = time.monotonic() - t_start
             if alive and rc == 0:
                 what = None
@@ -242,8 +258,8 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list, need_devices: 
                         what = "the process group did not come up within %.0f s of the first rank's rendezvous" % rdzv_limit
                     elif not all_up and elapsed > start_limit and any(s in ("nothing", "started") for s in stages):
                         what = "not every rank reached the rendezvous within %.0f s" % start_limit
-                if what is None and elapsed > wall_limit:
-                    what = "the run did not end within %.0f s" % wall_limit
+                if what is None and wall_limit > 0 and elapsed > wall_limit:
+                    what = "the run did not end within %.0f s (SART_LAUNCH_TIMEOUT)" % wall_limit
                 if what is not None:
                     stages = _rank_stages(status_dir, n_ranks)
                     print("launcher: %s; last report of every rank: %s" % (what, ", ".join("rank %d: %s" % (r, s) for r, s in enumerate(stages))),
@@ -254,6 +270,7 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list, need_devices: 
                     rc = 3
                     for q in alive:
                         q.terminate()
+                    t_term = time.monotonic()
             time.sleep(0.05)
     finally:
         for q in procs:                      # whatever ends the wait (an exception, a signal): no rank outlives the launcher

@@ -409,3 +409,72 @@ def test_two_rank_mass_scan_reduce_equals_single_process(tmp_path):
     np.testing.assert_allclose(per_mass["SUM_WEIGHTS_SQ"], ref_mass["SUM_WEIGHTS_SQ"], rtol=1e-12)
     assert int(np.argmax(per_mass["SUM_WEIGHTS"])) == 1
     assert sa.mass_scan_len(len(_SCAN_MASSES)) == one.size
+
+
+_FAIL_AFTER_REDUCE_SCRIPT = '''
+import os, sys, time
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+from solaraxionraytracing_amd import distributed as D
+rank, world, _ = D.init_process_group_from_env("gloo")
+acc = torch.ones(1000, dtype=torch.float64)
+D.reduce_accumulator(acc, dst=0)          # the path's one collective
+dist.barrier()                            # the barrier that closes bench.py's timed region
+if rank == 0:
+    if sys.argv[1] == "raise":
+        raise RuntimeError("rank 0 fails behind the reduce")       # (bench.py: a FIXED64 status surfacing in rt.synchronize())
+    os._exit(7)
+times = torch.zeros(2, dtype=torch.float64)
+if sys.argv[2] == "deaf":
+    import signal
+    signal.signal(signal.SIGTERM, signal.SIG_IGN)    # a rank that SIGTERM does not end (as if blocked in a driver call)
+    try:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+    except Exception:
+        pass
+    time.sleep(300)
+dist.all_reduce(times, op=dist.ReduceOp.MAX)   # the other ranks wait here for a rank that is gone
+'''
+
+
+@pytest.mark.parametrize("how,deaf", [("raise", "no"), ("exit", "no"), ("raise", "deaf")])
+def test_rank0_failing_behind_the_reduce_ends_the_launch_and_is_named(tmp_path, how, deaf):
+    """VERDICT r04 (5) + ADVICE r04: only rank 0 finalizes and can raise behind the reduce; the other ranks then wait in the next
+    collective.  The launcher must come back within seconds with rank 0's exit code, say which rank failed and that it ended the
+    others - and, when a rank does not die on SIGTERM, kill it after the grace period instead of waiting for ever."""
+    import subprocess
+    import time
+    script = tmp_path / "fail.py"
+    script.write_text(_FAIL_AFTER_REDUCE_SCRIPT % ROOT)
+    launcher = tmp_path / "launcher.py"
+    launcher.write_text("import sys\nsys.path.insert(0, %r)\nfrom solaraxionraytracing_amd import distributed as D\nD.visible_devices = lambda: 3\n"
+                        "raise SystemExit(D.launch_ranks_if_needed(3, %r, [%r, %r]))\n" % (ROOT, str(script), how, deaf))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(launcher)], env=_clean_env(SART_BENCH_BACKEND="gloo", SART_TERM_GRACE="3"), capture_output=True, text=True,
+                       timeout=400)
+    dt = time.time() - t0
+    assert r.returncode == (1 if how == "raise" else 7), (r.returncode, r.stderr[-1500:])
+    assert "launcher: rank 0 exited with code %d; ending rank(s) 1, 2" % r.returncode in r.stderr, r.stderr[-1500:]
+    if how == "raise":
+        assert any(l.startswith("[rank 0]") and "RuntimeError: rank 0 fails behind the reduce" in l for l in r.stderr.splitlines()), r.stderr[-1500:]
+    assert dt < 200      # seconds (the margin is a cold `import torch` in every rank); gloo's own collective timeout is 30 min
+    if deaf == "deaf":
+        assert "launcher: rank(s) 1, 2 still alive 3 s after SIGTERM: killed" in r.stderr, r.stderr[-1500:]
+
+
+def test_a_wall_limit_is_opt_in(tmp_path):
+    """ADVICE r04: the launcher used to end any self-launched run after 25 minutes.  Now only when SART_LAUNCH_TIMEOUT asks."""
+    import subprocess
+    script = tmp_path / "slow.py"
+    script.write_text("import time\ntime.sleep(4)\n")
+    launcher = tmp_path / "launcher.py"
+    launcher.write_text("import sys\nsys.path.insert(0, %r)\nfrom solaraxionraytracing_amd import distributed as D\nD.visible_devices = lambda: 2\n"
+                        "raise SystemExit(D.launch_ranks_if_needed(2, %r, []))\n" % (ROOT, str(script)))
+    r = subprocess.run([sys.executable, str(launcher)], env=_clean_env(SART_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([sys.executable, str(launcher)], env=_clean_env(SART_BENCH_BACKEND="gloo", SART_LAUNCH_TIMEOUT="1"), capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 3 and "SART_LAUNCH_TIMEOUT" in r.stderr, (r.returncode, r.stderr)
+    from solaraxionraytracing_amd import distributed as D
+    assert D.LAUNCH_TIMEOUT_S == 0

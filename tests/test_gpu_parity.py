@@ -938,3 +938,30 @@ def test_rays_outside_a_small_image_are_counted_like_the_oracles_records_say(mod
     assert abs(s["N_OUTSIDE_IMAGE"] - (~inside).sum()) <= 2          # (a ray within 1e-10 mm of the image's edge)
     assert img.sum() == pytest.approx(rec["weights"][p][inside].sum(), rel=1e-6)
     assert whole["N_OUTSIDE_IMAGE"] == 0
+
+
+def test_bench_rank0_failing_behind_the_reduce_ends_the_self_launched_run():
+    """only rank 0 finalizes and can raise behind the reduce (bench.py); the other rank walks into the next
+    all_reduce.  `bench.py --gpus 2` as its own launcher, two gloo ranks on this GPU, rank 0 made to fail there: the run ends
+    within seconds with a non-zero exit, no JSON line, and the launcher says which rank failed."""
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SART_BENCH_BACKEND="gloo", SART_BENCH_DEVICE="0", SART_BENCH_FAIL_RANK0_AFTER_REDUCE="1")
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rays-per-step", "2e7",
+                          "--profile-run"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 1, (out.returncode, out.stderr[-2000:])
+    assert time.time() - t0 < 300
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "launcher: rank 0 exited with code 1; ending rank(s) 1" in out.stderr, out.stderr[-2000:]
+    assert any(l.startswith("[rank 0]") and "SART_BENCH_FAIL_RANK0_AFTER_REDUCE" in l for l in out.stderr.splitlines())
+    # the knob is a rehearsal knob: without the gloo backend it does nothing (one rank, RCCL never involved)
+    env.pop("SART_BENCH_BACKEND")
+    env.pop("SART_BENCH_DEVICE")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--rays-per-step", "2e7", "--profile-run"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
