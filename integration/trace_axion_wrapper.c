@@ -16,6 +16,8 @@
  * 5. The two must agree: counters exactly, image and flux to rounding (the histogram adds in another order).
  * 6. The fused axion-mass scan (sart_trace_mass_scan): the same setup in the gas stage, every ray traced once and weighed for
  *    five axion masses - against the reference-shaped loop (set mAxion, :255, re-trace, sum the weights of the records).
+ * 7. The fused angular scan (sart_trace_angular_scan): back in the vacuum stage, every ray sampled and cut once and turned through
+ *    four telescope angles, against one traceAxionWrapper per angle (performAngularScan's shape, raytracer.nim:2791-2800).
  * Exit code 0 when everything agrees.
  */
 #include <math.h>
@@ -145,7 +147,36 @@ int main(int argc, char** argv) {
             scan[2 * SART_SCAN_ROW + SART_SCAN_SUM_WEIGHTS] > scan[4 * SART_SCAN_ROW + SART_SCAN_SUM_WEIGHTS];   /* the resonance */
   printf("{\"mass_scan\": {\"masses\": %d, \"flux_on_resonance\": %.17g, \"max_rel_diff_to_per_mass_records\": %.3g, \"agree\": %s}}\n",
          N_MASSES, scan[2 * SART_SCAN_ROW + SART_SCAN_SUM_WEIGHTS], scan_max_rel, scan_ok ? "true" : "false");
+  /* 7. vacuum stage again: one pass over the rays for all telescope angles (sart_trace_angular_scan) vs performAngularScan's
+   *    shape - set the angle, one traceAxionWrapper, sum the weights of the passed rays (raytracer.nim:2791-2800) */
+  enum { N_ANGLES = 4 };
+  const double angles[N_ANGLES] = {0.005, 0.01, 0.02, 0.04};   /* degrees; 0.04 deg walks the spot 5 mm across the 14 mm chip (f = 7.5 m) */
+  CHECK(sart_set_setup(ctx, &setup));
+  double ascan[(N_ANGLES + 1) * SART_ASCAN_ROW];
+  CHECK(sart_trace_angular_scan(ctx, &p, angles, N_ANGLES, ascan));
+  int ascan_ok = ascan[N_ANGLES * SART_ASCAN_ROW + SART_ASCAN_N_RAYS] == (double)n_rays;
+  double ascan_max_rel = 0.0;
+  for (int k = 0; k < N_ANGLES; ++k) {
+    CHECK(sart_set_telescope_angles(ctx, NAN, angles[k]));
+    CHECK(sart_host_trace_axion_wrapper(ctx, ax_buf, (int64_t)n_rays, p.seed, p.ray_id_offset, p.flags));
+    double f = 0.0;
+    uint64_t np = 0, nn = 0;
+    for (uint64_t i = 0; i < n_rays; ++i) {
+      if (ax_buf[i].passed) { f += ax_buf[i].weights; ++np; }
+      if (ax_buf[i].hitNickel) ++nn;
+    }
+    const double* row = ascan + k * SART_ASCAN_ROW;
+    const double rel = fabs(row[SART_ASCAN_SUM_WEIGHTS] - f) / f;
+    if (rel > ascan_max_rel) ascan_max_rel = rel;
+    const int row_ok = row[SART_ASCAN_N_PASSED] == (double)np && row[SART_ASCAN_N_HIT_NICKEL] == (double)nn && rel <= 1e-9 && np > 0;
+    if (!row_ok)
+      fprintf(stderr, "angle %g deg: scan passed %.0f nickel %.0f flux %.17g | records passed %llu nickel %llu flux %.17g\n", angles[k],
+              row[SART_ASCAN_N_PASSED], row[SART_ASCAN_N_HIT_NICKEL], row[SART_ASCAN_SUM_WEIGHTS], (unsigned long long)np, (unsigned long long)nn, f);
+    ascan_ok = ascan_ok && row_ok;
+  }
+  printf("{\"angular_scan\": {\"angles\": %d, \"flux_at_first_angle\": %.17g, \"max_rel_diff_to_per_angle_records\": %.3g, \"agree\": %s}}\n",
+         N_ANGLES, ascan[SART_ASCAN_SUM_WEIGHTS], ascan_max_rel, ascan_ok ? "true" : "false");
   free(ax_buf);
   CHECK(sart_destroy(ctx));
-  return (ok && scan_ok) ? 0 : 1;
+  return (ok && scan_ok && ascan_ok) ? 0 : 1;
 }

@@ -954,7 +954,8 @@ struct RayOut {
 // SCAN (fused mass scan): the gas-stage conversion probability is left out - out.weight is the mass-independent factor of the
 // weight, out.gas what gas_conversion_prob() needs of this ray, out.m_passed the rays on the chip for which that factor is not
 // zero; the caller applies the probability per mass.
-template <bool RECORDS, bool FAST, int GAS, bool ZEXT, bool SCAN = false>
+// NODRAW: the caller always hands the energy index in (fused angular scan: drawn once per ray in front of the angle loop).
+template <bool RECORDS, bool FAST, int GAS, bool ZEXT, bool SCAN = false, bool NODRAW = false>
 __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, const HotB& HB, const TraceArgs& A,
                                         const RayState& st, int e_idx_in, bool live, RayOut& out, sart_axion_t* rec) {
 #ifdef SART_STAGE_TIMING
@@ -964,7 +965,7 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
 #endif
   SART_B_STAMP(0, st.X0);
   // the energy draw runs beside the mirror arithmetic (its gathers are issued early, consumed late)
-  const bool draw_energy = __builtin_amdgcn_readfirstlane(e_idx_in) < 0;   // wave-uniform: false for the X-ray test source
+  const bool draw_energy = NODRAW ? false : __builtin_amdgcn_readfirstlane(e_idx_in) < 0;   // wave-uniform: false for the X-ray test source
   EnergyDraw ed = {};
 #ifdef SART_DEBUG_KNOBS
   // working-set experiments (wrong results by design): 0x04000000 guide rows folded onto 16, 0x02000000 CDF rows folded onto 16,
@@ -1857,7 +1858,9 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
 // into the telescope's frame (:1878-1899) and nowhere before it: sampling, the three sincos, the radius draw, bore, cold-bore
 // exit and pipe cuts (phase_a_bore: ~215 of phase A's ~365 vector instructions in the rotated variant, and all of stage A0) do
 // not depend on it.  This kernel therefore takes every ray through stage A0 and the first half of phase A ONCE and keeps the
-// full wave of rays that come out of it in registers (the "stash": 13 values per lane - x1, y1, x3, y3, path, u5, radius index);
+// full wave of rays that come out of it in registers (the "stash": 11 values per lane - x1, y1, x3, y3, path, energy index: the
+// energy draw (:444-471: radius index and u5 -> lowerBound in the CDF row) does not depend on the angle either, so its two
+// table gathers with the worst locality - guide word, CDF candidates - are paid once per ray, not once per ray and angle);
 // a wave-uniform walk over the launch's angles runs the second half of phase A (phase_a_telescope with that angle's rotation,
 // read from the kernel arguments with scalar loads) on the stash, compacts the survivors into ring 1 with their angle index, and
 // phase B runs on full waves of ring 1 as in the histogram kernel - a pass usually holds rays of two or three angles, so what
@@ -1956,8 +1959,8 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
   };
 
   // the stash: the wave of rays whose angles are being worked through (registers)
-  double st_x1 = 0.0, st_y1 = 0.0, st_x3 = 0.0, st_y3 = 0.0, st_path = 0.0, st_u5 = 0.0;
-  int st_ridx = 0;
+  double st_x1 = 0.0, st_y1 = 0.0, st_x3 = 0.0, st_y3 = 0.0, st_path = 0.0;
+  int st_eidx = 0;        // energy index of the ray (row n_energies: the X-ray test source's fixed energy)
   uint64_t stash_m = 0;   // its lanes that hold a ray of this launch that reached the telescope
   int ka = n_angles;      // next angle of the stash; n_angles: no stash
 
@@ -1974,7 +1977,16 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
     stash_m = ballot64(valid) & M.reached;
     n_reached += (uint32_t)__popcll(stash_m);
     st_x1 = br.x1; st_y1 = br.y1; st_x3 = br.x3; st_y3 = br.y3;
-    st_path = st.path_cb; st_u5 = st.u5; st_ridx = st.r_idx;
+    st_path = st.path_cb;
+    if (!FAST && Hl.test_active) {   // wave-uniform
+      st_eidx = Pb.n_energies;
+    } else {
+      // getRandomEnergyFromSolarModel (:444-471) once per ray: the three dependent gathers of the draw, here and not in phase B
+      // (lanes whose ray is dead draw from a valid row with a valid uniform: the result is not used)
+      HotB HB;
+      reload_kernarg(HB, offsetof(AScanKernArgs, HB));
+      st_eidx = sample_energy_index(HB, st.r_idx, st.u5);
+    }
     ka = stash_m ? 0 : n_angles;   // (a wave none of whose rays reached the telescope has no angles to walk)
   };
 
@@ -1992,7 +2004,7 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
     br.ok = __builtin_amdgcn_inverse_ballot_w64(stash_m);
     br.okm = stash_m;
     RayState st;
-    st.path_cb = st_path; st.u5 = st_u5; st.r_idx = st_ridx;
+    st.path_cb = st_path;
     double radial;
     LaneMasks M;
     (void)phase_a_telescope<FAST, 1>(Hl, Pb, ang.R, L, br, st, radial, M);
@@ -2006,8 +2018,7 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
       Q.w[wave].X0[slot] = st.X0; Q.w[wave].Y0[slot] = st.Y0;
       Q.w[wave].tsx[slot] = st.tsx; Q.w[wave].tsy[slot] = st.tsy;
       Q.w[wave].path[slot] = st.path_cb;
-      Q.w[wave].u5[slot] = st.u5;
-      Q.w[wave].idx[slot] = st.r_idx | (st.shell << 16) | (k << 24);
+      Q.w[wave].idx[slot] = st_eidx | (st.shell << 16) | (k << 24);   // energy index < 2^16 (the guide tables are u16), shell < 64, angle < 16
     }
     t1 += (uint32_t)__popcll(mask);
   };
@@ -2021,9 +2032,10 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
     st.X0 = Q.w[wave].X0[slot]; st.Y0 = Q.w[wave].Y0[slot];
     st.tsx = Q.w[wave].tsx[slot]; st.tsy = Q.w[wave].tsy[slot];
     st.path_cb = Q.w[wave].path[slot];
-    st.u5 = Q.w[wave].u5[slot];
+    st.u5 = 0.0;
+    st.r_idx = 0;
     const int packed = Q.w[wave].idx[slot];   // (slots beyond n_valid hold earlier rays or zeros: a real ray's indices, angle < n_angles)
-    st.r_idx = packed & 0xFFFF;
+    const int e_idx = packed & 0xFFFF;
     st.shell = (packed >> 16) & 0xFF;
     const uint32_t kl = (uint32_t)packed >> 24;
     {
@@ -2037,7 +2049,7 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
     reload_kernarg(HB, offsetof(AScanKernArgs, HB));
     asm volatile("" :: "s"(HB.cdf_hi32), "s"(HB.energy_guide), "s"(HB.energy_tab), "s"(HB.refl), "s"(HB.refl_n_angles), "s"(HB.cdf_stride));
     RayOut out;
-    phase_b<false, FAST, GAS, false>(Bo.P, L, HB, lds_opaque(Ab), st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
+    phase_b<false, FAST, GAS, false, false, true>(Bo.P, L, HB, lds_opaque(Ab), st, e_idx, valid, out, nullptr);   // (no draw in there)
     SART_STAGE_MARK("ACC");
     if (__builtin_amdgcn_inverse_ballot_w64(out.m_nickel)) atomicAdd(&cnt[4 * kl + 1], 1u);
     if (__builtin_amdgcn_inverse_ballot_w64(out.m_till)) atomicAdd(&cnt[4 * kl + 2], 1u);

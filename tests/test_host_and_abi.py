@@ -196,11 +196,13 @@ def test_c_host_records_agree_with_histogram(tmp_path):
     r = subprocess.run([_build_c_host(tmp_path), "200000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    out, scan = lines[0], lines[1]["mass_scan"]
-    assert out["agree"] is True and out["passed"] > 10000 and out["build"] == L.build_id() and out["abi"] == 2
+    out, scan, ascan = lines[0], lines[1]["mass_scan"], lines[2]["angular_scan"]
+    assert out["agree"] is True and out["passed"] > 10000 and out["build"] == L.build_id() and out["abi"] == 3
     assert abs(out["flux_records"] - out["flux_histogram"]) <= 1e-11 * out["flux_histogram"]
     # step 6 of the program: the fused mass scan (gas stage) against one traceAxionWrapper per mass, from plain C
     assert scan["agree"] is True and scan["masses"] == 5 and scan["max_rel_diff_to_per_mass_records"] <= 1e-9
+    # step 7: the fused angular scan against one traceAxionWrapper per telescope angle
+    assert ascan["agree"] is True and ascan["angles"] == 4 and ascan["max_rel_diff_to_per_angle_records"] <= 1e-9
 
 
 def test_product_does_not_link_or_import_the_oracle():
