@@ -436,6 +436,25 @@ int sart_get_fixed_quanta(sart_context* ctx, sart_fixed_quanta_t* out);
 int sart_finalize_accumulator_device(sart_context* ctx, const sart_trace_params_t* params, const void* acc_fixed_device,
                                      double* out_f64_device);
 
+/*
+ * Roll-over for long accumulations.  An int64 slot ends where 2^headroom_bits bound-weight rays have met on one pixel or bin
+ * (default 27: BabyIAXO's brightest pixel passes 2^62 after 1.1e12 rays).  Instead of hand-picking a larger headroom - and a
+ * coarser quantum - a caller can give every slot a second limb: `hi_limbs_device` is DEVICE memory of the accumulator's length
+ * (int64, zeroed by the caller when the accumulator is); this call moves the bits of every slot of acc_fixed_device above 2^40
+ * into the slot's limb (slot i then stands for (hi[i] 2^40 + acc[i]) quanta, 0 <= acc[i] < 2^40) - one pass over the slots,
+ * ~5 us for a 256 x 256 image.  Called between launches - after every one, or every few hundred 1e9-ray launches - an
+ * accumulation runs as long as anybody likes at the fine quantum; a slot that wrapped between two calls is still caught (this
+ * call checks sign and size of every slot it folds; the finalize's conservation sums include the limbs).  Both arrays reduce
+ * over ranks as int64 sums.  Asynchronous on the context's stream; problems surface as SART_ERR_ACCUMULATOR from the next
+ * sart_synchronize.
+ */
+int sart_rollover_accumulator_device(sart_context* ctx, const sart_trace_params_t* params, void* acc_fixed_device,
+                                     void* hi_limbs_device);
+/* sart_finalize_accumulator_device for an accumulator with roll-over limbs (hi_limbs_device may be NULL: no limbs).
+ * out_f64_device may equal acc_fixed_device, not hi_limbs_device. */
+int sart_finalize_accumulator_limbs_device(sart_context* ctx, const sart_trace_params_t* params, const void* acc_fixed_device,
+                                           const void* hi_limbs_device, double* out_f64_device);
+
 /* ---- fused axion-mass scan (BASELINE configs[4]) -------------------------- */
 /*
  * The reference has ONE constant axion mass (`mAxion`, raytracer.nim:255); a mass scan on it is a host loop that re-runs

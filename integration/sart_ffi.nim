@@ -124,6 +124,11 @@ proc sart_get_accumulation_mode*(ctx: ptr SartContext, modeOut: ptr cint): cint 
 proc sart_get_fixed_quanta*(ctx: ptr SartContext, quanta: ptr SartFixedQuanta): cint {.importc, header: sartH.}
 proc sart_finalize_accumulator_device*(ctx: ptr SartContext, p: ptr SartTraceParams, accFixedDevice: pointer,
                                        outF64Device: ptr cdouble): cint {.importc, header: sartH.}
+## long FIXED64 accumulations: a second limb per slot (value = (hi 2^40 + lo) quantum), folded between launches
+proc sart_rollover_accumulator_device*(ctx: ptr SartContext, p: ptr SartTraceParams, accFixedDevice: pointer,
+                                       hiLimbsDevice: pointer): cint {.importc, header: sartH.}
+proc sart_finalize_accumulator_limbs_device*(ctx: ptr SartContext, p: ptr SartTraceParams, accFixedDevice: pointer,
+                                             hiLimbsDevice: pointer, outF64Device: ptr cdouble): cint {.importc, header: sartH.}
 ## fused axion-mass scan (gas stage): every ray traced once, weighed for nMasses masses; (nMasses + 1) rows of SartScanRow slots
 proc sart_trace_mass_scan_device*(ctx: ptr SartContext, p: ptr SartTraceParams, massesEv: ptr cdouble, nMasses: int32,
                                   scanAccDevice: ptr cdouble): cint {.importc, header: sartH.}

@@ -202,6 +202,8 @@ SART_SYMBOLS = {
     "sart_get_accumulation_mode": (C.c_int, [C.c_void_p, _P(C.c_int)]),
     "sart_get_fixed_quanta": (C.c_int, [C.c_void_p, _P(FixedQuanta)]),
     "sart_finalize_accumulator_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p, C.c_void_p]),
+    "sart_rollover_accumulator_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p, C.c_void_p]),
+    "sart_finalize_accumulator_limbs_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     "sart_trace_mass_scan_device": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _i, C.c_void_p]),
     "sart_trace_mass_scan": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _i, _dp]),
     "sart_finalize_mass_scan_device": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _i, C.c_void_p, C.c_void_p]),

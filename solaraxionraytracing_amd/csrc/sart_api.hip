@@ -27,8 +27,9 @@
 namespace sart {
 void launch_trace_histogram(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, double* acc, int n_blocks,
                             hipStream_t stream, int variant, bool fixed);
-void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectra, int n_radial_bins, int n_energies1, double q_w,
+void launch_finalize_fixed(const void* in, const void* hi, double* out, size_t n_img, int spectra, int n_radial_bins, int n_energies1, double q_w,
                            double q_w2, double q_pos, double q_refl, void* check_dev, hipStream_t stream);
+void launch_rollover_fixed(void* acc, void* hi, size_t n, void* check_dev, hipStream_t stream);
 size_t fixed_check_bytes();
 bool launch_trace_mass_scan(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, const ScanArgs& SC, double* rows,
                             double* shared_row, int n_blocks, hipStream_t stream, int variant, bool fixed);
@@ -1587,13 +1588,32 @@ int sart_get_fixed_quanta(sart_context* c, sart_fixed_quanta_t* out) {
 }
 
 int sart_finalize_accumulator_device(sart_context* c, const sart_trace_params_t* p, const void* acc_fixed_dev, double* out_dev) {
+  return sart_finalize_accumulator_limbs_device(c, p, acc_fixed_dev, nullptr, out_dev);
+}
+
+int sart_rollover_accumulator_device(sart_context* c, const sart_trace_params_t* p, void* acc_fixed_dev, void* hi_limbs_dev) {
+  if (!c || !p || !acc_fixed_dev || !hi_limbs_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (((p->image_nx < 1 || p->image_ny < 1) && !(p->image_nx == 0 && p->image_ny == 0)) || (p->spectra && p->n_radial_bins < 1))
+    return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
+  if (acc_fixed_dev == hi_limbs_dev) return fail(SART_ERR_INVALID_ARGUMENT, "the limbs need an array of their own");
+  SART_HIP(hipSetDevice(c->device));
+  if (int rc = status_ensure(c)) return rc;
+  launch_rollover_fixed(acc_fixed_dev, hi_limbs_dev, acc_len_of(c, p), c->d_status.p, c->stream);
+  SART_HIP(hipGetLastError());
+  return status_enqueue_copy(c);
+}
+
+int sart_finalize_accumulator_limbs_device(sart_context* c, const sart_trace_params_t* p, const void* acc_fixed_dev, const void* hi_limbs_dev,
+                                           double* out_dev) {
   if (!c || !p || !acc_fixed_dev || !out_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  if (hi_limbs_dev && (hi_limbs_dev == acc_fixed_dev || hi_limbs_dev == static_cast<const void*>(out_dev)))
+    return fail(SART_ERR_INVALID_ARGUMENT, "the limbs need an array of their own");
   if (((p->image_nx < 1 || p->image_ny < 1) && !(p->image_nx == 0 && p->image_ny == 0)) || (p->spectra && p->n_radial_bins < 1))
     return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
   if (!c->quanta_frozen) return fail(SART_ERR_NOT_READY, "no FIXED64 launch has fixed the quanta yet");
   SART_HIP(hipSetDevice(c->device));
   if (int rc = status_ensure(c)) return rc;
-  launch_finalize_fixed(acc_fixed_dev, out_dev, static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny), p->spectra ? 1 : 0,
+  launch_finalize_fixed(acc_fixed_dev, hi_limbs_dev, out_dev, static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny), p->spectra ? 1 : 0,
                         p->spectra ? p->n_radial_bins : 0, c->n_energies + 1, std::ldexp(1.0, c->weight_exp),
                         std::ldexp(1.0, c->weight_sq_exp), 1.0 / kFixedPositionScale, 1.0 / kFixedReflectScale, c->d_status.p, c->stream);
   SART_HIP(hipGetLastError());

@@ -2380,10 +2380,11 @@ struct FixedCheck {
   long long want_lo, want_hi;                               // SUM_WEIGHTS
   long long spectra;
 };
-__device__ __forceinline__ void fixed_check_add(long long v, bool mine, long long* lo_dst, long long* hi_dst) {
+__device__ __forceinline__ void fixed_check_add(long long v, long long v_hi, bool mine, long long* lo_dst, long long* hi_dst) {
   constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
   if (!__builtin_amdgcn_ballot_w64(mine)) return;   // wave-uniform
-  long long lo = wave_sum_i64(mine ? (v & kMask) : 0ll), hi = wave_sum_i64(mine ? (v >> kFixedLimbBits) : 0ll);
+  // (v_hi: the slot's limb in the roll-over array, in units of 2^40 - sart_rollover_accumulator_device; 0 without one)
+  long long lo = wave_sum_i64(mine ? (v & kMask) : 0ll), hi = wave_sum_i64(mine ? ((v >> kFixedLimbBits) + v_hi) : 0ll);
   if ((threadIdx.x & 63) == 0) {
     hi += lo >> kFixedLimbBits;
     lo &= kMask;
@@ -2421,37 +2422,53 @@ struct FinalizeArgs {
   int32_t spectra, n_radial_bins, n_energies1, _pad;
   double q_w, q_w2, q_pos, q_refl;
 };
-__global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in, double* out, FinalizeArgs F, FixedCheck* C) {
+// `hi` (or nullptr): the roll-over limbs of sart_rollover_accumulator_device - slot i then stands for hi[i] 2^40 + in[i].
+__global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in, const long long* hi, double* out, FinalizeArgs F, FixedCheck* C) {
   uint32_t* const status = &C->status;
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long n_scalar0 = F.n_img, n_spec0 = F.n_img + SART_ACC_COUNT;
   const long long total = n_spec0 + (F.spectra ? 2ll * F.n_radial_bins + 3ll * F.n_energies1 : 0ll);
+  const double two40 = (double)(1ll << kFixedLimbBits);
   {
     // conservation sums (whole waves take part: the block size divides into waves, the last block is padded with idle threads)
     const long long v = i < total ? in[i] : 0ll;
+    const long long h = (hi && i < total) ? hi[i] : 0ll;
     const long long j = i - n_spec0, nr = F.n_radial_bins, ne = F.n_energies1;
-    fixed_check_add(v, i < n_scalar0, &C->pix_lo, &C->pix_hi);
+    fixed_check_add(v, h, i < n_scalar0, &C->pix_lo, &C->pix_hi);
     if (F.spectra) {
-      fixed_check_add(v, j >= nr && j < 2 * nr, &C->rad_lo, &C->rad_hi);
-      fixed_check_add(v, j >= 2 * nr + ne && j < 2 * nr + 2 * ne, &C->en_lo, &C->en_hi);
+      fixed_check_add(v, h, j >= nr && j < 2 * nr, &C->rad_lo, &C->rad_hi);
+      fixed_check_add(v, h, j >= 2 * nr + ne && j < 2 * nr + 2 * ne, &C->en_lo, &C->en_hi);
     }
   }
   if (i < n_scalar0) {
     const long long v = in[i];
     fixed_status_check_slot(v, status);
-    out[i] = (double)v * F.q_w;                            // power-of-two quantum: the product is exact
+    // power-of-two quantum: the product is exact; with a roll-over limb the sum of the two exact doubles rounds once
+    out[i] = (hi ? fma((double)hi[i], two40, (double)v) : (double)v) * F.q_w;
   } else if (i == n_scalar0) {
     long long v[SART_ACC_COUNT];
-    for (int k = 0; k < SART_ACC_COUNT; ++k) { v[k] = in[n_scalar0 + k]; fixed_status_check_slot(v[k], status); }
+    double vd[SART_ACC_COUNT];     // the slot's value with its roll-over limb
+    for (int k = 0; k < SART_ACC_COUNT; ++k) {
+      v[k] = in[n_scalar0 + k];
+      fixed_status_check_slot(v[k], status);
+      const long long h = hi ? hi[n_scalar0 + k] : 0ll;
+      if (h < 0) atomicOr(status, kFixedStatusWrapped);
+      vd[k] = hi ? fma((double)h, two40, (double)v[k]) : (double)v[k];
+    }
     auto limbs = [&](int k, int kh) {                      // hi * 2^40 and lo are exact doubles: one rounding in the sum
-      return (double)v[kh] * (double)(1ll << kFixedLimbBits) + (double)v[k];
+      return vd[kh] * two40 + vd[k];
     };
     const bool sq_ok = fixed_status_check_means(limbs(SART_ACC_SUM_WEIGHTS, SART_ACC_SUM_WEIGHTS_HI),
-                                                limbs(SART_ACC_SUM_WEIGHTS_SQ, SART_ACC_SUM_WEIGHTS_SQ_HI), (double)v[SART_ACC_N_PASSED], status);
+                                                limbs(SART_ACC_SUM_WEIGHTS_SQ, SART_ACC_SUM_WEIGHTS_SQ_HI), vd[SART_ACC_N_PASSED], status);
+    // SUM_WEIGHTS in units of the quantum as (lo, hi 2^40): its two slots, each with its roll-over limb (the limb of the *_HI slot
+    // counts 2^80 quanta: only a sum beyond 2^102 quanta would not fit the int64 below)
+    auto hi_of = [&](int k, int kh) {
+      return v[kh] + (hi ? hi[n_scalar0 + k] + (hi[n_scalar0 + kh] << kFixedLimbBits) : 0ll);
+    };
     C->want_lo = v[SART_ACC_SUM_WEIGHTS];
-    C->want_hi = v[SART_ACC_SUM_WEIGHTS_HI];
+    C->want_hi = hi_of(SART_ACC_SUM_WEIGHTS, SART_ACC_SUM_WEIGHTS_HI);
     C->want_in_lo = v[SART_ACC_SUM_WEIGHTS] - v[SART_ACC_SUM_WEIGHTS_OUTSIDE];
-    C->want_in_hi = v[SART_ACC_SUM_WEIGHTS_HI] - v[SART_ACC_SUM_WEIGHTS_OUTSIDE_HI];
+    C->want_in_hi = C->want_hi - hi_of(SART_ACC_SUM_WEIGHTS_OUTSIDE, SART_ACC_SUM_WEIGHTS_OUTSIDE_HI);
     C->spectra = F.spectra;
     for (int k = 0; k < SART_ACC_COUNT; ++k) {
       double r;
@@ -2462,7 +2479,7 @@ __global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in
         case SART_ACC_SUM_R: r = limbs(k, SART_ACC_SUM_R_HI) * F.q_pos; break;
         case SART_ACC_SUM_WEIGHTS_SQ: r = sq_ok ? limbs(k, SART_ACC_SUM_WEIGHTS_SQ_HI) * F.q_w2 : __builtin_nan(""); break;
         case SART_ACC_SUM_WEIGHTS_OUTSIDE: r = 0.0; break;   // (a raw-accumulator slot: the f64 layout has none)
-        default: r = fixed_is_hi_slot(k) ? 0.0 : (double)v[k]; break;   // counters (the reserved slots hold 0)
+        default: r = fixed_is_hi_slot(k) ? 0.0 : vd[k]; break;   // counters (the reserved slots hold 0)
       }
       out[n_scalar0 + k] = r;
     }
@@ -2473,9 +2490,23 @@ __global__ __launch_bounds__(256) void finalize_fixed_kernel(const long long* in
       const double q = j < nr ? 1.0 : j < 2 * nr ? F.q_w : j < 2 * nr + ne ? 1.0 : j < 2 * nr + 2 * ne ? F.q_w : F.q_refl;
       const long long v = in[i];
       fixed_status_check_slot(v, status);
-      out[i] = (double)v * q;
+      out[i] = (hi ? fma((double)hi[i], two40, (double)v) : (double)v) * q;
     }
   }
+}
+
+// sart_rollover_accumulator_device: the bits of every slot above 2^40 move into the slot's limb in `hi` (units of 2^40); the slot
+// keeps [0, 2^40).  A slot that is negative or >= 2^62 has wrapped (or is about to): reported like the finalize kernel does.
+__global__ __launch_bounds__(256) void rollover_fixed_kernel(long long* acc, long long* hi, long long n, FixedCheck* C) {
+  constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const long long v = acc[i];
+  fixed_status_check_slot(v, &C->status);
+  const long long h = hi[i] + (v >> kFixedLimbBits);
+  if (h < 0) atomicOr(&C->status, kFixedStatusWrapped);
+  hi[i] = h;
+  acc[i] = v & kMask;
 }
 
 // Raw FIXED64 scan accumulator -> doubles: rows [0, n) of `in` / `out` (a group of up to kScanMaxMasses masses, whose quanta
@@ -2736,14 +2767,18 @@ void launch_trace_angular_scan(const HotA& H, const HotB& HB, const DevBlob* blo
 }
 
 size_t fixed_check_bytes() { return sizeof(FixedCheck); }
-void launch_finalize_fixed(const void* in, double* out, size_t n_img, int spectra, int n_radial_bins, int n_energies1, double q_w,
+void launch_rollover_fixed(void* acc, void* hi, size_t n, void* check_dev, hipStream_t stream) {
+  hipLaunchKernelGGL(rollover_fixed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, static_cast<long long*>(acc),
+                     static_cast<long long*>(hi), (long long)n, static_cast<FixedCheck*>(check_dev));
+}
+void launch_finalize_fixed(const void* in, const void* hi, double* out, size_t n_img, int spectra, int n_radial_bins, int n_energies1, double q_w,
                            double q_w2, double q_pos, double q_refl, void* check_dev, hipStream_t stream) {
   FinalizeArgs F{(long long)n_img, spectra, n_radial_bins, n_energies1, 0, q_w, q_w2, q_pos, q_refl};
   const size_t total = n_img + SART_ACC_COUNT + (spectra ? 2 * (size_t)n_radial_bins + 3 * (size_t)n_energies1 : 0);
   FixedCheck* const C = static_cast<FixedCheck*>(check_dev);
   (void)hipMemsetAsync(reinterpret_cast<char*>(C) + 8, 0, sizeof(FixedCheck) - 8, stream);   // everything but the status word
   hipLaunchKernelGGL(finalize_fixed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                     reinterpret_cast<const long long*>(in), out, F, C);
+                     reinterpret_cast<const long long*>(in), reinterpret_cast<const long long*>(hi), out, F, C);
   hipLaunchKernelGGL(fixed_check_kernel, dim3(1), dim3(1), 0, stream, C);
 }
 // rows [0, n_masses) of in / out with the quanta q_w[k], q_w2[k]; shared_row >= 0: that row (relative to `in`) holds the counters

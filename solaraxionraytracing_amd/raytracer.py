@@ -250,6 +250,17 @@ class RayTracer:
         _lib.check(self.lib.sart_finalize_accumulator_device(self.handle, C.byref(params), C.c_void_p(acc_fixed_ptr),
                                                              C.c_void_p(out_f64_ptr if out_f64_ptr is not None else acc_fixed_ptr)))
 
+    def rollover_accumulator_device(self, params: TraceParams, acc_fixed_ptr: int, hi_limbs_ptr: int):
+        """Long FIXED64 accumulations: moves the bits of every slot above 2^40 into the slot's limb in ``hi_limbs`` (device int64
+        array of the accumulator's length, zeroed with it).  Asynchronous."""
+        _lib.check(self.lib.sart_rollover_accumulator_device(self.handle, C.byref(params), C.c_void_p(acc_fixed_ptr), C.c_void_p(hi_limbs_ptr)))
+
+    def finalize_accumulator_limbs_device(self, params: TraceParams, acc_fixed_ptr: int, hi_limbs_ptr: int | None, out_f64_ptr: int | None = None):
+        """finalize_accumulator_device for an accumulator with roll-over limbs."""
+        _lib.check(self.lib.sart_finalize_accumulator_limbs_device(self.handle, C.byref(params), C.c_void_p(acc_fixed_ptr),
+                                                                   C.c_void_p(hi_limbs_ptr) if hi_limbs_ptr else None,
+                                                                   C.c_void_p(out_f64_ptr if out_f64_ptr is not None else acc_fixed_ptr)))
+
     def set_solar_tables_device(self, em_rates_device_ptr: int, radii: np.ndarray, energies: np.ndarray):
         """sart_set_solar_tables_device: CDFs + guide tables built on the device from a device-resident emission table
         [n_radii][n_energies] (``torch_tensor.data_ptr()``)."""

@@ -454,3 +454,63 @@ def test_fixed64_sum_of_squared_weights_has_a_high_limb(name):
     x = run(name, "fixed64")
     assert x[1]["SUM_WEIGHTS_SQ"] == pytest.approx(f[1]["SUM_WEIGHTS_SQ"], rel=1e-9)
     assert x[3]["weight_sq"] == x[3]["weight"] ** 2 * 2.0 ** (2 * (63 - 27) - 39)     # 2^(2e - 39) beside 2^(e - 63 + 27)
+
+
+def test_fixed64_rollover_limbs_carry_an_accumulation_past_the_headroom():
+    """the only remedy for an accumulation that outlives its headroom used to be "pick 31 bits yourself".  With
+    sart_rollover_accumulator_device every slot has a second limb; folded between launches, the accumulation runs on at the fine
+    quantum.  Scaled down as test_fixed64_reports_a_slot_that_wrapped does it: at headroom_bits = 16 a pixel holds 2^16
+    bound-weight rays - what 2^27 hold in 3e12 BabyIAXO rays the brightest pixel of this image meets in ~1.5e9.
+      * without the roll-over the run ends in SART_ERR_ACCUMULATOR (wrapped);
+      * with it: no error, and every slot's (hi 2^40 + lo) is EXACTLY the sum of the integers of the fifteen launches traced one
+        by one into fresh accumulators - bit for bit;
+      * finalized, it equals the same rays accumulated with 40 bits of headroom (a 2^24 times coarser quantum) to 1e-9."""
+    import torch
+    full = full_setup("babyiaxo_xmm")
+    n, launches, seed = 100_000_000, 15, 6
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode("fixed64", headroom_bits=16)
+        with pytest.raises(L.SartError) as e:
+            _device_fixed_run(rt, torch, n, seed=seed, launches=launches)
+        assert e.value.code == L.SART_ERR_ACCUMULATOR and "wrapped" in str(e.value)
+        rt.synchronize()
+        # the same launches, a fold behind every one
+        acc = torch.zeros(sa.accumulator_len(256), dtype=torch.int64, device="cuda")
+        hi = torch.zeros_like(acc)
+        exact = np.zeros(acc.numel(), dtype=object)
+        one = torch.zeros_like(acc)
+        for k in range(launches):
+            p = rt.trace_params(n, seed=seed, ray_id_offset=k * n, accumulate=True)
+            rt.trace_histogram_device(p, acc.data_ptr())
+            rt.rollover_accumulator_device(p, acc.data_ptr(), hi.data_ptr())
+            q = rt.trace_params(n, seed=seed, ray_id_offset=k * n, accumulate=(k > 0))   # (k = 0 zeroes `one` and keeps the quanta)
+            one.zero_()
+            q.accumulate = 1
+            rt.trace_histogram_device(q, one.data_ptr())
+            rt.synchronize()
+            exact += one.cpu().numpy().astype(object)
+        lo_h, hi_h = acc.cpu().numpy(), hi.cpu().numpy()
+        assert lo_h.min() >= 0 and lo_h.max() < 2 ** 40 and hi_h.min() >= 0 and hi_h[:256 * 256].max() > 2 ** 22   # (> 2^62 in one limb)
+        got = hi_h.astype(object) * 2 ** 40 + lo_h.astype(object)
+        # the five two-limb sums of the accumulator keep their own high slot: compare slot pairs as one number
+        k0 = 256 * 256
+        pairs = dict(L.ACC_HI)
+        for name, kh in list(pairs.items()) + [("SUM_WEIGHTS_OUTSIDE", 18)]:
+            kl = 17 if name == "SUM_WEIGHTS_OUTSIDE" else L.ACC[name]
+            a = got[k0 + kh] * 2 ** 40 + got[k0 + kl]
+            b = exact[k0 + kh] * 2 ** 40 + exact[k0 + kl]
+            assert a == b, name
+            got[k0 + kh] = got[k0 + kl] = exact[k0 + kh] = exact[k0 + kl] = 0
+        assert (got == exact).all()
+        out = torch.zeros(acc.numel(), dtype=torch.float64, device="cuda")
+        rt.finalize_accumulator_limbs_device(p, acc.data_ptr(), hi.data_ptr(), out.data_ptr())
+        rt.synchronize()                                   # no error: nothing wrapped, the conservation sums include the limbs
+        fine = out.cpu().numpy()
+        rt.set_accumulation_mode("fixed64", headroom_bits=40)
+        coarse = _device_fixed_run(rt, torch, n, seed=seed, launches=launches)
+    assert fine[k0 + L.ACC["N_RAYS"]] == coarse[k0 + L.ACC["N_RAYS"]] == n * launches
+    for name in ("SUM_WEIGHTS", "SUM_X", "SUM_Y", "SUM_R", "N_PASSED", "SUM_WEIGHTS_SQ"):
+        assert fine[k0 + L.ACC[name]] == pytest.approx(coarse[k0 + L.ACC[name]], rel=1e-9), name
+    lit = coarse[:k0] > 1e-3 * coarse[:k0].max()
+    assert np.abs(fine[:k0][lit] / coarse[:k0][lit] - 1.0).max() < 1e-6      # (the coarse run's own rounding: 2^-23 of the bound per ray)
+    assert fine[:k0].sum() == pytest.approx(fine[k0 + L.ACC["SUM_WEIGHTS"]], rel=1e-12)

@@ -89,8 +89,10 @@ def build_asm() -> str:
     return os.path.join(out_dir, "sart_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")
 
 
-def kernel_lines(asm_path: str, variant: int, fixed: bool, scan: bool = False):
+def kernel_lines(asm_path: str, variant: int, fixed: bool, scan: bool = False, ascan: str | None = None):
     tag = "_ZN4sart22trace_histogram_kernelILi1024E" + VARIANTS[variant] + ("Lb1E" if fixed else "Lb0E") + ("Lb1E" if scan else "Lb0E")
+    if ascan:   # the fused angular scan: trace_angular_scan_kernel<1024, FAST, GAS, FIXED> (fast: <true, 0>, generic: <false, -1>)
+        tag = "_ZN4sart25trace_angular_scan_kernelILi1024E" + ("Lb1ELi0E" if ascan == "fast" else "Lb0ELin1E") + ("Lb1E" if fixed else "Lb0E")
     lines = open(asm_path).read().splitlines()
     start = next(i for i, l in enumerate(lines) if l.startswith(tag) and l.rstrip().split(":")[0].startswith(tag) and ":" in l)
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
@@ -181,6 +183,7 @@ def main():
     ap.add_argument("--variant", type=int, default=5, help="0 vacuum, 1 generic, 2 generic rotated, 3 gas, 4 rotated, 5 vacuum + constant path (headline)")
     ap.add_argument("--fixed", action="store_true", help="the SART_ACCUM_FIXED64 instantiation")
     ap.add_argument("--scan", action="store_true", help="the fused mass-scan instantiation (variants 1, 2, 3, 6)")
+    ap.add_argument("--ascan", default=None, choices=["fast", "generic"], help="the fused angular-scan kernel instead (stages A0, A1a, A1b, B, ACC)")
     ap.add_argument("--asm", default=None, help="existing listing (default: compile now)")
     ap.add_argument("--pmc", default=None, help="profiles/<tag>_<workload>_pmc_summary.json of the same build: measured totals beside the model")
     ap.add_argument("--passes-b", type=float, default=None, help="phase-B passes per 64 launched rays (default: from --pmc results or 0.3295)")
@@ -188,7 +191,7 @@ def main():
     ap.add_argument("--dump", default=None, help="comma-separated classes: print the hot-path instructions of these classes (e.g. mov,select,cvt,lane)")
     args = ap.parse_args()
     asm = args.asm or build_asm()
-    h = histogram(kernel_lines(asm, args.variant, args.fixed, args.scan))
+    h = histogram(kernel_lines(asm, args.variant, args.fixed, args.scan, args.ascan))
     report = {"variant": args.variant, "fixed64": args.fixed, "stages": {}, "how": "tools/isa_histogram.py: static counts of the hot path "
               "(blocks without a `; rare` marker) per stage of the gfx950 listing; rare = the divergent alternatives"}
     print("%-9s %5s | " % ("stage", "VALU") + " ".join("%6s" % c for c in VALU_CLASSES) + " | salu  lds vmem atom wait | rare VALU")
