@@ -267,6 +267,10 @@ def main():
     # 8-byte slots: doubles, or int64 in fixed64 mode.  Image accumulator - or, for the scans, (points + 1) rows of 8 slots
     acc_len = sa.mass_scan_len(SCAN_MASSES) if scan_masses is not None else sa.angular_scan_len(SCAN_ANGLES) if scan_angles is not None else sa.accumulator_len(256)
     acc = torch.zeros(acc_len, dtype=torch.float64, device=dev)
+    # fixed64, image workloads: a second limb per slot (sart_rollover_accumulator_device), folded every 64 steps - a run of any
+    # length at the default headroom (2500 steps = 2.5e12 rays used to need --headroom 31)
+    roll = fixed64 and scan_masses is None and scan_angles is None
+    hi_limbs = torch.zeros(acc_len, dtype=torch.int64, device=dev) if roll else None
     seed = 299792458
 
     def step(k: int):
@@ -279,6 +283,8 @@ def main():
             rt.trace_angular_scan_device(p, scan_angles, acc.data_ptr())   # one pass over the rays, every angle
         else:
             rt.trace_histogram_device(p, acc.data_ptr())
+            if roll and (k + 1) % 64 == 0:
+                rt.rollover_accumulator_device(p, acc.data_ptr(), hi_limbs.data_ptr())
 
     def barrier():
         if world > 1:
@@ -291,6 +297,8 @@ def main():
         D.reduce_accumulator(acc.clone(), dst=0, fixed64=fixed64)
     barrier()
     acc.zero_()
+    if roll:
+        hi_limbs.zero_()
     rt.enable_kernel_timing(True)
     barrier()
     t0 = time.perf_counter()
@@ -298,9 +306,14 @@ def main():
         step(k)
     stream.synchronize()                 # this rank's launches are done (the reduce would wait for them anyway)
     t_red = time.perf_counter()
+    if roll:                             # fold once more: every slot < 2^40 on every rank, then both limb arrays reduce as int64 sums
+        rt.rollover_accumulator_device(rt.trace_params(1), acc.data_ptr(), hi_limbs.data_ptr())
+        D.reduce_accumulator(hi_limbs, dst=0, fixed64=True)
     D.reduce_accumulator(acc, dst=0, fixed64=fixed64)     # the single RCCL reduce of the output histograms
     if fixed64 and rank == 0:            # raw integer accumulator -> doubles, in place (part of the timed region)
-        if scan_masses is not None:
+        if roll:
+            rt.finalize_accumulator_limbs_device(rt.trace_params(1), acc.data_ptr(), hi_limbs.data_ptr())
+        elif scan_masses is not None:
             rt.finalize_mass_scan_device(rt.trace_params(1, flags=flags), scan_masses, acc.data_ptr())
         elif scan_angles is not None:
             rt.finalize_angular_scan_device(rt.trace_params(1, flags=flags), SCAN_ANGLES, acc.data_ptr())

@@ -215,6 +215,70 @@ def write_reflectivity_h5(path: str, grid: ReflectivityGrid):
                                                     _lib.as_dp(np.ascontiguousarray(grid.data))), host=True)
 
 
+def henke_directory_to_grid(directory: str, pattern: str = "*degGold0.25microns.csv") -> ReflectivityGrid:
+    """tools/convert_reflectivities_to_h5.nim:9-32: the gold reflectivity scans downloaded from henke.lbl.gov by
+    tools/download_henke_files.nim - one file per grazing angle, named `<angle>degGold0.25microns.csv` (:14, :155-161), two `#`
+    header lines (column names `PhotonEnergy(eV) Reflectivity ...`, then Henke's description), one blank-separated row per
+    energy - collected (walkFiles), sorted by the angle in the file name (sortedByIt) and stacked into [angle][energy].
+    The energy axis is what the reference writes whatever the files say: linspace(0.03, 15.0, rows) keV (:23) - checked here
+    against the files' own first column (eV), a mismatch raises."""
+    import glob
+    import re
+    files = []
+    for f in glob.glob(os.path.join(directory, pattern)):
+        m = re.match(r"([-+]?[0-9]*\.?[0-9]+(?:[eE][-+]?[0-9]+)?)deg", os.path.basename(f))   # scanTuple(..., "$fdeg")
+        if not m:
+            raise IOError("Could not parse input gold file: " + f)
+        files.append((float(m.group(1)), f))
+    if len(files) < 2:
+        raise IOError("%s: fewer than two files match %s" % (directory, pattern))
+    files.sort(key=lambda t: t[0])
+    rows = []
+    energy_ev = None
+    for angle, f in files:
+        with open(f) as fh:
+            names = fh.readline().lstrip("#").split()
+        if "Reflectivity" not in names:
+            raise KeyError("%s: no column Reflectivity in %s" % (f, names))
+        data = np.loadtxt(f, comments="#", ndmin=2)
+        if rows and data.shape[0] != rows[0].size:
+            raise ValueError("%s: %d rows, the first file has %d" % (f, data.shape[0], rows[0].size))
+        rows.append(np.ascontiguousarray(data[:, names.index("Reflectivity")]))
+        if energy_ev is None:
+            energy_ev = data[:, 0]
+    n_e = rows[0].size
+    energies = np.linspace(0.03, 15.0, n_e)
+    if not np.allclose(energy_ev / 1000.0, energies, rtol=1e-4, atol=1e-6):
+        raise ValueError("%s: the energy column is not linspace(30, 15000, %d) eV - the reference's converter assumes that axis" % (directory, n_e))
+    angles = np.array([a for a, _ in files])
+    if not np.allclose(angles, np.linspace(angles[0], angles[-1], angles.size), rtol=0, atol=2e-6):   # (file names carry six decimals)
+        raise ValueError("%s: the angles of the files are not equidistant - the raytracer reads (min, max) of /Angles only" % directory)
+    return ReflectivityGrid(np.ascontiguousarray(np.stack(rows)[None]), float(angles[0]), float(angles[-1]), 0.03, 15.0)
+
+
+def convert_henke_directory_to_h5(directory: str, out_path: str, pattern: str = "*degGold0.25microns.csv") -> ReflectivityGrid:
+    """The whole of tools/convert_reflectivities_to_h5.nim but its plot: `henke_download/` -> `gold_0.25microns_reflectivities.h5`
+    in the schema initReflectivity reads (:34-48: /Energy (nE, 1), /Angles (nA, 1), /Reflectivity declared (nE, nA), laid out
+    [angle][energy])."""
+    grid = henke_directory_to_grid(directory, pattern)
+    write_reflectivity_h5(out_path, grid)
+    return grid
+
+
+def write_henke_directory(directory: str, grid: ReflectivityGrid, thickness_microns: float = 0.25):
+    """The inverse, for tests and fixtures: one `<angle>degGold<t>microns.csv` per angle of coating 0 in the format
+    tools/download_henke_files.nim stores (:139-161)."""
+    os.makedirs(directory, exist_ok=True)
+    _, n_a, n_e = grid.data.shape
+    angles = np.linspace(grid.angle_min, grid.angle_max, n_a)
+    energies_ev = np.linspace(grid.energy_min, grid.energy_max, n_e) * 1000.0
+    for i, a in enumerate(angles):
+        with open(os.path.join(directory, "%.6fdegGold%.2fmicrons.csv" % (a, thickness_microns)), "w") as f:
+            f.write("#PhotonEnergy(eV) Reflectivity Transmission\n# Au %g.nm on SiO2 at %.4fdeg, P=0.\n" % (thickness_microns * 1000.0, a))
+            for e, r in zip(energies_ev, grid.data[0, i]):
+                f.write("%s %s 0.0\n" % (repr(float(e)), repr(float(r))))
+
+
 def analytic_reflectivity_grid(n_coatings: int = 1, n_angles: int = 1000, n_energies: int = 1000) -> ReflectivityGrid:
     """G2 (stress): R = exp(-alpha / 0.5 deg) * exp(-E / 10 keV)."""
     angles = np.linspace(0.0, 1.5, n_angles)[:, None]

@@ -178,3 +178,41 @@ def test_incomplete_opcd_directory_degrades_with_a_note_instead_of_failing(tmp_p
     with pytest.raises(RuntimeError) as e:
         Oracle(full)
     assert "fetch_solar_tables" in str(e.value)
+
+
+@pytest.mark.skipif(not _h5_available(), reason="libhdf5 not loadable")
+def test_henke_directory_converts_to_the_gold_h5_file_the_config_names(tmp_path):
+    """tools/convert_reflectivities_to_h5.nim:9-48: `henke_download/<angle>degGold0.25microns.csv`, one file per
+    grazing angle, sorted by the angle in the name -> `gold_0.25microns_reflectivities.h5`.  Files synthesised from the Henke
+    data the package ships (data/gold_henke.npz, resampled as tables.gold_reflectivity_grid does) in the downloader's naming and
+    layout round-trip to that grid, through the CLI tool, and config.py then finds the result through `goldReflFile`."""
+    import sys
+    g = tables.gold_reflectivity_grid(n_angles=40, n_energies=120)
+    cfgdir = tmp_path / "config"
+    res = cfgdir / "res"
+    henke = res / "henke_download"
+    res.mkdir(parents=True)
+    tables.write_henke_directory(str(henke), g)
+    names = sorted(os.listdir(henke))
+    assert len(names) == 40 and names[0] == "0.000000degGold0.25microns.csv" and names[-1] == "1.500000degGold0.25microns.csv"
+    (henke / "notes.txt").write_text("not a scan")                      # walkFiles' pattern skips what is not a scan
+    out = res / "gold_0.25microns_reflectivities.h5"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "convert_reflectivities_to_h5.py"), "--indir", str(henke), "--out", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    back = tables.read_reflectivity_h5(str(out))
+    assert back.data.shape == (1, 40, 120) and np.array_equal(back.data, g.data)
+    assert (back.angle_min, back.angle_max, back.energy_min, back.energy_max) == (0.0, 1.5, 0.03, 15.0)
+    # the grid does not depend on the order the directory lists its files in, only on the angles in their names
+    assert np.array_equal(tables.henke_directory_to_grid(str(henke)).data, g.data)
+    # config.py: a BabyIAXO / XMM setup reads its reflectivity from that file (goldReflFile, raytracer.nim:1193-1194)
+    toml = SAMPLE.replace('experimentSetup = "CAST"', 'experimentSetup = "BabyIAXO"').replace('telescopeSetup  = "LLNL"', 'telescopeSetup  = "XMM"')
+    toml = toml.replace('detectorSetup   = "InGrid2018"', 'detectorSetup   = "InGridIAXO"').replace("useConfig = true", "useConfig = false")
+    (cfgdir / "config.toml").write_text(toml)
+    full = config.init_full_setup_from_config(str(cfgdir / "config.toml"))
+    assert np.array_equal(full.reflectivity.data, g.data) and not [n for n in full.meta["notes"] if "goldReflFile" in n]
+    # what the reference's converter would choke on, it says
+    (henke / "abcdegGold0.25microns.csv").write_text("#PhotonEnergy(eV) Reflectivity\n# x\n1 1\n")
+    with pytest.raises(IOError):
+        tables.henke_directory_to_grid(str(henke))
