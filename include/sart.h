@@ -350,7 +350,10 @@ int sart_trace_records_device(sart_context* ctx, const sart_trace_params_t* para
  * `accumulator_device` is DEVICE memory of sart_accumulator_len(nx,ny) doubles; the call is
  * asynchronous on the context's stream (pair with sart_synchronize) - except for the first launch after the geometry,
  * the tables or the image binning changed: it is preceded by a 2e5-ray pilot launch whose centroid places the LDS image
- * tile, read back with one stream synchronisation (~60 us).
+ * tile, read back with one stream synchronisation (~60 us).  That holds for every kernel variant (rotated
+ * telescope and gas stage included): a host loop that changes the telescope's angle between image launches pays it per angle.
+ * Launches without an image do not: flux-only launches (image_nx = image_ny = 0) and the fused scans (sart_trace_mass_scan,
+ * sart_trace_angular_scan) place no tile and never synchronise.
  */
 int sart_trace_histogram_device(sart_context* ctx, const sart_trace_params_t* params,
                                 double* accumulator_device);

@@ -91,7 +91,10 @@ int sart_host_angular_scan(sart_context* ctx, const double* angles_deg, int32_t 
 int sart_host_axion_mass_scan(sart_context* ctx, const double* masses_ev, int32_t n_masses, uint64_t n_rays, uint64_t seed,
                               uint64_t ray_id_offset, uint32_t flags, double* fluxes_out, double* flux_sq_out,
                               double* n_passed_out);
-/* The same with the argument list of rounds 1-3 (n_rays_per_mass = the rays every mass is evaluated on). */
+/* The scan of rounds 1-3 under its old name, with its old meaning: a host loop in performAngularScan's shape - mass i on its OWN
+ * block of fresh rays, ids [ray_id_offset + i n_rays_per_mass, ...) - through flux-only launches.  (Round 4 had routed this name
+ * through the fused kernel: same signature, correlated scan points, other numbers for the same seed.  The fused scan is
+ * sart_host_axion_mass_scan above and nowhere else.)  The context's own axion mass is put back afterwards. */
 int sart_host_perform_axion_mass_scan(sart_context* ctx, const double* masses_ev, int32_t n_masses,
                                       uint64_t n_rays_per_mass, uint64_t seed, uint64_t ray_id_offset,
                                       uint32_t flags, double* fluxes_out);

@@ -519,7 +519,34 @@ int sart_host_axion_mass_scan(sart_context* ctx, const double* masses_ev, int32_
 
 int sart_host_perform_axion_mass_scan(sart_context* ctx, const double* masses_ev, int32_t n_masses, uint64_t n_rays_per_mass,
                                       uint64_t seed, uint64_t ray_id_offset, uint32_t flags, double* fluxes_out) {
-  return sart_host_axion_mass_scan(ctx, masses_ev, n_masses, n_rays_per_mass, seed, ray_id_offset, flags, fluxes_out, nullptr, nullptr);
+  // The meaning of rounds 1-3, back under the name of rounds 1-3 (round 4 had silently routed it through the fused scan): a host
+  // loop in performAngularScan's shape - per mass set m_a, trace n_rays_per_mass FRESH rays (mass i on the ray ids
+  // [offset + i n, offset + (i + 1) n)), sum the weights of the passed rays.  Flux-only launches; the context's own mass is put
+  // back on every way out.
+  if (!ctx || !masses_ev || n_masses < 1 || !fluxes_out)
+    return fail(SART_ERR_INVALID_ARGUMENT, "sart_host_perform_axion_mass_scan: bad argument");
+  sart_setup_t setup;
+  if (int rc = sart_get_setup(ctx, &setup)) { g_err = sart_last_error(); return rc; }
+  sart_trace_params_t p;
+  std::memset(&p, 0, sizeof p);
+  p.n_rays = n_rays_per_mass;
+  p.seed = seed;
+  p.flags = flags;
+  p.image_nx = 0; p.image_ny = 0;   // the scan reads the sum of the weights alone
+  int rc_scan = 0;
+  for (int32_t i = 0; i < n_masses && rc_scan == 0; ++i) {
+    rc_scan = sart_set_axion_mass(ctx, masses_ev[i]);
+    if (rc_scan) { g_err = sart_last_error(); break; }
+    p.ray_id_offset = ray_id_offset + static_cast<uint64_t>(i) * n_rays_per_mass;
+    sart_summary_t sum;
+    rc_scan = sart_trace_histogram(ctx, &p, nullptr, &sum);
+    if (rc_scan) { g_err = sart_last_error(); break; }
+    fluxes_out[i] = sum.v[SART_ACC_SUM_WEIGHTS];
+  }
+  if (int rc = sart_set_axion_mass(ctx, setup.m_axion)) {
+    if (!rc_scan) { g_err = sart_last_error(); rc_scan = rc; }
+  }
+  return rc_scan;
 }
 
 int sart_host_h5_reflectivity_info(const char* path, int32_t* n_coatings, int32_t* n_angles, int32_t* n_energies,

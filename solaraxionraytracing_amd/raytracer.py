@@ -528,9 +528,15 @@ def performAxionMassScanHostLoop(tracer: RayTracer, masses_ev, n_rays_per_mass: 
                                  flags: int | None = None, ray_id_offset: int = 0, same_rays: bool = True):
     """The reference-shaped scan (a host loop: set the mass, re-trace, sum) - what the fused kernel replaces; kept as the
     comparison of the parity tests and of bench.py.  ``same_rays``: every mass on the same ray ids (what the fused scan
-    computes), else mass i on its own block of ids."""
+    computes), else mass i on its own block of ids = the C++ host driver sart_host_perform_axion_mass_scan."""
     masses = np.ascontiguousarray(masses_ev, dtype=np.float64)
     out = np.empty_like(masses)
+    if not same_rays:
+        host = _lib.load_host()
+        fl = tracer.full.flags if flags is None else flags
+        _lib.check(host.sart_host_perform_axion_mass_scan(tracer.handle, _lib.as_dp(masses), masses.size, n_rays_per_mass, seed,
+                                                          ray_id_offset, fl, _lib.as_dp(out)), host=True)
+        return out
     m0 = tracer.full.setup.m_axion
     try:
         for i, m in enumerate(masses):

@@ -9,6 +9,8 @@ every ray once and evaluates that probability for K masses.  Demanded here, per 
   * the flux equals the CPU oracle (80-bit build) with that mass to 1e-6, on small and on full-size AGSS09 tables."""
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -268,3 +270,26 @@ def test_scan_cli_writes_the_curve(tmp_path):
     assert rows[0][:3] == ["m_a [eV]", "flux", "relative flux"] and len(rows) == 10
     rel = np.array([float(x[2]) for x in rows[1:]])
     assert rel.max() == 1.0 and int(np.argmax(rel)) in (4, 5)     # 0.008 / 0.009 eV bracket m_gamma = 0.008235 eV
+
+
+def test_host_loop_driver_keeps_its_own_ray_block_per_mass():
+    """sart_host_perform_axion_mass_scan had kept its name and signature while changing meaning (fused: every mass on
+    the same rays).  It is the host loop of rounds 1-3 again - mass i on the ray ids [offset + i n, offset + (i + 1) n), flux-only
+    launches, the context's mass back afterwards; the fused scan lives under sart_host_axion_mass_scan alone."""
+    full = make_setup("babyiaxo_xmm_gas")
+    ms = masses(4)
+    n, seed, off = 400_000, 9, 5000
+    with sa.RayTracer(full) as rt:
+        loop = sa.performAxionMassScanHostLoop(rt, ms, n, seed=seed, ray_id_offset=off, same_rays=False)
+        for i, m in enumerate(ms):
+            rt.set_axion_mass(float(m))
+            want = rt.trace_histogram(n, seed=seed, ray_id_offset=off + i * n)[1]["SUM_WEIGHTS"]
+            assert loop[i] == pytest.approx(want, rel=1e-12), i
+        rt.set_axion_mass(full.setup.m_axion)
+        fused = sa.performAxionMassScan(rt, ms, n, seed=seed, ray_id_offset=off)
+        s = L.Setup()
+        L.check(rt.lib.sart_get_setup(rt.handle, C.byref(s)))
+        assert s.m_axion == full.setup.m_axion
+    assert fused[0] == pytest.approx(loop[0], rel=1e-12)          # mass 0 sits on the same block in both
+    assert abs(fused[1] / loop[1] - 1.0) > 1e-9                    # the others are other rays: close, not equal
+    assert abs(fused[1] / loop[1] - 1.0) < 0.05
