@@ -1219,6 +1219,23 @@ __device__ __forceinline__ void phase_b(const DevParams& P, const LdsTables& L, 
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
+// Wave priorities by pipeline stage (s_setprio: the SIMD's arbiter picks the ready wave with the highest priority): the four
+// persistent waves of a SIMD are in different stages at any moment, and the later the stage the sooner its instructions should
+// go - a wave in phase B has three dependent table gathers to get into flight (everything it issues ahead of them is latency
+// the others could have hidden), a wave in phase A feeds it, the accumulation behind phase B (atomics nobody waits for) and
+// stage A0 are filler that runs whenever nobody else can.  Priced in profiles/r05_exp_setprio.txt (same-box A/B of eleven
+// assignments, bitwise the same results): B 3 > A1 2 > accumulation 1 > A0 / loop glue 0 is worth 9 % on BabyIAXO / XMM, 9 % on
+// the gas stage and the rotated telescope, 8 % on CAST / LLNL against every wave at priority 0 (oldest first); what matters
+// most is stage A0 below everything else (A1 = B = 1: 6 %), then B above A1 (+3 %).
+#ifndef SART_PRIO_A1
+#define SART_PRIO_A1 2
+#endif
+#ifndef SART_PRIO_B
+#define SART_PRIO_B 3
+#endif
+#ifndef SART_PRIO_ACC
+#define SART_PRIO_ACC 1
+#endif
 constexpr int kQueue = 128;   // ring capacity per wave: < 64 left over + <= 64 new survivors
 
 struct __align__(16) TablesLds {
@@ -1446,6 +1463,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
   // stage A1 for the ray with id id_base + rel (valid lanes only count); u3_hi = its word of the shared stream
   auto run_phase_a = [&](uint32_t rel, bool valid, uint32_t u3_hi) {
     SART_STAGE_MARK("A1");
+    __builtin_amdgcn_s_setprio(SART_PRIO_A1);
     RayState st;
     bool sampled = false, reached = false;
     double radial;
@@ -1480,10 +1498,12 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       Q.w[wave].idx[slot] = st.r_idx | (st.shell << 16);
     }
     t1 += cnt;
+    __builtin_amdgcn_s_setprio(0);
   };
 
   auto run_phase_b = [&](uint32_t n_valid) {
     SART_STAGE_MARK("B");
+    __builtin_amdgcn_s_setprio(SART_PRIO_B);
     RayState st;
     const bool valid = (uint32_t)lane < n_valid;
     const uint32_t slot = (h1 + (uint32_t)lane) % kQueue;
@@ -1513,6 +1533,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
       phase_b<false, FAST, GAS, FAST && !ROT && GAS >= 0, SCAN>(Bo.P, L, HB, lds_opaque(Ab), st, (!FAST && H.test_active) ? Pb.n_energies : -1, valid, out, nullptr);
       if constexpr (SCAN) {
         SART_STAGE_MARK("SCAN");
+        // (the per-mass loop stays at phase B's priority: 23.8 against 24.2 ms per 32-mass scan with it below phase A)
         // out.m_passed: rays on the chip whose mass-independent weight factor out.weight is not zero.  Per mass: weight =
         // out.weight x conversion probability (the single-mass kernels multiply in the same order), accumulated per lane.
         n_passed += (uint32_t)__popcll(out.m_passed);
@@ -1553,8 +1574,10 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
     h1 += n_valid;
     if constexpr (SCAN) {
       n_nickel += (uint32_t)__popcll(out.m_nickel);
+      __builtin_amdgcn_s_setprio(0);
       return;
     }
+    __builtin_amdgcn_s_setprio(SART_PRIO_ACC);
 #ifdef SART_STAGE_TIMING
     for (int k = 0; k < 5; ++k) cyc_bs[k] += out.tb[k + 1] - out.tb[k];
     cyc_bs[5] += out.tb[0];     // entry stamps, to place the sub-stages inside the B span
@@ -1656,6 +1679,7 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // Zone bounds of stage A0.  The specialised variants have vector registers to spare (<= 120 of 128) and keep the eight bounds
@@ -1967,6 +1991,7 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
   // stage A1a: sample -> bore -> pipes for the ray with id id_base + rel
   auto run_bore = [&](uint32_t rel, bool valid, uint32_t u3_hi) {
     SART_STAGE_MARK("A1a");
+    __builtin_amdgcn_s_setprio(SART_PRIO_A1);
     RayState st;
     bool sampled = false, reached = false;
     HotA Hl;
@@ -1988,11 +2013,13 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
       st_eidx = sample_energy_index(HB, st.r_idx, st.u5);
     }
     ka = stash_m ? 0 : n_angles;   // (a wave none of whose rays reached the telescope has no angles to walk)
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // stage A1b: the stash through telescope frame, opaque structures and shell selection for angle k (wave-uniform)
   auto run_telescope = [&](int k) {
     SART_STAGE_MARK("A1b");
+    __builtin_amdgcn_s_setprio(SART_PRIO_A1);
     HotA Hl;
     reload_hot(Hl);
     struct { TelRot R; double shell0_miss_radius; } ang;   // the head of AScanAngle
@@ -2021,11 +2048,13 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
       Q.w[wave].idx[slot] = st_eidx | (st.shell << 16) | (k << 24);   // energy index < 2^16 (the guide tables are u16), shell < 64, angle < 16
     }
     t1 += (uint32_t)__popcll(mask);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // stage B: mirrors -> weight on a wave of ring 1 (rays of several angles), accumulated per angle
   auto run_mirrors = [&](uint32_t n_valid) {
     SART_STAGE_MARK("B");
+    __builtin_amdgcn_s_setprio(SART_PRIO_B);
     RayState st;
     const bool valid = (uint32_t)lane < n_valid;
     const uint32_t slot = (h1 + (uint32_t)lane) % kQueue;
@@ -2051,6 +2080,7 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
     RayOut out;
     phase_b<false, FAST, GAS, false, false, true>(Bo.P, L, HB, lds_opaque(Ab), st, e_idx, valid, out, nullptr);   // (no draw in there)
     SART_STAGE_MARK("ACC");
+    __builtin_amdgcn_s_setprio(SART_PRIO_ACC);
     if (__builtin_amdgcn_inverse_ballot_w64(out.m_nickel)) atomicAdd(&cnt[4 * kl + 1], 1u);
     if (__builtin_amdgcn_inverse_ballot_w64(out.m_till)) atomicAdd(&cnt[4 * kl + 2], 1u);
     if (out.passed) {
@@ -2069,6 +2099,7 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
         __hip_atomic_fetch_add(cell + kScanLanes, out.weight * out.weight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // zone bounds of stage A0 (see trace_histogram_kernel)
