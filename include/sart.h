@@ -519,7 +519,7 @@ int sart_finalize_mass_scan_device(sart_context* ctx, const sart_trace_params_t*
  *                      value = (hi 2^40 + lo) quantum)
  *   row n_angles       angle-independent counters SART_ASCAN_N_RAYS, SART_ASCAN_N_REACHED_TELESCOPE
  * Only params->n_rays, seed, ray_id_offset, flags and accumulate are read (no image is accumulated).
- * Angles are processed in groups of up to 16 per kernel launch (balanced: 50 angles = 13 + 13 + 12 + 12); every group traces
+ * Angles are processed in groups of up to 32 per kernel launch (balanced: 50 angles = 25 + 25); every group traces
  * the rays again.  FIXED64: the quanta are a function of (setup, tables, flags, headroom) alone, the same for every angle and
  * every rank of a multi-GPU job; a reduce is an int64 sum of the raw scan accumulators; sart_finalize_angular_scan_device
  * converts to doubles.

@@ -47,7 +47,7 @@ ASCAN_ROW = 8
 ASCAN = dict(SUM_WEIGHTS=0, SUM_WEIGHTS_SQ=1, N_PASSED=2, N_SHELL_SELECTED=3, N_HIT_NICKEL=6, N_PASSED_TILL_WINDOW=7)
 ASCAN_HI = dict(SUM_WEIGHTS=4, SUM_WEIGHTS_SQ=5)
 ASCAN_SHARED = dict(N_RAYS=0, N_REACHED_TELESCOPE=1)
-ASCAN_MAX_ANGLES = 16   # csrc/sart_device.h: kAScanMaxAngles (angles per kernel launch)
+ASCAN_MAX_ANGLES = 32   # csrc/sart_device.h: kAScanMaxAngles (angles per kernel launch)
 FIXED_LIMB_BITS = 40
 
 ACC = dict(SUM_WEIGHTS=0, N_PASSED=1, N_PASSED_TILL_WINDOW=2, N_HIT_NICKEL=3, SUM_X=4, SUM_Y=5, SUM_R=6,

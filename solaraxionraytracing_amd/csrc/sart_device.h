@@ -266,9 +266,9 @@ constexpr int kScanPartialSlots = 4;
 // telescope's frame (raytracer.nim:1878-1899) and nowhere before it, so trace_angular_scan_kernel samples a ray and takes it through
 // bore and pipes ONCE and runs telescope frame -> opaque structures -> shell selection -> mirrors -> weight once per angle of this
 // table.  One launch takes up to kAScanMaxAngles angles: per angle a workgroup keeps [sum of w, sum of w^2][kScanLanes] f64 / int64
-// cells (the scan accumulates no image: the cells live where the histogram kernels keep the image tile behind the tables) and four
-// counters in LDS.
-constexpr int kAScanMaxAngles = 16;
+// cells - in the u5 column of ring 1, which this kernel does not use (the energy draw happens in front of the angle loop: the ring
+// carries the energy index) - and four counters in LDS.
+constexpr int kAScanMaxAngles = 32;
 struct AScanAngle {
   // rotateInY(rotateInX(., turnedX), turnedY) about (0, 0, lT/2) as hoist_setup() evaluates it for this angle (TelRot)
   double rx_c, rx_s, ry_c, ry_s, half_length_telescope;

@@ -1889,7 +1889,8 @@ __global__ __launch_bounds__(BLOCK) void trace_histogram_kernel(HotA H, const De
 // read from the kernel arguments with scalar loads) on the stash, compacts the survivors into ring 1 with their angle index, and
 // phase B runs on full waves of ring 1 as in the histogram kernel - a pass usually holds rays of two or three angles, so what
 // phase B needs of the angle (the third column of the rotation, for z of pointExitCB) comes from a small LDS table per lane and
-// the sums go to per-angle LDS cells (ds_add_f64 / ds_add_u64) and counters (ds_add_u32).  No image, no position sums.
+// the sums go to per-angle LDS cells (ds_add_f64 / ds_add_u64; ring 1's u5 column, free here) and counters (ds_add_u32).  No image,
+// no position sums.
 // One loop iteration runs at most one pass of each stage (one call site each: the instruction footprint of the histogram kernel):
 //   no stash (ka == n_angles):  A0 pass -> ring 0;  ring 0 holds a full wave (or the input is exhausted) -> A1a -> stash, ka = 0
 //   stash (ka < n_angles):      A1b for angle ka -> ring 1, ++ka
@@ -1909,9 +1910,10 @@ struct AScanKernArgs {
 static_assert(offsetof(AScanKernArgs, A) == offsetof(HistKernArgs, A) && offsetof(AScanKernArgs, HB) == offsetof(HistKernArgs, HB) &&
                   offsetof(AScanKernArgs, AN) == offsetof(HistKernArgs, SC) && sizeof(AScanAngle) % 8 == 0,
               "the angular-scan kernel re-reads its arguments at the offsets of the histogram kernel's");
-constexpr int kAScanCells = kAScanMaxAngles * 2 * kScanLanes;          // [angle][sum w, sum w^2][kScanLanes]
-constexpr int kAScanMTable = kAScanCells;                              // [angle][mx, my, mz] behind the cells
-static_assert(kAScanCells + 3 * kAScanMaxAngles <= kTileExtraCells, "cells + rotation columns live where the histogram kernels keep the image tile behind the tables");
+constexpr int kAScanCells = kAScanMaxAngles * 2 * kScanLanes;          // [angle][sum w, sum w^2][kScanLanes]: ring 1's u5 column, 128 doubles per wave
+constexpr int kAScanMTable = 0;                                        // [angle][mx, my, mz] in the cells behind the tables (the histogram kernels' tile_extra)
+constexpr int kAScanCounters = 3 * kAScanMaxAngles;                    // behind it: (4 kAScanMaxAngles + 4) u32
+static_assert(kAScanMTable + 3 * kAScanMaxAngles + (4 * kAScanMaxAngles + 4 + 1) / 2 <= kTileExtraCells, "rotation columns + counters live where the histogram kernels keep the image tile behind the tables");
 static_assert(2 * kScanLanes == 64, "one cell per lane in the epilogue");
 
 template <int BLOCK, bool FAST, int GAS, bool FIXED>
@@ -1925,12 +1927,14 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
     QueueLds<BLOCK / 64> Q;
   };
   __shared__ LdsLayout lds;
-  // per angle: N_PASSED, N_HIT_NICKEL, N_PASSED_TILL_WINDOW, N_SHELL_SELECTED of this workgroup; [4 kAScanMaxAngles]: N_REACHED_TELESCOPE
-  __shared__ uint32_t cnt[4 * kAScanMaxAngles + 4];
   static_assert((offsetof(LdsLayout, Q) % 512) == 0, "the rings are addressed with ds_*2st64 offsets");
-  static_assert(BLOCK / 64 >= kAScanMaxAngles, "the epilogue gives every angle a wave");
+  static_assert(kAScanCells == (BLOCK / 64) * kQueue, "the per-angle cells are the u5 column of the workgroup's rings");
   TablesLds& S = lds.S;
   QueueLds<BLOCK / 64>& Q = lds.Q;
+  // per angle: N_PASSED, N_HIT_NICKEL, N_PASSED_TILL_WINDOW, N_SHELL_SELECTED of this workgroup; [4 kAScanMaxAngles]: N_REACHED_TELESCOPE
+  uint32_t* const cnt = reinterpret_cast<uint32_t*>(&lds.cells[kAScanCounters]);
+  // cell t of the per-angle sums: slot t % 128 of wave t / 128's u5 column
+  auto acc_cell = [&](uint32_t t) -> double* { return &Q.w[t >> 7].u5[t & 127u]; };
   DevBlob& B = lds.B;
   TraceArgs& Ab = lds.Ab;
   (void)unused; (void)HBarg;
@@ -1940,8 +1944,7 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
     for (int i = threadIdx.x; i < (int)(sizeof(DevBlob) / 8); i += BLOCK) dst[i] = src[i];
     if (threadIdx.x == 0) Ab = A;
     uint64_t* q = reinterpret_cast<uint64_t*>(&Q);
-    for (int i = threadIdx.x; i < (int)(sizeof(Q) / 8); i += BLOCK) q[i] = 0ull;
-    for (int i = threadIdx.x; i < kAScanCells; i += BLOCK) lds.cells[i] = 0.0;
+    for (int i = threadIdx.x; i < (int)(sizeof(Q) / 8); i += BLOCK) q[i] = 0ull;   // (the rings, and with them the cells)
     if (threadIdx.x < 4 * kAScanMaxAngles + 4) cnt[threadIdx.x] = 0u;
     if (threadIdx.x < 3 * kAScanMaxAngles) {
       // third column of every angle's rotation, from the kernel arguments (a per-thread read of the argument segment)
@@ -2045,7 +2048,7 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
       Q.w[wave].X0[slot] = st.X0; Q.w[wave].Y0[slot] = st.Y0;
       Q.w[wave].tsx[slot] = st.tsx; Q.w[wave].tsy[slot] = st.tsy;
       Q.w[wave].path[slot] = st.path_cb;
-      Q.w[wave].idx[slot] = st_eidx | (st.shell << 16) | (k << 24);   // energy index < 2^16 (the guide tables are u16), shell < 64, angle < 16
+      Q.w[wave].idx[slot] = st_eidx | (st.shell << 16) | (k << 24);   // energy index < 2^16 (the guide tables are u16), shell < 64, angle < 32
     }
     t1 += (uint32_t)__popcll(mask);
     __builtin_amdgcn_s_setprio(0);
@@ -2086,7 +2089,7 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
     if (out.passed) {
       atomicAdd(&cnt[4 * kl], 1u);
       // cell [kl][0][lane % 32]; [kl][1][.] is kScanLanes further on (lanes l and l + 32 share a cell, as in the mass scan)
-      double* const cell = &lds.cells[kl * (2u * kScanLanes) + ((uint32_t)lane & (kScanLanes - 1u))];
+      double* const cell = acc_cell(kl * (2u * kScanLanes) + ((uint32_t)lane & (kScanLanes - 1u)));   // (+ kScanLanes stays inside the wave's column)
       if constexpr (FIXED) {
         double fx_w, fx_w2;
         { const TraceArgs& Al = lds_opaque(Ab); fx_w = Al.fx_scale_w; fx_w2 = Al.fx_scale_w2; }
@@ -2192,7 +2195,7 @@ __global__ __launch_bounds__(BLOCK) void trace_angular_scan_kernel(HotA H, const
   using Sum = std::conditional_t<FIXED, long long, double>;
   for (int k = wave; k < n_angles; k += BLOCK / 64) {
     Sum* const dst = reinterpret_cast<Sum*>(ANarg.partials) + ((size_t)blockIdx.x * kAScanMaxAngles + (size_t)k) * kAScanPartialSlots;
-    const double cell = lds.cells[k * 64 + lane];
+    const double cell = *acc_cell((uint32_t)(k * 64 + lane));
     Sum v;
     if constexpr (FIXED) v = __double_as_longlong(cell); else v = cell;
 #pragma unroll
@@ -2213,8 +2216,8 @@ __global__ __launch_bounds__(1024) void fold_ascan_kernel(double* __restrict__ r
                                                          int n_blocks, int n_angles, double n_rays) {
   using Sum = std::conditional_t<FIXED, long long, double>;
   constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
-  constexpr int kPairs = kAScanMaxAngles * kAScanPartialSlots, kGroups = 8;
-  static_assert(kPairs * kGroups == 1024, "one thread per (angle, partial slot, group of workgroups)");
+  constexpr int kPairs = kAScanMaxAngles * kAScanPartialSlots, kGroups = 1024 / kPairs;
+  static_assert(kPairs * kGroups == 1024 && kGroups >= 1, "one thread per (angle, partial slot, group of workgroups)");
   Sum* const rows = reinterpret_cast<Sum*>(rows_);
   Sum* const shared_row = reinterpret_cast<Sum*>(shared_row_);
   const Sum* const part = reinterpret_cast<const Sum*>(partials_);

@@ -108,7 +108,7 @@ def check_rows_equal_singles(scan, an, singles, n, label):
 def test_fixed64_scan_equals_single_angle_launches_bit_for_bit(name):
     import torch
     full, knobs, flags = variant_setup(name)
-    an = angles(19, top=1.2 if name.startswith("cast") else 0.4)   # two groups of angles: 10 + 9
+    an = angles(35, top=1.2 if name.startswith("cast") else 0.4)   # two groups of angles: 18 + 17
     n, seed = 2_000_000, 17
     with env(**knobs):
         with sa.RayTracer(full) as rt:
@@ -124,15 +124,15 @@ def test_fixed64_scan_equals_single_angle_launches_bit_for_bit(name):
 
 
 def test_fixed64_scan_is_independent_of_the_grouping_of_the_angles():
-    """16 angles per launch: 33 angles run as 11 + 11 + 11; every row equals the row of a scan of that angle alone."""
+    """32 angles per launch: 67 angles run as 23 + 22 + 22; every row equals the row of a scan of that angle alone."""
     import torch
     full = make_setup("babyiaxo_xmm")
-    an = angles(33)
+    an = angles(67)
     n, seed = 1_000_000, 29
     with sa.RayTracer(full) as rt:
         rt.set_accumulation_mode("fixed64")
         scan = raw_scan(rt, torch, an, [(0, n)], seed)
-        for k in (0, 10, 11, 21, 22, 32):
+        for k in (0, 22, 23, 44, 45, 66):
             one = raw_scan(rt, torch, an[k:k + 1], [(0, n)], seed)
             assert np.array_equal(one[0], scan[k]), k
             assert np.array_equal(one[1], scan[len(an)])
@@ -215,7 +215,7 @@ def test_scan_matches_the_oracle_per_angle(name):
 
 def test_scan_on_full_size_tables_matches_the_oracle_and_the_host_loop():
     """BASELINE configs[3] at its table sizes (1968 x 1500 CDFs, 1000 x 1000 reflectivity): 50 angles of the XMM off-axis curve
-    through the C++ host driver (four launches of 13 / 13 / 12 / 12 angles), three of them against the 80-bit oracle and the
+    through the C++ host driver (two launches of 25 angles), three of them against the 80-bit oracle and the
     single-angle launches."""
     from oracle.oracle import Oracle
     full = sa.initFullSetup()
