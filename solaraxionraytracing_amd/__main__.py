@@ -35,6 +35,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--angularScanMin", type=float, default=0.0)
     ap.add_argument("--angularScanMax", type=float, default=0.0)
     ap.add_argument("--numAngularScanPoints", type=int, default=50)
+    ap.add_argument("--fusedAngularScan", action="store_true",
+                    help="extension: the angular scan through the fused kernel (sart_trace_angular_scan: every ray sampled once and "
+                         "turned through every angle, the same rays for all angles) instead of a re-trace on fresh rays per angle")
     ap.add_argument("--massScanMin", type=float, default=0.0, help="eV (extension: fused axion-mass scan)")
     ap.add_argument("--massScanMax", type=float, default=0.0, help="eV")
     ap.add_argument("--numMassScanPoints", type=int, default=32)
@@ -92,13 +95,15 @@ def main(argv=None) -> int:
             print("The total flux", flux)
             print("wrote", out)
         else:
-            angles, fluxes, rel = performAngularScan(rt, args.angularScanMin, args.angularScanMax, args.numAngularScanPoints, n,
-                                                     seed=args.seed, flags=flags)
+            res = performAngularScan(rt, args.angularScanMin, args.angularScanMax, args.numAngularScanPoints, n, seed=args.seed, flags=flags,
+                                     fused=args.fusedAngularScan, errors=args.fusedAngularScan)
+            angles, fluxes, rel = res[:3]
+            errs = res[3] if args.fusedAngularScan else [float("nan")] * len(angles)
             out = os.path.join(args.outpath, "angular_scan_telescope_y.csv")   # the reference only saves the PDF of this curve
             with open(out, "w") as f:
-                f.write("Angles [deg],Flux fraction,relative flux\n")
-                for a, fl, r in zip(angles, fluxes, rel):
-                    f.write("%r,%r,%r\n" % (float(a), float(fl), float(r)))
+                f.write("Angles [deg],Flux fraction,relative flux,flux error\n")
+                for a, fl, r, e in zip(angles, fluxes, rel, errs):
+                    f.write("%r,%r,%r,%r\n" % (float(a), float(fl), float(r), float(e)))
             print("wrote", out)
     return 0
 

@@ -516,7 +516,16 @@ def test_command_line_full_run_and_angular_scan(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     scan = np.loadtxt(out / "angular_scan_telescope_y.csv", delimiter=",", skiprows=1)
-    assert scan.shape == (3, 3) and scan[0, 2] == 1.0 and scan[2, 2] < 1.0
+    assert scan.shape == (3, 4) and scan[0, 2] == 1.0 and scan[2, 2] < 1.0 and np.all(np.isnan(scan[:, 3]))
+    # the same scan through the fused kernel (--fusedAngularScan: the same rays for every angle, errors in the fourth column)
+    r = subprocess.run([sys.executable, "-m", "solaraxionraytracing_amd", "--rays", "200000", "--outpath", str(out), "--ignoreDetWindow",
+                        "--ignoreGasAbs", "--ignoreConvProb", "--angularScanMax", "0.05", "--numAngularScanPoints", "3", "--fusedAngularScan"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    fused = np.loadtxt(out / "angular_scan_telescope_y.csv", delimiter=",", skiprows=1)
+    assert fused.shape == (3, 4) and fused[0, 2] == 1.0 and fused[2, 2] < 1.0 and np.all(fused[:, 3] > 0) and np.all(fused[:, 3] < 0.05 * fused[:, 1])
+    assert fused[0, 1] == scan[0, 1]                          # angle 0: the same ray ids in both shapes
+    assert abs(fused[2, 1] / scan[2, 1] - 1.0) < 0.05         # the other angles: other rays in the host loop
     # the third mode (not in the reference): the fused axion-mass scan on a gas-stage config.toml
     cfg = tmp_path / "config.toml"
     sample = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "make_nim_parity_kit.py")).read()
