@@ -478,3 +478,70 @@ def test_a_wall_limit_is_opt_in(tmp_path):
     assert r.returncode == 3 and "SART_LAUNCH_TIMEOUT" in r.stderr, (r.returncode, r.stderr)
     from solaraxionraytracing_amd import distributed as D
     assert D.LAUNCH_TIMEOUT_S == 0
+
+
+# ---- fused angular scan on N ranks (BASELINE configs[3]: "8 GPUs sharded by angle bin"), rebuilt from the CPU oracle -----------------
+_SCAN_ANGLES = (0.0, 0.05, 0.1, 0.15, 0.2)
+
+
+def _ascan_rows(o, full, angles, lo, n, seed):
+    """What sart_trace_angular_scan_device leaves in a rank's scan accumulator for `angles` on the ray ids [lo, lo + n): one oracle
+    run per angle on the same ray ids; the angle-independent counters from the first."""
+    from solaraxionraytracing_amd import _lib
+    rows = np.zeros((len(angles) + 1, _lib.ASCAN_ROW))
+    for k, a in enumerate(angles):
+        s = full.setup.copy()
+        s.telescope_turned_y_deg = float(a)
+        summ = o.trace_histogram(n, seed=seed, ray_id_offset=lo, setup=s, flags=full.flags, n_threads=2)[1]
+        for name, slot in _lib.ASCAN.items():
+            rows[k, slot] = summ[name]
+        if k == 0:
+            for name, slot in _lib.ASCAN_SHARED.items():
+                rows[len(angles), slot] = summ[name]
+    return rows
+
+
+def _ascan_worker(rank, world, port, n_total, seed, shard, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    from tests.conftest import make_setup
+    from oracle.oracle import Oracle
+    import solaraxionraytracing_amd as sa
+    D.init_process_group_from_env("gloo")
+    full = make_setup("babyiaxo_xmm_rot")
+    o = Oracle(full)
+    if shard == "rays":      # every rank turns its share of the ray ids through all angles; one reduce of (K + 1) x 8 slots
+        acc = D.trace_sharded(lambda lo, n: _ascan_rows(o, full, _SCAN_ANGLES, lo, n, seed).ravel(), n_total, rank, world, dst=0).numpy()
+        curve = sa.split_angular_scan(acc, len(_SCAN_ANGLES))[0]["SUM_WEIGHTS"]
+    else:                    # the angles are dealt out (tools/scan.py angular --fused): every rank on ALL ray ids for its group
+        mine = D.shard_angles(len(_SCAN_ANGLES), rank, world)
+        rows = _ascan_rows(o, full, [_SCAN_ANGLES[i] for i in mine], 0, n_total, seed)
+        vals = sa.split_angular_scan(rows.ravel(), len(mine))[0]["SUM_WEIGHTS"]
+        curve = D.gather_scan(torch.tensor(vals, dtype=torch.float64), mine, len(_SCAN_ANGLES)).numpy()
+    if rank == 0:
+        np.save(out_path, curve)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard,world", [("rays", 2), ("bins", 2), ("bins", 3)])
+def test_fused_angular_scan_on_n_ranks_equals_single_process(tmp_path, shard, world):
+    """The two shapes of the fused angular scan on N ranks (tools/scan.py angular --fused [--shard rays]): the curve of one
+    process, whatever the number of ranks - angle groups: every rank sees all ray ids, so its rows ARE the single process's rows;
+    ray shards: counts exact, sums to 1e-12."""
+    import solaraxionraytracing_amd as sa
+    from tests.conftest import make_setup
+    from oracle.oracle import Oracle
+    n_total, seed = 20_001, 83
+    out = str(tmp_path / "ascan.npy")
+    mp.spawn(_ascan_worker, args=(world, 29631 + world + (7 if shard == "rays" else 0), n_total, seed, shard, out), nprocs=world, join=True)
+    full = make_setup("babyiaxo_xmm_rot")
+    one = sa.split_angular_scan(_ascan_rows(Oracle(full), full, _SCAN_ANGLES, 0, n_total, seed).ravel(), len(_SCAN_ANGLES))[0]["SUM_WEIGHTS"]
+    got = np.load(out)
+    if shard == "bins":
+        assert np.array_equal(got, one)
+    else:
+        np.testing.assert_allclose(got, one, rtol=1e-12)
+    assert got.min() > 0 and got[0] > got[-1]
+    assert sa.angular_scan_len(len(_SCAN_ANGLES)) == (len(_SCAN_ANGLES) + 1) * 8
