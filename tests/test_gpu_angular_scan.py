@@ -333,3 +333,25 @@ def test_fused_scan_driver_sharded_over_two_ranks_equals_one_process(tmp_path, s
     ca, cb = np.loadtxt(a, delimiter=",", skiprows=1, usecols=(0, 1, 2)), np.loadtxt(b, delimiter=",", skiprows=1, usecols=(0, 1, 2))
     np.testing.assert_allclose(cb[:, 1], ca[:, 1], rtol=1e-12)
     assert ca[:, 1].min() > 0 and ca[0, 1] > ca[-1, 1]
+
+
+@pytest.mark.parametrize("mode", ["f64", "fixed64"])
+def test_flux_only_launch_carries_the_spectra(mode):
+    """image_nx = image_ny = 0 with params.spectra = 1: the accumulator is the 24 scalars followed by the radial and per-energy
+    histograms - the post-processing of generateResultPlots without an image (and, in the integer mode, a conservation check whose
+    pixel sum is all in SUM_WEIGHTS_OUTSIDE)."""
+    full = make_setup("babyiaxo_xmm")
+    n, seed = 1_000_000, 14
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode(mode)
+        img, s, spec = rt.trace_spectra(n, seed=seed, n_radial_bins=500, radial_max=10.0)
+        img0, s0, spec0 = rt.trace_spectra(n, seed=seed, image_n=0, n_radial_bins=500, radial_max=10.0)
+    assert img0.size == 0 and s0["N_OUTSIDE_IMAGE"] == s0["N_PASSED"] == s["N_PASSED"]
+    for key in ("radial_counts", "energy_counts"):
+        assert np.array_equal(spec0[key], spec[key]), key
+    for key in ("radial_weights", "energy_weights", "energy_reflect"):
+        if mode == "fixed64":
+            assert np.array_equal(spec0[key], spec[key]), key
+        else:
+            np.testing.assert_allclose(spec0[key], spec[key], rtol=1e-11, atol=1e-30)
+    assert spec0["radial_weights"].sum() == pytest.approx(s0["SUM_WEIGHTS"], rel=1e-12)
