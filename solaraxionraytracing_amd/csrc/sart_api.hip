@@ -1596,6 +1596,9 @@ int sart_rollover_accumulator_device(sart_context* c, const sart_trace_params_t*
   if (((p->image_nx < 1 || p->image_ny < 1) && !(p->image_nx == 0 && p->image_ny == 0)) || (p->spectra && p->n_radial_bins < 1))
     return fail(SART_ERR_INVALID_ARGUMENT, "invalid image specification");
   if (acc_fixed_dev == hi_limbs_dev) return fail(SART_ERR_INVALID_ARGUMENT, "the limbs need an array of their own");
+  if (c->accum_mode != SART_ACCUM_FIXED64)
+    return fail(SART_ERR_INVALID_ARGUMENT, "sart_rollover_accumulator_device folds the int64 slots of a raw SART_ACCUM_FIXED64 accumulator; the "
+                                           "context is in SART_ACCUM_F64 mode (its accumulators hold doubles)");
   SART_HIP(hipSetDevice(c->device));
   if (int rc = status_ensure(c)) return rc;
   launch_rollover_fixed(acc_fixed_dev, hi_limbs_dev, acc_len_of(c, p), c->d_status.p, c->stream);

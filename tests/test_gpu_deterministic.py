@@ -508,6 +508,11 @@ def test_fixed64_rollover_limbs_carry_an_accumulation_past_the_headroom():
         fine = out.cpu().numpy()
         rt.set_accumulation_mode("fixed64", headroom_bits=40)
         coarse = _device_fixed_run(rt, torch, n, seed=seed, launches=launches)
+        # the fold is an integer operation: a context whose accumulators hold doubles refuses it
+        rt.set_accumulation_mode("f64")
+        with pytest.raises(L.SartError) as e:
+            rt.rollover_accumulator_device(p, acc.data_ptr(), hi.data_ptr())
+        assert e.value.code == L.SART_ERR_INVALID_ARGUMENT and "F64" in str(e.value)
     assert fine[k0 + L.ACC["N_RAYS"]] == coarse[k0 + L.ACC["N_RAYS"]] == n * launches
     for name in ("SUM_WEIGHTS", "SUM_X", "SUM_Y", "SUM_R", "N_PASSED", "SUM_WEIGHTS_SQ"):
         assert fine[k0 + L.ACC[name]] == pytest.approx(coarse[k0 + L.ACC[name]], rel=1e-9), name
