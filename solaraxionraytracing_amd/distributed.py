@@ -359,15 +359,16 @@ def preflight(backend: str | None = None, n_bytes: int = 512 * 1024) -> dict:
     return out
 
 
-def reduce_accumulator(acc, dst: int | None = 0, fixed64: bool = False):
+def reduce_accumulator(acc, dst: int | None = 0, fixed64: bool = False, even_alone: bool = False):
     """The single collective of the path: sum the fused accumulator tensor over ranks (``dst`` = root rank, or
     None for an all-reduce).  No-op without a process group.  ``fixed64``: the 8-byte slots hold the int64 of a raw
     SART_ACCUM_FIXED64 accumulator - they are summed as integers (exact, so the result does not depend on the number of
-    ranks or on the reduction tree)."""
+    ranks or on the reduction tree).  ``even_alone``: issue the collective in a one-rank group too (the one-GPU rehearsal of
+    the RCCL call: communicator, dtype and stream handling are what an N-rank run uses; tests/test_gpu_parity.py)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not even_alone):
         return acc
     buf = acc.view(torch.int64) if (fixed64 and acc.dtype != torch.int64) else acc
     if dst is None:

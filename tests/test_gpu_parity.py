@@ -331,6 +331,57 @@ def test_trace_records_chunked_path_is_byte_identical():
         assert raw[:24].tobytes() != b"" and one["passed"].sum() > 0.5 * n
 
 
+RCCL_ALONE = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, %r)
+import solaraxionraytracing_amd as sa
+from solaraxionraytracing_amd import _lib as L
+from solaraxionraytracing_amd import distributed as D
+rank, world, local = D.init_process_group_from_env("nccl")
+assert (rank, world) == (0, 1)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+n = sa.accumulator_len(256)
+with sa.RayTracer(sa.initFullSetup()) as rt:
+    p = rt.trace_params(3_000_000, seed=5)
+    for mode, dtype in (("f64", torch.float64), ("fixed64", torch.int64)):
+        rt.set_accumulation_mode(mode)
+        acc = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+        rt.trace_histogram_device(p, acc.data_ptr())
+        torch.cuda.synchronize()
+        before = acc.clone()
+        for dst in (0, None):
+            out = D.reduce_accumulator(acc, dst=dst, fixed64=(mode == "fixed64"), even_alone=True)   # the RCCL call of an N-rank run
+            torch.cuda.synchronize()
+            assert out is acc and torch.equal(acc.view(torch.int64), before.view(torch.int64)), (mode, dst)
+        if mode == "fixed64":
+            rt.finalize_accumulator_device(p, acc.data_ptr())
+        s = acc[256 * 256:].cpu().numpy()
+        assert s[L.ACC["N_RAYS"]] == 3_000_000 and s[L.ACC["N_PASSED"]] > 5e5 and abs(acc[:256 * 256].sum().item() / s[L.ACC["SUM_WEIGHTS"]] - 1) < 1e-9
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_ALONE_OK", flush=True)
+'''
+
+
+def test_rccl_carries_the_accumulator_in_a_one_rank_group():
+    """What a one-GPU box can show of the RCCL leg (the N > 1 runs are the driver's): torch.distributed backend "nccl" comes up
+    on this card, and the path's one collective - reduce / all-reduce of the fused accumulator, as f64 and as the int64 of a raw
+    SART_ACCUM_FIXED64 accumulator - runs through the RCCL communicator on the accumulator the kernel has just filled and leaves
+    it bit for bit as it was."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29561", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", RCCL_ALONE % root], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_ALONE_OK" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
 def test_bench_gpus_n_starts_its_own_ranks_and_refuses_to_lie():
     """`python bench.py --gpus 2` WITHOUT torchrun: the script starts two ranks itself (gloo rehearsal on this one card) and
     the line says n_gpus 2; `--gpus 8` on a one-GPU box exits non-zero without a line."""
