@@ -115,6 +115,12 @@ proc sart_set_detector_tables*(ctx: ptr SartContext, strongbackX, strongbackY: p
                                gasAbsX, gasAbsY: ptr cdouble, nGasAbs: int32): cint {.importc, header: sartH.}
 proc sart_trace_records*(ctx: ptr SartContext, p: ptr SartTraceParams, axBuf: pointer): cint {.importc, header: sartH.}
 proc sart_trace_records_device*(ctx: ptr SartContext, p: ptr SartTraceParams, axBufDevice: pointer): cint {.importc, header: sartH.}
+type SartRecordCounts* {.importc: "sart_record_counts_t", header: sartH, bycopy.} = object
+  n_rays*, n_passed*, n_passed_till_window*, n_hit_nickel*: uint64
+proc sart_trace_records_passed*(ctx: ptr SartContext, p: ptr SartTraceParams, axBuf: pointer, capacity: uint64,
+                                counts: ptr SartRecordCounts): cint {.importc, header: sartH.}
+proc sart_trace_records_passed_device*(ctx: ptr SartContext, p: ptr SartTraceParams, axBufDevice: pointer, capacity: uint64,
+                                       countsDevice: pointer): cint {.importc, header: sartH.}
 proc sart_trace_histogram_device*(ctx: ptr SartContext, p: ptr SartTraceParams, accumulatorDevice: ptr cdouble): cint {.importc, header: sartH.}
 proc sart_trace_histogram*(ctx: ptr SartContext, p: ptr SartTraceParams, imageOutHost: ptr cdouble, summary: ptr SartSummary): cint {.importc, header: sartH.}
 proc sart_trace_histogram_spectra*(ctx: ptr SartContext, p: ptr SartTraceParams, imageOutHost: ptr cdouble, summary: ptr SartSummary,
@@ -293,6 +299,18 @@ proc traceAxionWrapperGpu*(ctx: ptr SartContext, axBuf: ptr UncheckedArray[Axion
   ## Literal drop-in: `bufLen` Axion records into the caller's buffer.
   var p = sartParams(bufLen, flags, seed, rayIdOffset)
   sartCheck sart_trace_records(ctx, addr p, axBuf)
+
+proc traceAxionsPassedGpu*(ctx: ptr SartContext, bufLen: int, flags: set[ConfigFlags], counts: var SartRecordCounts,
+                           seed = 299792458'u64, rayIdOffset = 0'u64, capacity = 0): seq[Axion] =
+  ## `axions.filterIt(it.passed)` of the buffer traceAxionWrapper would fill (what generateResultPlots :2252 and the scan
+  ## sum :2800 go on with), in ray order, and the counts echoed at :2253-2257 - without the records of the other rays
+  ## crossing PCIe.  `capacity` = records to make room for (0: bufLen, always enough; a caller that knows its pass
+  ## fraction allocates less and checks counts.n_passed <= capacity).
+  let cap = if capacity > 0: capacity else: bufLen
+  result = newSeq[Axion](cap)
+  var p = sartParams(bufLen, flags, seed, rayIdOffset)
+  sartCheck sart_trace_records_passed(ctx, addr p, (if cap > 0: addr result[0] else: nil), cap.uint64, addr counts)
+  result.setLen(min(counts.n_passed.int, cap))
 
 proc traceHistogramGpu*(ctx: ptr SartContext, nRays: int, flags: set[ConfigFlags], image: var seq[cdouble],
                         seed = 299792458'u64, rayIdOffset = 0'u64): SartSummary =

@@ -102,6 +102,23 @@ int main(int argc, char** argv) {
     if (fx >= 0.0 && fx < IMG && fy >= 0.0 && fy < IMG) img_rec[(int)fy * IMG + (int)fx] += a->weights;
   }
 
+  /* 3b. the passed rays only (sart_trace_records_passed): the records `filterIt(it.passed)` keeps, in the same order, and the
+   *     three counts - with a buffer a quarter over the number that passed */
+  int passed_ok = 0;
+  {
+    const uint64_t cap = n_passed + n_passed / 4 + 1;
+    sart_axion_t* only = malloc(cap * sizeof *only);
+    sart_record_counts_t rc;
+    if (!only) return 2;
+    CHECK(sart_trace_records_passed(ctx, &p, only, cap, &rc));
+    passed_ok = rc.n_rays == n_rays && rc.n_passed == n_passed && rc.n_passed_till_window == n_till && rc.n_hit_nickel == n_nickel;
+    uint64_t k = 0;
+    for (uint64_t i = 0; i < n_rays && passed_ok; ++i)
+      if (ax_buf[i].passed) passed_ok = memcmp(&only[k++], &ax_buf[i], sizeof *only) == 0;
+    passed_ok = passed_ok && k == n_passed;
+    free(only);
+  }
+
   /* 4. the same rays through the fused histogram entry */
   static double image[IMG * IMG];
   sart_summary_t s;
@@ -118,9 +135,9 @@ int main(int argc, char** argv) {
                  s.v[SART_ACC_N_HIT_NICKEL] == (double)n_nickel && s.v[SART_ACC_N_RAYS] == (double)n_rays &&
                  fabs(s.v[SART_ACC_SUM_WEIGHTS] - flux) <= 1e-11 * flux && max_diff <= 1e-11 * img_max && n_passed > 0;
   printf("{\"abi\": %d, \"build\": \"%s\", \"n_rays\": %llu, \"passed\": %llu, \"passed_till_window\": %llu, \"hit_nickel\": %llu, "
-         "\"flux_records\": %.17g, \"flux_histogram\": %.17g, \"image_max_abs_diff\": %.3g, \"agree\": %s}\n",
+         "\"flux_records\": %.17g, \"flux_histogram\": %.17g, \"image_max_abs_diff\": %.3g, \"passed_only_records_agree\": %s, \"agree\": %s}\n",
          sart_abi_version(), sart_build_id(), (unsigned long long)n_rays, (unsigned long long)n_passed, (unsigned long long)n_till,
-         (unsigned long long)n_nickel, flux, s.v[SART_ACC_SUM_WEIGHTS], max_diff, ok ? "true" : "false");
+         (unsigned long long)n_nickel, flux, s.v[SART_ACC_SUM_WEIGHTS], max_diff, passed_ok ? "true" : "false", (ok && passed_ok) ? "true" : "false");
   /* 6. gas stage: one pass over the rays for all masses vs one traceAxionWrapper per mass */
   enum { N_MASSES = 5 };
   const double masses[N_MASSES] = {0.0, 0.004, 0.008235, 0.012, 0.05};   /* eV; m_gamma = 0.008235 eV for this magnet (literal units) */
@@ -178,5 +195,5 @@ int main(int argc, char** argv) {
          N_ANGLES, ascan[SART_ASCAN_SUM_WEIGHTS], ascan_max_rel, ascan_ok ? "true" : "false");
   free(ax_buf);
   CHECK(sart_destroy(ctx));
-  return (ok && scan_ok && ascan_ok) ? 0 : 1;
+  return (ok && passed_ok && scan_ok && ascan_ok) ? 0 : 1;
 }

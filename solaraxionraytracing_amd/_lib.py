@@ -16,7 +16,7 @@ LIBSART_HOST_PATH = os.path.join(_PKG_DIR, "libsart_host.so")
 SART_MAX_SHELLS = 64
 SART_MAX_COATINGS = 8
 SART_ACC_COUNT = 24
-SART_ABI_VERSION = 3
+SART_ABI_VERSION = 4
 
 # enums (values of include/sart.h)
 ES_CAST, ES_BABYIAXO = 0, 1
@@ -119,6 +119,11 @@ AXION_DTYPE = _np.dtype({
 })
 
 
+class RecordCounts(C.Structure):
+    """sart_record_counts_t"""
+    _fields_ = [("n_rays", C.c_uint64), ("n_passed", C.c_uint64), ("n_passed_till_window", C.c_uint64), ("n_hit_nickel", C.c_uint64)]
+
+
 class TraceParams(C.Structure):
     """sart_trace_params_t"""
     _fields_ = [
@@ -195,6 +200,8 @@ SART_SYMBOLS = {
     "sart_set_detector_tables": (C.c_int, [C.c_void_p, _dp, _dp, _i, _dp, _dp, _i, _dp, _dp, _i]),
     "sart_trace_records": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p]),
     "sart_trace_records_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p]),
+    "sart_trace_records_passed": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p, C.c_uint64, _P(RecordCounts)]),
+    "sart_trace_records_passed_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p, C.c_uint64, C.c_void_p]),
     "sart_trace_histogram_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p]),
     "sart_trace_histogram": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _P(Summary)]),
     "sart_trace_histogram_spectra": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _P(Summary), _dp]),

@@ -42,6 +42,9 @@ int histogram_block_of(int variant);
 void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream, const double* uniforms_dev);
 int records_block();
+int compact_chunk_max();
+void launch_compact_records(const sart_axion_t* rec, uint32_t n, sart_axion_t* out, unsigned long long capacity, uint32_t* block_counts,
+                            unsigned long long* block_first, unsigned long long* counts, hipStream_t stream);
 int histogram_blocks_per_cu(int variant);
 void launch_build_solar_tables(const double* em_dev, const double* radii_dev, const double* energies_dev, int n_radii, int n_energies,
                                double* cdf_dev, double* row_sum_dev, double* rcdf_dev, uint16_t* rguide_dev, uint16_t* eguide_dev,
@@ -204,6 +207,12 @@ struct sart_context {
   bool d_acc_stale = false;    // its contents belong to another accumulation mode: the next call starts from zero
   DevBuf<sart_axion_t> d_rec;  // scratch records of the blocking convenience call
   DevBuf<sart_axion_t> d_rec2; // its second half-buffer (chunked, double-buffered record path)
+  // passed-rays-only record path: compacted chunks (two half-buffers), scan scratch, counts {n_rays, n_passed, n_passed_till_window,
+  // n_hit_nickel} per half-buffer on the device and in pinned host memory
+  DevBuf<sart_axion_t> d_cmp[2];
+  DevBuf<uint32_t> d_cmp_counts;
+  DevBuf<unsigned long long> d_cmp_first, d_cmp_totals;
+  unsigned long long* h_cmp_totals = nullptr;
   hipStream_t copy_stream = nullptr;   // D2H of the record chunks, beside the kernels on `stream`
   hipEvent_t rec_traced[2] = {nullptr, nullptr}, rec_copied[2] = {nullptr, nullptr};
   bool derived_dirty = true;
@@ -968,6 +977,7 @@ int sart_destroy(sart_context* c) {
   if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->h_status) (void)hipHostFree(c->h_status);
+  if (c->h_cmp_totals) (void)hipHostFree(c->h_cmp_totals);
   delete c;
   return 0;
 }
@@ -1268,8 +1278,10 @@ namespace {
 
 class HostPrefault {   // faults [base, base + bytes) in, chunk by chunk, on a background thread; wait(k) blocks until chunk k is mapped
  public:
-  HostPrefault(char* base, size_t bytes, size_t chunk_bytes, bool enabled, unsigned threads)
-      : base_(base), bytes_(bytes), chunk_(chunk_bytes), threads_(threads ? threads : 8u) {
+  // keep: the buffer's contents survive (every page's first byte is rewritten with itself); otherwise a zero is written - every
+  // byte touched is one the caller's records overwrite
+  HostPrefault(char* base, size_t bytes, size_t chunk_bytes, bool enabled, unsigned threads, bool keep = false)
+      : base_(base), bytes_(bytes), chunk_(chunk_bytes), threads_(threads ? threads : 8u), keep_(keep) {
     n_chunks_ = (bytes + chunk_bytes - 1) / chunk_bytes;
     if (!enabled || bytes < (size_t(8) << 20)) { done_ = n_chunks_; return; }   // small buffers: not worth a thread
     const long page = sysconf(_SC_PAGESIZE);
@@ -1279,10 +1291,25 @@ class HostPrefault {   // faults [base, base + bytes) in, chunk by chunk, on a b
     if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);   // a hint: failure changes nothing
     worker_ = std::thread([this] { run(); });
   }
-  ~HostPrefault() { if (worker_.joinable()) worker_.join(); }
+  ~HostPrefault() {
+    allow(0, true);
+    if (worker_.joinable()) worker_.join();
+  }
   void wait(size_t k) {
+    allow(k + 1);
     std::unique_lock<std::mutex> lock(m_);
     cv_.wait(lock, [&] { return done_ > k; });
+  }
+  // lazy mode (sart_trace_records_passed: how much of the buffer will be written is known chunk by chunk): the worker maps
+  // chunk k only once allow(> k) has been called
+  void set_lazy() { std::lock_guard<std::mutex> lock(m_); allowed_ = 0; }
+  void allow(size_t chunks, bool stop = false) {
+    {
+      std::lock_guard<std::mutex> lock(m_);
+      allowed_ = std::max(allowed_, std::min(chunks, n_chunks_));
+      stop_ = stop_ || stop;
+    }
+    cv_.notify_all();
   }
 
  private:
@@ -1290,6 +1317,11 @@ class HostPrefault {   // faults [base, base + bytes) in, chunk by chunk, on a b
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned n_threads = std::min(threads_, hw);
     for (size_t k = 0; k < n_chunks_; ++k) {
+      {
+        std::unique_lock<std::mutex> lock(m_);
+        cv_.wait(lock, [&] { return allowed_ > k || stop_; });
+        if (allowed_ <= k) break;   // stopped: the chunks nobody asked for stay untouched
+      }
       // whole pages inside this chunk (the partial pages at the ends of the buffer are mapped by the copy itself)
       const uintptr_t b = reinterpret_cast<uintptr_t>(base_) + k * chunk_;
       const uintptr_t e = reinterpret_cast<uintptr_t>(base_) + std::min(bytes_, (k + 1) * chunk_);
@@ -1302,7 +1334,8 @@ class HostPrefault {   // faults [base, base + bytes) in, chunk by chunk, on a b
           if (p1 > p0)
             th.emplace_back([=] {
               volatile char* q = reinterpret_cast<volatile char*>(lo);
-              for (size_t pg = p0; pg < p1; ++pg) q[pg * page_] = 0;   // one write per page: overwritten by the records
+              if (keep_) for (size_t pg = p0; pg < p1; ++pg) q[pg * page_] = q[pg * page_];
+              else for (size_t pg = p0; pg < p1; ++pg) q[pg * page_] = 0;   // one write per page: overwritten by the records
             });
         }
         for (auto& t : th) t.join();
@@ -1315,8 +1348,10 @@ class HostPrefault {   // faults [base, base + bytes) in, chunk by chunk, on a b
     }
   }
   char* base_;
-  size_t bytes_, chunk_, n_chunks_ = 0, page_ = 4096, done_ = 0;
+  size_t bytes_, chunk_, n_chunks_ = 0, page_ = 4096, done_ = 0, allowed_ = ~size_t(0);
+  bool stop_ = false;
   unsigned threads_;
+  bool keep_ = false;
   std::mutex m_;
   std::condition_variable cv_;
   std::thread worker_;
@@ -1382,6 +1417,111 @@ int sart_trace_records(sart_context* c, const sart_trace_params_t* p, sart_axion
   if (rc) return rc;
   if (he != hipSuccess) return fail(SART_ERR_NO_DEVICE, std::string("sart_trace_records: ") + what + ": " + hipGetErrorString(he));
   if (e1 != hipSuccess || e2 != hipSuccess) return fail(SART_ERR_NO_DEVICE, std::string("sart_trace_records: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  return 0;
+}
+
+// ---- passed rays only ----------------------------------------------------------------------------------------------------------
+// The consumers of the record buffer (generateResultPlots raytracer.nim:2252-2283, the scan sum :2800) filter on `passed` and
+// count two flags; BabyIAXO passes 21 % of its rays, so 79 % of what sart_trace_records moves across PCIe is never read.  Here
+// the records of a chunk are traced into device scratch as before, compacted in ray order on the device (sart_kernels.hip:
+// records_count / scan / scatter), and only the passed ones travel.
+namespace {
+int compact_scratch(sart_context* c, uint64_t chunk) {
+  if (int rc = c->d_rec.resize(chunk)) return rc;
+  if (int rc = c->d_cmp_counts.resize(1024)) return rc;
+  if (int rc = c->d_cmp_first.resize(1024)) return rc;
+  return 0;
+}
+uint64_t compact_chunk_of(const sart_context* c) {
+  const uint64_t cap = static_cast<uint64_t>(compact_chunk_max());
+  return c->knobs.records_chunk > 0 ? std::min<uint64_t>(static_cast<uint64_t>(c->knobs.records_chunk), cap) : cap;
+}
+}  // namespace
+
+int sart_trace_records_passed_device(sart_context* c, const sart_trace_params_t* p, sart_axion_t* out_dev, uint64_t capacity, uint64_t* counts_dev) {
+  if (!c || !p || !counts_dev || (!out_dev && capacity)) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  SART_HIP(hipSetDevice(c->device));
+  if (!p->accumulate) SART_HIP(hipMemsetAsync(counts_dev, 0, 4 * sizeof(uint64_t), c->stream));
+  if (p->n_rays == 0) return 0;
+  const uint64_t chunk = compact_chunk_of(c);
+  if (int rc = compact_scratch(c, std::min<uint64_t>(chunk, p->n_rays))) return rc;
+  sart_trace_params_t q = *p;
+  for (uint64_t done = 0; done < p->n_rays; done += chunk) {
+    q.n_rays = std::min(chunk, p->n_rays - done);
+    q.ray_id_offset = p->ray_id_offset + done;
+    if (int rc = sart_trace_records_device(c, &q, c->d_rec.p)) return rc;
+    launch_compact_records(c->d_rec.p, static_cast<uint32_t>(q.n_rays), out_dev, capacity, c->d_cmp_counts.p, c->d_cmp_first.p,
+                           reinterpret_cast<unsigned long long*>(counts_dev), c->stream);
+    SART_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int sart_trace_records_passed(sart_context* c, const sart_trace_params_t* p, sart_axion_t* out, uint64_t capacity, sart_record_counts_t* counts) {
+  if (!c || !p || !counts || (!out && capacity)) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
+  std::memset(counts, 0, sizeof *counts);
+  if (p->n_rays == 0) return 0;
+  SART_HIP(hipSetDevice(c->device));
+  const uint64_t n = p->n_rays, chunk = compact_chunk_of(c), n_chunks = (n + chunk - 1) / chunk;
+  if (int rc = compact_scratch(c, std::min(chunk, n))) return rc;
+  for (int k = 0; k < (n_chunks > 1 ? 2 : 1); ++k)
+    if (int rc = c->d_cmp[k].resize(std::min(chunk, n))) return rc;
+  if (int rc = c->d_cmp_totals.resize(8)) return rc;
+  if (!c->h_cmp_totals) SART_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_cmp_totals), 8 * sizeof(unsigned long long), hipHostMallocDefault));
+  if (!c->copy_stream) SART_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  for (int k = 0; k < 2; ++k) {
+    if (!c->rec_traced[k]) SART_HIP(hipEventCreateWithFlags(&c->rec_traced[k], hipEventDisableTiming));
+    if (!c->rec_copied[k]) SART_HIP(hipEventCreateWithFlags(&c->rec_copied[k], hipEventDisableTiming));
+  }
+  // (pages of `out` beyond the records written keep what they held: the pre-fault rewrites every page's first byte with itself)
+  HostPrefault prefault(reinterpret_cast<char*>(out), std::min(capacity, n) * sizeof(sart_axion_t), chunk * sizeof(sart_axion_t),
+                        !c->knobs.no_host_prefault, static_cast<unsigned>(c->knobs.prefault_threads), /*keep=*/true);
+  prefault.set_lazy();
+  sart_trace_params_t q = *p;
+  int rc = 0;
+  hipError_t he = hipSuccess;   // as in sart_trace_records: no early return while work on the caller's buffer is queued
+  const char* what = "";
+  auto step = [&](hipError_t e, const char* name) {
+    if (e != hipSuccess && he == hipSuccess) { he = e; what = name; }
+    return e == hipSuccess;
+  };
+  uint64_t written = 0;
+  for (uint64_t k = 0; k <= n_chunks && rc == 0 && he == hipSuccess; ++k) {
+    if (k < n_chunks) {   // trace + compact chunk k into half-buffer k & 1 once the copy of chunk k - 2 has left it
+      const int b = static_cast<int>(k & 1);
+      if (k >= 2 && !step(hipStreamWaitEvent(c->stream, c->rec_copied[b], 0), "hipStreamWaitEvent(stream)")) break;
+      q.n_rays = std::min(chunk, n - k * chunk);
+      q.ray_id_offset = p->ray_id_offset + k * chunk;
+      unsigned long long* totals = c->d_cmp_totals.p + 4 * b;
+      if (!step(hipMemsetAsync(totals, 0, 4 * sizeof(unsigned long long), c->stream), "hipMemsetAsync(counts)")) break;
+      rc = (c->knobs.records_fail_chunk > 0 && k + 1 == static_cast<uint64_t>(c->knobs.records_fail_chunk))
+               ? fail(SART_ERR_INTERNAL, "sart_trace_records_passed: failure injected by SART_RECORDS_FAIL_CHUNK (test hook)")
+               : sart_trace_records_device(c, &q, c->d_rec.p);
+      if (rc) break;
+      launch_compact_records(c->d_rec.p, static_cast<uint32_t>(q.n_rays), c->d_cmp[b].p, q.n_rays, c->d_cmp_counts.p, c->d_cmp_first.p, totals, c->stream);
+      if (!step(hipGetLastError(), "compaction kernels")) break;
+      if (!step(hipMemcpyAsync(c->h_cmp_totals + 4 * b, totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync(counts)")) break;
+      if (!step(hipEventRecord(c->rec_traced[b], c->stream), "hipEventRecord(traced)")) break;
+    }
+    if (k > 0) {          // the passed records of chunk k - 1 cross PCIe while chunk k is traced
+      const int b = static_cast<int>((k - 1) & 1);
+      if (!step(hipEventSynchronize(c->rec_traced[b]), "hipEventSynchronize(traced)")) break;
+      const unsigned long long* t = c->h_cmp_totals + 4 * b;
+      counts->n_rays += t[0]; counts->n_passed += t[1]; counts->n_passed_till_window += t[2]; counts->n_hit_nickel += t[3];
+      const uint64_t room = capacity - written, cnt = std::min<uint64_t>(t[1], room);
+      if (cnt) {
+        prefault.allow((written + 3 * cnt) / chunk + 1);   // this copy and, at this pass rate, the next two
+        for (uint64_t j = written / chunk; j <= (written + cnt - 1) / chunk; ++j) prefault.wait(j);   // (its chunks: `chunk` records each)
+        if (!step(hipMemcpyAsync(out + written, c->d_cmp[b].p, cnt * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->copy_stream), "hipMemcpyAsync(records)")) break;
+        written += cnt;
+      }
+      if (!step(hipEventRecord(c->rec_copied[b], c->copy_stream), "hipEventRecord(copied)")) break;
+    }
+  }
+  const hipError_t e1 = hipStreamSynchronize(c->copy_stream), e2 = hipStreamSynchronize(c->stream);
+  if (rc) return rc;
+  if (he != hipSuccess) return fail(SART_ERR_NO_DEVICE, std::string("sart_trace_records_passed: ") + what + ": " + hipGetErrorString(he));
+  if (e1 != hipSuccess || e2 != hipSuccess) return fail(SART_ERR_NO_DEVICE, std::string("sart_trace_records_passed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
   return 0;
 }
 

@@ -2643,6 +2643,84 @@ __global__ __launch_bounds__(kRecBlock) void trace_records_kernel(HotA H, const 
   }
 }
 
+// ---- passed rays only (include/sart.h: sart_trace_records_passed): the records of one chunk, compacted in ray order ----------
+// What generateResultPlots (raytracer.nim:2252-2283) and the scan sum (:2800) read of the record buffer: the records with
+// `passed` set, and how many records have passedTillWindow / hitNickel set.  Three small kernels behind trace_records_kernel on
+// the same stream: flags -> per-block counts, one-block exclusive scan, cooperative copy (each wave moves the records of its
+// passed lanes as one contiguous run of 8-byte words: coalesced stores, 208-byte runs of loads).  Integer arithmetic only: the
+// order and the counts do not depend on the launch geometry.
+constexpr int kCompactBlock = 1024;                  // records per block of the three kernels
+constexpr int kCompactMaxBlocks = 1024;              // blocks one scan covers: chunks of at most 2^20 records
+__device__ __forceinline__ uint32_t record_flags(const sart_axion_t* rec, uint32_t i, uint32_t n) {
+  return i < n ? *reinterpret_cast<const uint32_t*>(rec + i) : 0u;   // passed @0, passedTillWindow @1, hitNickel @2
+}
+__global__ __launch_bounds__(kCompactBlock) void records_count_kernel(const sart_axion_t* __restrict__ rec, uint32_t n,
+                                                                       uint32_t* __restrict__ block_counts,
+                                                                       unsigned long long* __restrict__ counts) {
+  __shared__ uint32_t part[kCompactBlock / 64][3];
+  const uint32_t f = record_flags(rec, blockIdx.x * kCompactBlock + threadIdx.x, n);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t np = (uint32_t)__popcll(ballot64((f & 0xFFu) != 0u)), nw = (uint32_t)__popcll(ballot64((f & 0xFF00u) != 0u)),
+                 nn = (uint32_t)__popcll(ballot64((f & 0xFF0000u) != 0u));
+  if (lane == 0) { part[wave][0] = np; part[wave][1] = nw; part[wave][2] = nn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t a = 0, b = 0, c = 0;
+    for (int w = 0; w < kCompactBlock / 64; ++w) { a += part[w][0]; b += part[w][1]; c += part[w][2]; }
+    block_counts[blockIdx.x] = a;
+    if (b) atomicAdd(&counts[2], (unsigned long long)b);
+    if (c) atomicAdd(&counts[3], (unsigned long long)c);
+  }
+}
+// block_counts[b] -> the index of block b's first passed record in the output (counts[1] = passed records of earlier chunks);
+// counts[0] += n, counts[1] += the passed records of this chunk
+__global__ __launch_bounds__(kCompactMaxBlocks) void records_scan_kernel(uint32_t* __restrict__ block_counts, uint32_t n_blocks,
+                                                                          unsigned long long* __restrict__ block_first,
+                                                                          unsigned long long* __restrict__ counts, uint32_t n) {
+  __shared__ uint32_t wave_sum[kCompactMaxBlocks / 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t v = threadIdx.x < n_blocks ? block_counts[threadIdx.x] : 0u;
+  uint32_t incl = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+    if (lane >= d) incl += o;
+  }
+  if (lane == 63) wave_sum[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (int w = 0; w < kCompactMaxBlocks / 64; ++w) { before += w < wave ? wave_sum[w] : 0u; total += wave_sum[w]; }
+  const unsigned long long base = counts[1];
+  if (threadIdx.x < n_blocks) block_first[threadIdx.x] = base + before + (incl - v);
+  __syncthreads();   // every thread has read counts[1]
+  if (threadIdx.x == 0) { counts[0] += n; counts[1] = base + total; }
+}
+__global__ __launch_bounds__(kCompactBlock) void records_scatter_kernel(const sart_axion_t* __restrict__ rec, uint32_t n,
+                                                                         const unsigned long long* __restrict__ block_first,
+                                                                         sart_axion_t* __restrict__ out, unsigned long long capacity) {
+  __shared__ uint32_t wave_count[kCompactBlock / 64];
+  __shared__ uint8_t src_lane[kCompactBlock / 64][64];
+  const uint32_t i = blockIdx.x * kCompactBlock + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool passed = (record_flags(rec, i, n) & 0xFFu) != 0u;
+  const uint64_t m = ballot64(passed);
+  const uint32_t cnt = (uint32_t)__popcll(m);
+  const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  if (passed) src_lane[wave][prefix] = (uint8_t)lane;
+  if (lane == 0) wave_count[wave] = cnt;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int w = 0; w < wave; ++w) before += wave_count[w];
+  const unsigned long long first = block_first[blockIdx.x] + before;   // output index of this wave's first passed record
+  constexpr uint32_t kWords = sizeof(sart_axion_t) / 8;                 // 26
+  const uint64_t* src = reinterpret_cast<const uint64_t*>(rec + (blockIdx.x * kCompactBlock + wave * 64));
+  uint64_t* dst = reinterpret_cast<uint64_t*>(out);
+  for (uint32_t e = (uint32_t)lane; e < cnt * kWords; e += 64u) {
+    const uint32_t r = e / kWords, w = e - r * kWords;
+    if (first + r < capacity) dst[(first + r) * kWords + w] = src[(uint32_t)src_lane[wave][r] * kWords + w];
+  }
+}
+
 // The offsets the kernels assume for their own arguments when they re-read them from the kernel-argument segment
 // (reload_hot / reload_zones / reload_kernarg).  Not part of the C-ABI: tests/test_host_and_abi.py compares them with the
 // argument offsets in the code object's metadata, so that a compiler that lays arguments out differently fails a CPU test
@@ -2825,6 +2903,15 @@ void launch_finalize_scan(const void* in, double* out, int n_masses, const doubl
   F.counter_slots = counter_slots;
   for (int k = 0; k < n_masses; ++k) { F.q_w[k] = q_w[k]; F.q_w2[k] = q_w2[k]; }
   hipLaunchKernelGGL(finalize_scan_kernel, dim3(1), dim3(64), 0, stream, reinterpret_cast<const long long*>(in), out, F, static_cast<FixedCheck*>(check_dev));
+}
+int compact_chunk_max() { return kCompactBlock * kCompactMaxBlocks; }
+// scratch: block_counts[kCompactMaxBlocks] u32, block_first[kCompactMaxBlocks] u64; counts[4] = {n_rays, n_passed, n_passed_till_window, n_hit_nickel}
+void launch_compact_records(const sart_axion_t* rec, uint32_t n, sart_axion_t* out, unsigned long long capacity, uint32_t* block_counts,
+                            unsigned long long* block_first, unsigned long long* counts, hipStream_t stream) {
+  const uint32_t n_blocks = (n + kCompactBlock - 1) / kCompactBlock;
+  hipLaunchKernelGGL(records_count_kernel, dim3(n_blocks), dim3(kCompactBlock), 0, stream, rec, n, block_counts, counts);
+  hipLaunchKernelGGL(records_scan_kernel, dim3(1), dim3(kCompactMaxBlocks), 0, stream, block_counts, n_blocks, block_first, counts, n);
+  hipLaunchKernelGGL(records_scatter_kernel, dim3(n_blocks), dim3(kCompactBlock), 0, stream, rec, n, block_first, out, capacity);
 }
 void launch_trace_records(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, sart_axion_t* out, int n_blocks,
                           hipStream_t stream, const double* uniforms_dev) {

@@ -309,6 +309,26 @@ class RayTracer:
         _lib.check(self.lib.sart_trace_records(self.handle, C.byref(p), buf.ctypes.data_as(C.c_void_p)))
         return buf
 
+    def traceAxionWrapperPassed(self, bufLen: int, seed: int = 299792458, ray_id_offset: int = 0, flags: int | None = None,
+                                capacity: int | None = None, out: np.ndarray | None = None):
+        """The rays of traceAxionWrapper(bufLen, ...) whose ``passed`` is set, in ray order, and the counts generateResultPlots
+        echoes (raytracer.nim:2252-2257): (records, {"n_rays", "n_passed", "n_passed_till_window", "n_hit_nickel"}).  Only the
+        passed records cross PCIe (sart_trace_records_passed).  ``capacity`` = room of the buffer in records (default bufLen:
+        always enough); ``out`` = a buffer of the caller's.  len(records) = min(n_passed, capacity)."""
+        if out is None:
+            out = np.empty(bufLen if capacity is None else capacity, dtype=AXION_DTYPE)
+        assert out.dtype == AXION_DTYPE and out.flags.c_contiguous
+        capacity = len(out) if capacity is None else min(int(capacity), len(out))
+        p = self.trace_params(bufLen, seed, ray_id_offset, flags)
+        cnt = _lib.RecordCounts()
+        _lib.check(self.lib.sart_trace_records_passed(self.handle, C.byref(p), out.ctypes.data_as(C.c_void_p), capacity, C.byref(cnt)))
+        counts = {k: int(getattr(cnt, k)) for k, _ in _lib.RecordCounts._fields_}
+        return out[:min(counts["n_passed"], capacity)], counts
+
+    def trace_records_passed_device(self, params: TraceParams, out_ptr: int, capacity: int, counts_ptr: int):
+        """sart_trace_records_passed_device: device pointers (records, four uint64 counts); enqueues on the stream."""
+        _lib.check(self.lib.sart_trace_records_passed_device(self.handle, C.byref(params), C.c_void_p(out_ptr), int(capacity), C.c_void_p(counts_ptr)))
+
     def trace_records_uniforms(self, uniforms: np.ndarray, flags: int | None = None) -> np.ndarray:
         """Test entry (sart_internal_trace_records_uniforms, not part of include/sart.h): the records of the rays whose six
         uniforms are the rows of ``uniforms`` [n][6] (draw order of SURVEY App. B) instead of draws from the Philox stream."""

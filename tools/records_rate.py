@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Rate of the literal drop-in sart_trace_records (208-byte Axion records into caller memory, raytracer.nim:2223-2244, :2760):
 records per second into a FRESH pageable buffer (what a Nim `newSeq[Axion]` or numpy.empty hands over), into the same buffer
-again (pages mapped), with the host-side pre-fault switched off, and on the device alone.
+again (pages mapped), with the host-side pre-fault switched off, and on the device alone; and of sart_trace_records_passed
+(only the records with `passed` set travel): rays per second into a fresh buffer sized for all rays / for the passed ones, into
+mapped pages, and on the device alone.
 
   python tools/records_rate.py [--records 2e7] [--out gpurun_out/records_rate.json]"""
 import argparse
@@ -44,6 +46,7 @@ def main():
         res["same_buffer_again"] = {"seconds": dt, "records_per_s": n / dt, "gb_per_s": n * 208 / dt / 1e9}
         assert first == buf[:100_000].tobytes(), "the second call wrote other records"
         n_passed = int(buf["passed"].sum(dtype=np.int64))
+        first_passed = buf[:400_000].view(np.uint8).reshape(-1, 208)[buf[:400_000]["passed"] != 0][:20_000].tobytes()
         assert n_passed > 0.2 * n * 0.9, (n_passed, n)
         del buf
         # the device side alone
@@ -54,6 +57,38 @@ def main():
         L.check(rt.lib.sart_trace_records_device(rt.handle, C.byref(p), C.c_void_p(d.data_ptr())))
         ms, _ = rt.kernel_timing()
         res["device_only"] = {"seconds": ms / 1e3, "records_per_s": n / (ms / 1e3)}
+    # the passed rays only (sart_trace_records_passed): rays per second through the record interface when only the records the
+    # reference's consumers read cross PCIe; buffer sized for all rays (fresh pages), for the passed ones + 2 %, and reused
+    os.environ.pop("SART_NO_HOST_PREFAULT", None)
+    with sa.RayTracer(full) as rt:
+        rt.traceAxionWrapperPassed(200_000, seed=5)
+        for label, cap in (("passed_only_fresh_buffer_of_n", n), ("passed_only_fresh_buffer_fitted", int(n_passed * 1.02))):
+            out = got = None                  # (the buffer of the round before is unmapped here, not inside the timed call)
+            out = np.empty(cap, dtype=L.AXION_DTYPE)
+            t0 = time.perf_counter()
+            res_call = rt.traceAxionWrapperPassed(n, seed=5, out=out)
+            dt = time.perf_counter() - t0
+            got, c = res_call
+            assert c["n_passed"] == n_passed == len(got)
+            res[label] = {"seconds": dt, "rays_per_s": n / dt, "passed_records_per_s": n_passed / dt, "gb_per_s": n_passed * 208 / dt / 1e9,
+                          "passed_fraction": n_passed / n}
+        t0 = time.perf_counter()
+        got, c = rt.traceAxionWrapperPassed(n, seed=5, out=out)
+        dt = time.perf_counter() - t0
+        res["passed_only_same_buffer_again"] = {"seconds": dt, "rays_per_s": n / dt, "passed_records_per_s": n_passed / dt, "gb_per_s": n_passed * 208 / dt / 1e9}
+        assert got[:20_000].tobytes() == first_passed
+        import torch
+        d = torch.empty(int(n_passed * 1.02) * 208, dtype=torch.uint8, device="cuda:0")
+        cnt = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+        p = rt.trace_params(n, seed=5)
+        for rep in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rt.trace_records_passed_device(p, d.data_ptr(), int(n_passed * 1.02), cnt.data_ptr())
+            rt.synchronize()
+            dt = time.perf_counter() - t0
+        assert cnt.tolist()[1] == n_passed
+        res["passed_only_device_only"] = {"seconds": dt, "rays_per_s": n / dt}
     os.environ["SART_NO_HOST_PREFAULT"] = "1"
     with sa.RayTracer(full) as rt:
         buf = np.empty(n, dtype=L.AXION_DTYPE)
