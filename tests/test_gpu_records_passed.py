@@ -87,6 +87,14 @@ def test_device_entry_appends_over_launches():
         got = buf.cpu().numpy()[:counts["n_passed"] * 208].view(L.AXION_DTYPE)
         assert got.tobytes() == want.tobytes()
         assert not buf[counts["n_passed"] * 208:].any().item()
+        # a device buffer with room for half of them: the first half arrives, nothing is written behind it, the counts are whole
+        half = counts["n_passed"] // 2
+        small = torch.full(((half + 3) * 208,), 0xAB, dtype=torch.uint8, device="cuda")
+        p = rt.trace_params(n1 + n2, seed=9, ray_id_offset=11)
+        rt.trace_records_passed_device(p, small.data_ptr(), half, cnt.data_ptr())
+        rt.synchronize()
+        assert cnt.tolist()[1] == counts["n_passed"] and cnt.tolist()[0] == n1 + n2
+        assert small[:half * 208].cpu().numpy().tobytes() == want[:half].tobytes() and (small[half * 208:] == 0xAB).all().item()
 
 
 def test_failure_inside_the_pipeline_leaves_through_the_synchronised_exit():
