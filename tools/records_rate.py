@@ -63,7 +63,7 @@ def main():
     with sa.RayTracer(full) as rt:
         rt.traceAxionWrapperPassed(200_000, seed=5)
         for label, cap in (("passed_only_fresh_buffer_of_n", n), ("passed_only_fresh_buffer_fitted", int(n_passed * 1.02))):
-            out = got = None                  # (the buffer of the round before is unmapped here, not inside the timed call)
+            out = got = res_call = None       # (the buffer of the round before is unmapped here, not inside the timed call)
             out = np.empty(cap, dtype=L.AXION_DTYPE)
             t0 = time.perf_counter()
             res_call = rt.traceAxionWrapperPassed(n, seed=5, out=out)
