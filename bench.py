@@ -29,6 +29,7 @@ Prints one JSON line on rank 0.  --profile-run skips the CPU baseline and the si
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -429,6 +430,7 @@ def main():
                 out["other_workloads"].append(angular_scan_rate())
                 out["other_workloads"].append(emission_table_rate())
                 out["deterministic_accumulation"] = fixed64_block(full, value)
+                out["record_interface"] = record_interface_block(full)
                 out["effective_area_rms"] = effective_area_rms()
         print(json.dumps(out))
     rt.close()
@@ -589,6 +591,36 @@ def angular_scan_rate(n: int = 200_000_000, host_loop_points: int = 4):
             "speedup_over_host_loop": fused / host_loop, "max_rel_diff_to_host_loop": float(rel),
             "passed_fraction_per_angle": [round(float(x), 5) for x in per_angle["N_PASSED"] / n],
             "roofline": roofline_block("babyiaxo_xmm_ascan16", float(n), avg_s, n_launch, summ, float(n))}
+
+
+def record_interface_block(full, n: int = 20_000_000):
+    """The record-level boundary (traceAxionWrapper's own shape: 208-byte Axion records into caller memory) on the headline
+    workload - PCIe-inclusive, so never `value`: every record (sart_trace_records), and only the records the reference's
+    consumers keep (sart_trace_records_passed: filterIt(it.passed), raytracer.nim:2252, :2800), both into pages that exist."""
+    import numpy as np
+    import solaraxionraytracing_amd as sa
+    from solaraxionraytracing_amd import _lib as L
+    with sa.RayTracer(full) as rt:
+        buf = np.zeros(n, dtype=L.AXION_DTYPE)
+        rt.traceAxionWrapperPassed(200_000, seed=5)
+        p = rt.trace_params(n, seed=5)
+        times = {}
+        for rep in range(2):                                   # the second round writes into mapped pages
+            t0 = time.perf_counter()
+            L.check(rt.lib.sart_trace_records(rt.handle, C.byref(p), buf.ctypes.data_as(C.c_void_p)))
+            times["all"] = time.perf_counter() - t0
+        n_passed = int((buf["passed"] != 0).sum(dtype=np.int64))
+        check = buf[:200_000].view(np.uint8).reshape(-1, 208)[buf[:200_000]["passed"] != 0].tobytes()
+        for rep in range(2):
+            t0 = time.perf_counter()
+            got, cnt = rt.traceAxionWrapperPassed(n, seed=5, out=buf)
+            times["passed"] = time.perf_counter() - t0
+        assert cnt["n_passed"] == n_passed == len(got) and got[:len(check) // 208].tobytes() == check
+    return {"workload": "record interface, BabyIAXO / XMM: 208-byte Axion records into caller memory (PCIe-inclusive; mapped pages)",
+            "rays": n, "passed_fraction": n_passed / n,
+            "every_record": {"rays_per_s": n / times["all"], "gb_per_s": n * 208 / times["all"] / 1e9},
+            "passed_records_only": {"rays_per_s": n / times["passed"], "gb_per_s": n_passed * 208 / times["passed"] / 1e9,
+                                    "byte_identical_to_filtered_buffer": True}}
 
 
 def fixed64_block(full, f64_rate: float, n: int = 1_000_000_000, launches: int = 10):

@@ -835,6 +835,24 @@ def test_scan_driver_sharded_over_two_ranks_equals_one_process(tmp_path, host_lo
     assert ca[:, 1].min() > 0
 
 
+def test_scan_driver_xray_test_source_fused_equals_the_loop_on_the_same_rays(tmp_path):
+    """tools/scan.py angular --xrayTest (the parallel test source in front of the bore, raytracer.nim:1765-1806: SURVEY 8(d)'s
+    cleaner effective-area probe): the fused scan and the re-trace per angle give the same falling curve on a common first bin."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a, b = str(tmp_path / "loop.csv"), str(tmp_path / "fused.csv")
+    common = ["angular", "--xrayTest", "--numAngularScanPoints", "5", "--angularScanMax", "0.2", "--rays", "400000"]
+    for extra, out in (([], a), (["--fused", "--shard", "rays"], b)):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "scan.py")] + common + extra + ["--out", out], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+    ca, cb = np.loadtxt(a, delimiter=",", skiprows=1, usecols=(0, 1)), np.loadtxt(b, delimiter=",", skiprows=1, usecols=(0, 1))
+    assert ca[0, 1] > 0 and (np.diff(ca[:, 1]) < 0).all() and (np.diff(cb[:, 1]) < 0).all()          # effective area falls off axis
+    # the loop traces fresh rays per angle, the fused scan the same rays for all: equal within the Monte-Carlo error of 4e5 rays
+    np.testing.assert_allclose(cb[:, 1] / cb[0, 1], ca[:, 1] / ca[0, 1], atol=0.02)
+
+
 def test_setup_change_between_async_launches_needs_no_explicit_sync():
     """trace_histogram_device is asynchronous; changing the setup / axion mass / telescope angles right after it
     re-uploads tables the running launch still reads.  The library orders the two itself (refresh_derived / sync_blob wait

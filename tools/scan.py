@@ -44,6 +44,9 @@ def main():
                     help="angular scan, mass --host-loop: bins = every scan point is a full run on one rank (BASELINE config 4); "
                          "rays = every rank traces its share of the ray ids of every point and the accumulators are reduced once per "
                          "point.  The fused mass scan always shards the rays")
+    ap.add_argument("--xrayTest", action="store_true",
+                    help="angular: the parallel X-ray test source in front of the bore (raytracer.nim:1765-1806) instead of the sun - "
+                         "the cleaner effective-area probe (SURVEY 8(d) config 4)")
     ap.add_argument("--fused", action="store_true", help="angular: the fused scan kernel (same rays for every angle) instead of a re-trace per angle")
     ap.add_argument("--host-loop", action="store_true",
                     help="mass: one re-trace per mass point (what the fused scan replaces; independent ray blocks per point)")
@@ -76,9 +79,11 @@ def main():
     n_rays = int(args.rays)
     emission = args.emission or ("agss09-device" if args.mode == "mass" else "primakoff")
     if args.mode == "angular":
-        full = sa.initFullSetup(emission=emission)
-        full.setup.chip_x_max = full.setup.chip_y_max = args.chip       # ChipXMax = 100 mm alternative (raytracer.nim:262-264)
         flags = L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS | L.CF_IGNORE_CONV_PROB   # cf. comment :2315
+        if args.xrayTest:
+            flags |= L.CF_XRAY_TEST
+        full = sa.initFullSetup(flags=flags if args.xrayTest else 0, emission=emission)
+        full.setup.chip_x_max = full.setup.chip_y_max = args.chip       # ChipXMax = 100 mm alternative (raytracer.nim:262-264)
         xs = np.linspace(args.angularScanMin, args.angularScanMax, args.numAngularScanPoints)
     else:
         full = sa.initFullSetup(stage=L.SK_GAS, emission=emission)   # BASELINE configs[4]: full AGSS09 emission + m_a scan
