@@ -1568,11 +1568,11 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
     // Measured on CAST / LLNL (88 % of all rays land within ~30 pixels): 1 replica 12.4 ms per 1e8 rays, 16: 5.5, 64: 4.4,
     // 128: 4.4, 512: 4.6 (3.99 ms with the atomics switched off).
     int R = spot_px > 96.0 ? 8 : 64;
-    if (p->image_nx == 0) R = 1;      // flux-only launch: no image, so no scratch copies, no LDS tile, no pilot launch
     if (static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny) > (1u << 20)) R = std::min(R, 1);   // heat maps of millions of pixels: no scratch copies
     if (s.test_active) R = 64;
     if (c->knobs.image_replicas > 0) R = std::min(kMaxImageReplicas, c->knobs.image_replicas);
     if (c->tile.in_pilot) R = 64;     // one-pixel image
+    if (p->image_nx == 0) R = 1;      // flux-only launch: no image, so no scratch copies, no LDS tile, no pilot launch - whatever the source or the knobs say
     while (R & (R - 1)) R &= R - 1;   // power of two
     if (R > 1) {
       const size_t n_img = static_cast<size_t>(p->image_nx) * static_cast<size_t>(p->image_ny);

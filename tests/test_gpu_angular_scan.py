@@ -262,11 +262,12 @@ def test_scan_accumulation_errors_and_zero_rays():
         assert before == after
 
 
-@pytest.mark.parametrize("name", ["babyiaxo_xmm", "babyiaxo_xmm_rot", "cast_llnl", "babyiaxo_xmm_gas"])
+@pytest.mark.parametrize("name", ["babyiaxo_xmm", "babyiaxo_xmm_rot", "cast_llnl", "babyiaxo_xmm_gas", "babyiaxo_xmm_xray"])
 @pytest.mark.parametrize("mode", ["f64", "fixed64"])
 def test_flux_only_launch_equals_the_scalars_of_an_image_launch(name, mode):
     """image_nx = image_ny = 0: no image, no LDS tile, no pilot launch - and the very same scalars (every passed ray counts as
-    outside the image: N_OUTSIDE_IMAGE = N_PASSED)."""
+    outside the image: N_OUTSIDE_IMAGE = N_PASSED).  (The X-ray test source asks for 64 image replicas: a flux-only launch must
+    not follow it into a pilot launch on an image that does not exist - it did until round 5's tools/scan.py --xrayTest.)"""
     full = make_setup(name)
     n, seed = 1_500_000, 8
     with sa.RayTracer(full) as rt:
