@@ -122,6 +122,76 @@ def test_histogram_matches_oracle(name):
     assert img.sum() == pytest.approx(summ["SUM_WEIGHTS"], rel=1e-12)
 
 
+@pytest.mark.parametrize("name", ["babyiaxo_xmm", "cast_llnl", "babyiaxo_xmm_gas"])
+def test_image_and_flux_agree_with_the_reference_rng_stream_within_monte_carlo_error(name):
+    """The acceptance sentence of the north star, literally: "results match the Nim CPU reference's focal-plane image ... within
+    sqrt(N) Monte-Carlo error".  Two INDEPENDENT sets of rays: the HIP path on its Philox stream, and the oracle driven by the
+    reference's own generator (std/random's xoroshiro128+ behind randomize(299792458), raytracer.nim:276, six draws per ray in the
+    reference's order; oracle.trace_records_nim_stream).  Per pixel of a 16 x 16 image the difference of the two fluxes over
+    its Monte-Carlo error (sum of squared weights of both) is a unit normal: chi^2 ~ n_pixels +- sqrt(2 n_pixels); the total flux
+    and the three counters agree within five standard deviations.  (Every other parity test traces the SAME rays on both sides -
+    stronger ray by ray, but blind to anything the two sides would share through the common stream.)"""
+    from oracle.oracle import Oracle
+    full = make_setup(name)
+    n = 400_000
+    with sa.RayTracer(full) as rt:
+        g = rt.traceAxionWrapper(n, seed=20261005)
+    o = Oracle(full).trace_records_nim_stream(n, init_variant=1)
+    chip = full.setup.chip_x_max
+
+    def binned(rec):
+        p = rec[rec["passed"] != 0]
+        ix = np.clip((p["pointdataX"] / chip * 16).astype(int), 0, 15)
+        iy = np.clip((p["pointdataY"] / chip * 16).astype(int), 0, 15)
+        w, w2, cnt = np.zeros((16, 16)), np.zeros((16, 16)), np.zeros((16, 16))
+        np.add.at(w, (iy, ix), p["weights"]); np.add.at(w2, (iy, ix), p["weights"] ** 2); np.add.at(cnt, (iy, ix), 1.0)
+        return w, w2, cnt, p
+
+    gw, gw2, gc, gp = binned(g)
+    ow, ow2, oc, op = binned(o)
+    lit = (gc >= 30) & (oc >= 30)
+    assert lit.sum() >= 16, "too few populated pixels to test anything"
+    chi2 = ((gw - ow)[lit] ** 2 / (gw2 + ow2)[lit]).sum()
+    k = int(lit.sum())
+    assert chi2 < k + 5.0 * np.sqrt(2.0 * k), (chi2, k)
+    assert chi2 > k - 5.0 * np.sqrt(2.0 * k), (chi2, k)     # (not suspiciously equal either: the rays ARE independent)
+    z = (gp["weights"].sum() - op["weights"].sum()) / np.sqrt((gp["weights"] ** 2).sum() + (op["weights"] ** 2).sum())
+    assert abs(z) < 5.0, z
+    for f in ("passed", "passedTillWindow", "hitNickel"):
+        pg, po = (g[f] != 0).mean(), (o[f] != 0).mean()
+        assert abs(pg - po) < 5.0 * np.sqrt((pg * (1 - pg) + po * (1 - po)) / n) + 1e-12, (f, pg, po)
+
+
+def test_effective_area_curve_agrees_with_the_reference_rng_stream_within_monte_carlo_error():
+    """... and its effective-area curve: the fused angular scan on the Philox stream against one oracle run per angle on the
+    reference's generator (performAngularScan's shape, raytracer.nim:2791-2800: fresh draws for every angle), chip 100 mm and the
+    effective-area flags.  Per angle the two fluxes differ by less than five Monte-Carlo errors, and so do
+    the max-normalised curves."""
+    from oracle.oracle import Oracle
+    full = make_setup("babyiaxo_xmm")
+    full.setup.chip_x_max = full.setup.chip_y_max = 100.0
+    flags = L.CF_IGNORE_DET_WINDOW | L.CF_IGNORE_GAS_ABS | L.CF_IGNORE_CONV_PROB
+    angles = np.array([0.0, 0.1, 0.2, 0.3])
+    n = 300_000
+    with sa.RayTracer(full) as rt:
+        per, shared = rt.trace_angular_scan(angles, n, seed=77, flags=flags)
+    o = Oracle(full)
+    of, of2 = np.zeros(len(angles)), np.zeros(len(angles))
+    for i, a in enumerate(angles):
+        s = full.setup.copy()
+        s.telescope_turned_y_deg = float(a)
+        rec = o.trace_records_nim_stream(n, ray_id_offset=i * n, flags=flags, init_variant=1, setup=s)   # the stream goes on from angle to angle
+        w = rec["weights"][rec["passed"] != 0]
+        of[i], of2[i] = w.sum(), (w ** 2).sum()
+    gf, gf2 = per["SUM_WEIGHTS"], per["SUM_WEIGHTS_SQ"]
+    z = (gf - of) / np.sqrt(gf2 + of2)
+    assert np.all(np.abs(z) < 5.0), z
+    assert gf[0] > gf[1] > gf[2] > gf[3] > 0.3 * gf[0]
+    rel_g, rel_o = gf / gf.max(), of / of.max()
+    err = np.sqrt(gf2 + of2) / gf.max() * 2.0       # (both normalisations carry an error of their own)
+    assert np.all(np.abs(rel_g - rel_o) < 5.0 * err + 1e-12), (rel_g, rel_o)
+
+
 def test_flags_change_weights_like_the_reference():
     from oracle.oracle import Oracle
     full = make_setup("babyiaxo_xmm")
