@@ -309,7 +309,8 @@ proc traceAxionsPassedGpu*(ctx: ptr SartContext, bufLen: int, flags: set[ConfigF
   let cap = if capacity > 0: capacity else: bufLen
   result = newSeq[Axion](cap)
   var p = sartParams(bufLen, flags, seed, rayIdOffset)
-  sartCheck sart_trace_records_passed(ctx, addr p, (if cap > 0: addr result[0] else: nil), cap.uint64, addr counts)
+  let buf: pointer = if cap > 0: cast[pointer](addr result[0]) else: nil
+  sartCheck sart_trace_records_passed(ctx, addr p, buf, cap.uint64, addr counts)
   result.setLen(min(counts.n_passed.int, cap))
 
 proc traceHistogramGpu*(ctx: ptr SartContext, nRays: int, flags: set[ConfigFlags], image: var seq[cdouble],
