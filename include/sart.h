@@ -288,7 +288,11 @@ int sart_set_stream(sart_context* ctx, void* hip_stream);
 int sart_synchronize(sart_context* ctx);
 
 /* ---- inputs (the captures of traceAxionWrapper, raytracer.nim:2223-2232) -- */
-/* expSetup + detectorSetup + centerVecs. The library copies; caller keeps ownership. */
+/* expSetup + detectorSetup + centerVecs. The library copies; caller keeps ownership.
+ * SART_ERR_UNSUPPORTED: a telescope / reflectivity kind the reference asserts on (:1233, :1347).  SART_ERR_INVALID_ARGUMENT (the
+ * message names the field): n_shells outside [9, 64], shell radii not ascending or glass thicker than the spacing, an enum out
+ * of range, number_of_holes outside [0, 64], impossible magnet geometry, or any double of the struct (shell arrays: the first
+ * n_shells entries) that is NaN or infinite - such a setup would trace to zero flux without a word. */
 int sart_set_setup(sart_context* ctx, const sart_setup_t* setup);
 int sart_get_setup(sart_context* ctx, sart_setup_t* out);
 /* Cheap updates used by the scan drivers (performAngularScan :2796; m_a scan). */

@@ -1022,6 +1022,36 @@ int sart_set_setup(sart_context* c, const sart_setup_t* s) {
   if (!(s->magnet_radiusCB > 0) || !(s->magnet_lengthB > 0) || !(s->magnet_lengthColdbore >= s->magnet_lengthB))
     return fail(SART_ERR_INVALID_ARGUMENT, "magnet geometry");
   if (s->number_of_strips < 0 || s->number_of_strips > 2 * kMaxStrips) return fail(SART_ERR_INVALID_ARGUMENT, "number_of_strips");
+  // (the hole loop of lineIntersectsOpaqueTelescopeStructures runs number_of_holes times per ray on the device: a count from
+  // uninitialised memory must not become a kernel that never ends; the reference builds 1 and 5, :1256-1346)
+  if (s->hole_type < SART_HT_NONE || s->hole_type > SART_HT_DIAMOND) return fail(SART_ERR_INVALID_ARGUMENT, "hole_type");
+  if (s->number_of_holes < 0 || s->number_of_holes > 64) return fail(SART_ERR_INVALID_ARGUMENT, "number_of_holes must be in [0, 64]");
+  {
+    // a NaN or an infinity in the geometry gives rays that fail every comparison: zero flux and no error.  Refused here by name.
+    struct Field { const char* name; const double* p; int n; };
+    const Field fields[] = {
+        {"magnet_B", &s->magnet_B, 1}, {"magnet_lengthB", &s->magnet_lengthB, 1}, {"magnet_lengthColdbore", &s->magnet_lengthColdbore, 1},
+        {"magnet_radiusCB", &s->magnet_radiusCB, 1}, {"magnet_pGasRoom", &s->magnet_pGasRoom, 1}, {"magnet_tGas", &s->magnet_tGas, 1},
+        {"pipe_cb_vt3_length", &s->pipe_cb_vt3_length, 1}, {"pipe_cb_vt3_radius", &s->pipe_cb_vt3_radius, 1},
+        {"pipe_vt3_xrt_length", &s->pipe_vt3_xrt_length, 1}, {"pipe_vt3_xrt_radius", &s->pipe_vt3_xrt_radius, 1},
+        {"pipes_turned_deg", &s->pipes_turned_deg, 1}, {"distance_cb_axis_xrt_axis", &s->distance_cb_axis_xrt_axis, 1},
+        {"optics_entrance", s->optics_entrance, 3}, {"optics_exit", s->optics_exit, 3},
+        {"telescope_turned_x_deg", &s->telescope_turned_x_deg, 1}, {"telescope_turned_y_deg", &s->telescope_turned_y_deg, 1},
+        {"all_r1", s->all_r1, s->n_shells}, {"all_thickness", s->all_thickness, s->n_shells}, {"all_xsep", s->all_xsep, s->n_shells},
+        {"all_angles_deg", s->all_angles_deg, s->n_shells}, {"l_mirror", &s->l_mirror, 1}, {"hole_in_optics", &s->hole_in_optics, 1},
+        {"distance_detector_xrt", &s->distance_detector_xrt, 1}, {"distance_window_focal_plane", &s->distance_window_focal_plane, 1},
+        {"lateral_shift", &s->lateral_shift, 1}, {"transversal_shift", &s->transversal_shift, 1}, {"radius_window", &s->radius_window, 1},
+        {"open_aperture_ratio", &s->open_aperture_ratio, 1}, {"strip_dist_window", &s->strip_dist_window, 1},
+        {"strip_width_window", &s->strip_width_window, 1}, {"theta_rad", &s->theta_rad, 1}, {"depth_det", &s->depth_det, 1},
+        {"test_energy", &s->test_energy, 1}, {"test_distance", &s->test_distance, 1}, {"test_radius", &s->test_radius, 1},
+        {"test_off_axis_up", &s->test_off_axis_up, 1}, {"test_off_axis_left", &s->test_off_axis_left, 1},
+        {"test_activity", &s->test_activity, 1}, {"test_length_col", &s->test_length_col, 1},
+        {"distance_sun_earth", &s->distance_sun_earth, 1}, {"radius_sun", &s->radius_sun, 1}, {"room_temp", &s->room_temp, 1},
+        {"m_axion", &s->m_axion, 1}, {"g_agamma", &s->g_agamma, 1}, {"chip_x_max", &s->chip_x_max, 1}, {"chip_y_max", &s->chip_y_max, 1}};
+    for (const Field& f : fields)
+      for (int i = 0; i < f.n; ++i)
+        if (!std::isfinite(f.p[i])) return fail(SART_ERR_INVALID_ARGUMENT, std::string("setup field is not finite: ") + f.name);
+  }
   c->setup = *s;
   c->have_setup = true;
   c->derived_dirty = true;
@@ -1038,6 +1068,7 @@ int sart_get_setup(sart_context* c, sart_setup_t* out) {
 int sart_set_telescope_angles(sart_context* c, double tx, double ty) {
   if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (!c->have_setup) return fail(SART_ERR_NOT_READY, "no setup");
+  if (std::isinf(tx) || std::isinf(ty)) return fail(SART_ERR_INVALID_ARGUMENT, "telescope angle is infinite (NaN = keep)");
   if (!std::isnan(tx)) c->setup.telescope_turned_x_deg = tx;
   if (!std::isnan(ty)) c->setup.telescope_turned_y_deg = ty;
   if (c->derived_dirty) return 0;
@@ -1051,6 +1082,7 @@ int sart_set_telescope_angles(sart_context* c, double tx, double ty) {
 int sart_set_axion_mass(sart_context* c, double m) {
   if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
   if (!c->have_setup) return fail(SART_ERR_NOT_READY, "no setup");
+  if (!std::isfinite(m)) return fail(SART_ERR_INVALID_ARGUMENT, "axion mass is not finite");
   c->setup.m_axion = m;
   // (FIXED64, gas stage: the weight bound follows the mass - gas_prob_bound - and with it the quanta of the next launch that
   // STARTS an accumulator, accumulate == 0.  Frozen quanta are not released here: an accumulate == 1 launch adds into integers

@@ -265,6 +265,23 @@ def test_errors_are_reported_not_crashed():
         s = sa.newFullSetup(L.ES_BABYIAXO, L.DK_INGRIDIAXO, L.SK_VACUUM, L.TK_XMM)
         s.telescope_kind = L.TK_CUSTOM_BABYIAXO
         assert lib.sart_set_setup(h, C.byref(s)) == -4                                         # UNSUPPORTED (doAssert :1233)
+        s = sa.newFullSetup(L.ES_BABYIAXO, L.DK_INGRIDIAXO, L.SK_VACUUM, L.TK_XMM)
+        s.number_of_holes = 1 << 30                                                            # would be a 2^30-pass loop per ray
+        assert lib.sart_set_setup(h, C.byref(s)) == -1 and b"number_of_holes" in lib.sart_last_error()
+        s.number_of_holes, s.hole_type = 1, 17
+        assert lib.sart_set_setup(h, C.byref(s)) == -1 and b"hole_type" in lib.sart_last_error()
+        for field, j in (("pipe_vt3_xrt_radius", None), ("all_angles_deg", 40), ("optics_entrance", 2), ("chip_y_max", None)):
+            s = sa.newFullSetup(L.ES_BABYIAXO, L.DK_INGRIDIAXO, L.SK_VACUUM, L.TK_XMM)
+            if j is None:
+                setattr(s, field, float("nan"))
+            else:
+                getattr(s, field)[j] = float("inf")
+            assert lib.sart_set_setup(h, C.byref(s)) == -1 and field.encode() in lib.sart_last_error(), field
+        s = sa.newFullSetup(L.ES_BABYIAXO, L.DK_INGRIDIAXO, L.SK_VACUUM, L.TK_XMM)
+        s.all_r1[60] = float("nan")                                                            # behind n_shells = 58: not looked at
+        assert lib.sart_set_setup(h, C.byref(s)) == 0
+        assert lib.sart_set_axion_mass(h, float("nan")) == -1 and lib.sart_set_telescope_angles(h, float("inf"), 0.0) == -1
+        assert lib.sart_set_telescope_angles(h, float("nan"), 0.01) == 0
         bad = np.array([0.1, 0.5, 0.9])
         assert lib.sart_set_solar_tables(h, L.as_dp(bad), L.as_dp(np.ones((3, 4))), L.as_dp(np.ones(4)), 3, 4) == -1
         assert b"1.0" in lib.sart_last_error()
