@@ -61,3 +61,49 @@ def test_every_door_counts_the_same_rays(name, mode):
             # (the scan keeps the setup's x angle: its first angle is the setup itself)
             assert per["N_PASSED"][0] == want["N_PASSED"] and per["N_HIT_NICKEL"][0] == want["N_HIT_NICKEL"]
             assert per["SUM_WEIGHTS"][0] == pytest.approx(flux, rel=1e-9)
+
+
+def test_contexts_in_concurrent_threads_are_independent():
+    """include/sart.h: a context is not thread-safe, distinct contexts are independent.  Six host threads (ctypes releases the GIL
+    inside a call), each with a context of its own on a different setup, trace through several doors at the same time - every
+    result is what the same thread's work gives when it runs alone."""
+    import threading
+    names = ["babyiaxo_xmm", "cast_llnl", "babyiaxo_xmm_gas", "cast_abrixas", "babyiaxo_xmm_rot", "babyiaxo_xmm_xray"]
+
+    def work(name, mode):
+        full = make_setup(name)
+        out = []
+        with sa.RayTracer(full) as rt:
+            rt.set_accumulation_mode(mode)
+            for k in range(3):
+                img, s = rt.trace_histogram(400_000 + 1000 * k, seed=4 + k, ray_id_offset=77 * k)
+                out.append((img.tobytes() if mode == "fixed64" else None, {c: s[c] for c in ("N_RAYS", "N_PASSED", "N_HIT_NICKEL", "N_SHELL_SELECTED")},
+                            s["SUM_WEIGHTS"]))
+                rec, cnt = rt.traceAxionWrapperPassed(150_000, seed=9 + k)
+                out.append((rec.tobytes(), cnt))
+                if full.setup.stage == L.SK_GAS:
+                    per, sh = rt.trace_mass_scan([0.001, 0.01], 200_000, seed=k)
+                else:
+                    per, sh = rt.trace_angular_scan([0.0, 0.02], 200_000, seed=k)
+                out.append((per["N_PASSED"].tolist(), sh["N_RAYS"]))
+        return out
+
+    alone = {n: work(n, "fixed64") for n in names}
+    together, errors = {}, []
+
+    def run(n):
+        try:
+            together[n] = work(n, "fixed64")
+        except Exception as e:   # noqa: BLE001
+            errors.append((n, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(n,)) for n in names]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for n in names:
+        assert len(together[n]) == len(alone[n])
+        for a, b in zip(together[n], alone[n]):
+            assert a == b, n
