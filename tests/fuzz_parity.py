@@ -88,9 +88,11 @@ def build_case(case, sa, L, small):
     return full, flags, gas, xray, label, int(rng.integers(0, 1 << 40)), int(rng.integers(1, 1 << 31))
 
 
-def run_case(case, n, sa, L, Oracle, compare_records):
+def run_case(case, n, sa, L, Oracle, compare_records, full_size=False):
     from tests.conftest import SMALL
-    full, flags, gas, xray, label, off, seed = build_case(case, sa, L, SMALL)
+    # full_size: the tables of BASELINE's configurations (1968 x 1500 emission CDFs, 1000 x 1000 reflectivity grid) instead of the
+    # shrunken ones - the guide tables, the shell look-up table and the hoisted per-energy tables at the sizes the bench runs on
+    full, flags, gas, xray, label, off, seed = build_case(case, sa, L, {} if full_size else SMALL)
     ref = Oracle(full, "q").trace_records(n, seed=seed, ray_id_offset=off, flags=flags)
     g = {"rec_" + k: ref[k] for k in ref.dtype.names}
     want = {k: int((ref[f] != 0).sum()) for k, f in (("N_PASSED", "passed"), ("N_PASSED_TILL_WINDOW", "passedTillWindow"), ("N_HIT_NICKEL", "hitNickel"))}
@@ -163,6 +165,7 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--rays", type=int, default=30_000)
+    ap.add_argument("--full-size", action="store_true", help="full-size tables (1968 x 1500, 1000 x 1000) instead of the shrunken ones")
     ap.add_argument("--out", default="gpurun_out/fuzz_parity.txt")
     args = ap.parse_args()
     import solaraxionraytracing_amd as sa
@@ -176,10 +179,11 @@ def main():
             print(line, flush=True)
             out.write(line + "\n")
             out.flush()
-        emit("# tests/fuzz_parity.py: cases %d .. %d, %d rays each, build %s" % (args.first, args.first + args.cases - 1, args.rays, L.build_id()))
+        emit("# tests/fuzz_parity.py: cases %d .. %d, %d rays each, %s tables, build %s" % (args.first, args.first + args.cases - 1, args.rays,
+                                                                                            "full-size" if args.full_size else "shrunken", L.build_id()))
         for case in range(args.first, args.first + args.cases):
             try:
-                label, frac = run_case(case, args.rays, sa, L, Oracle, compare_records)
+                label, frac = run_case(case, args.rays, sa, L, Oracle, compare_records, args.full_size)
                 emit("case %4d ok    %-38s passed %.3f" % (case, label, frac))
             except Exception as e:   # noqa: BLE001 - the campaign goes on
                 failed.append(case)
