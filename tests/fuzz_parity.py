@@ -151,7 +151,25 @@ def run_case(case, n, sa, L, Oracle, compare_records, full_size=False):
                 assert per["N_PASSED"][0] == want["N_PASSED"] and per["N_HIT_NICKEL"][0] == want["N_HIT_NICKEL"] and shared["N_RAYS"] == n, (mode, "angular scan")
                 if flux > 0:
                     assert abs(per["SUM_WEIGHTS"][0] / flux - 1.0) < 1e-7, (mode, "angular scan")
-        rt.set_accumulation_mode("f64")
+        rt.set_accumulation_mode("f64")      # (the integer mode rounds every weight to its quantum: not a pixel-for-pixel comparison)
+        # a random image window and binning (prepareHeatmap with any nx x ny over any rectangle, :818-842): the histogram of the
+        # library against the same arithmetic on its own records - floor((x - x_min) * (1 / ((x_max - x_min) / nx))) - pixel for
+        # pixel in counts, and the passed rays that fall outside the window counted as such
+        irng = np.random.default_rng(90_000 + case)
+        chip = full.setup.chip_x_max
+        nx, ny = int(irng.integers(1, 400)), int(irng.integers(1, 400))
+        x0, y0 = irng.uniform(-0.2, 0.6) * chip, irng.uniform(-0.2, 0.6) * chip
+        x1, y1 = x0 + irng.uniform(0.05, 1.0) * chip, y0 + irng.uniform(0.05, 1.0) * chip
+        img, si = rt.trace_image(n, nx, ny, x_range=(x0, x1), y_range=(y0, y1), seed=seed, ray_id_offset=off, flags=flags)
+        pr = rec[rec["passed"] != 0]
+        fx = (pr["pointdataX"] - x0) * (1.0 / ((x1 - x0) / nx))
+        fy = (pr["pointdataY"] - y0) * (1.0 / ((y1 - y0) / ny))
+        inside = (fx >= 0.0) & (fx < nx) & (fy >= 0.0) & (fy < ny)
+        want_img = np.zeros((ny, nx))
+        np.add.at(want_img, (fy[inside].astype(int), fx[inside].astype(int)), pr["weights"][inside])
+        assert si["N_OUTSIDE_IMAGE"] == int((~inside).sum()), ("image window", si["N_OUTSIDE_IMAGE"], int((~inside).sum()))
+        assert np.array_equal(img != 0, want_img != 0), "image window: lit pixels"
+        np.testing.assert_allclose(img, want_img, rtol=1e-11, atol=0, err_msg="image window")
         if not gas:   # the scan's second angle against the records of a context turned to it
             s2 = full.setup.copy()
             s2.telescope_turned_y_deg = full.setup.telescope_turned_y_deg + 0.02
