@@ -50,6 +50,8 @@ BYTES_KILLED, BYTES_MIRROR, BYTES_DETECTOR = 184.0, 184.0 + 64.0, 456.0
 WORKLOADS = {
     "babyiaxo_xmm": "BabyIAXO magnet + XMM-Newton 58 shells, vacuum, InGridIAXO, 256x256 focal-plane image (BASELINE configs[2])",
     "cast_llnl_gold": "CAST magnet + LLNL 14 shells, gold_0.25microns reflectivities (BASELINE configs[1])",
+    "cast_llnl": "CAST magnet + LLNL 14 shells, the reference's own pairing: four multilayer coatings by shell group "
+                 "(raytracer.nim:1164-1187, computeReflectivity :1571-1580), InGrid2018",
     "babyiaxo_xmm_gas": "BabyIAXO magnet + XMM-Newton shells, gas stage (the m_a-scan kernel variant of BASELINE configs[4])",
     "babyiaxo_xmm_rot": "BabyIAXO magnet + XMM-Newton shells, telescope turned 0.1 deg, effective-area flags, chip 100 mm "
                         "(one angle bin of BASELINE configs[3])",
@@ -81,6 +83,9 @@ def parse():
                     help="fixed64: bits of headroom (0 = the library's default, 27: one accumulator then lasts ~1e12 BabyIAXO rays; "
                          "31 carries 2.6e12, profiles/r04_v48_fixed64_long_run.txt)")
     ap.add_argument("--profile-run", action="store_true", help="no CPU baseline / side workloads (run under rocprofv3)")
+    ap.add_argument("--emit-bitwise-constants", metavar="PATH", default=None,
+                    help="one GPU: write the FIXED64 reference image's SHA-256, integer flux and the hash of the input tables to PATH "
+                         "(the committed copy is tests/golden/bench_bitwise_fixed64.json; a --gpus N run holds its reduced image to it)")
     ap.add_argument("--preflight", action="store_true",
                     help="first contact with a multi-GPU node: only bring the process group up (RCCL), reduce one 512 KB buffer "
                          "once and print {world_size, backend, reduce_ms}; no tables, no rays")
@@ -99,6 +104,8 @@ def make_setup(workload: str):
         full = sa.initFullSetup(n_radii=400, n_energies=300, refl_n_angles=200, refl_n_energies=200)
     elif workload == "cast_llnl_gold":
         full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
+    elif workload == "cast_llnl":
+        full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL)
     elif workload == "babyiaxo_xmm_gas":
         full = sa.initFullSetup(stage=L.SK_GAS)
     elif workload == "babyiaxo_xmm_gas_scan32":
@@ -221,6 +228,134 @@ def check_image(host, n_img: int, summ: dict):
         assert 0.0 < img_sum <= summ["SUM_WEIGHTS"] * (1.0 + 1e-9), (img_sum, summ["SUM_WEIGHTS"])
     assert summ["N_PASSED"] > 0 and img_sum > 0.0
     return img_sum
+
+
+BITWISE_RAYS = 200_000_000     # the id range [0, 2e8) of the bitwise proof (seed 299792458): 2.3 ms of kernel time on one GPU
+BITWISE_CONSTANTS = os.path.join(ROOT, "tests", "golden", "bench_bitwise_fixed64.json")
+
+
+def tables_sha256(full) -> str:
+    """Identity of everything the image is a function of on the input side: the flattened setup and every table handed to the
+    library.  (The synthetic tables come out of numpy / libm on the host: a host whose libm rounds one entry differently makes
+    other inputs - then the committed constants do not apply, and the line says so instead of reporting a mismatch.)"""
+    import hashlib
+    import numpy as np
+    h = hashlib.sha256()
+    h.update(bytes(full.setup))
+    for a in (full.energies, full.fluxRadiusCDF, full.diffFluxCDFs, full.reflectivity.data, full.detector_tables.x_kev,
+              full.detector_tables.strongback, full.detector_tables.window, full.detector_tables.gas_x_kev,
+              full.detector_tables.gas_absorption):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def bitwise_proof(rt, full, flags, rank: int, world: int, dev, seed: int, D, restore=("f64", 0)):
+    """The multi-GPU leg proving its RESULT: rays are independent (raytracer.nim:2234) and in
+    SART_ACCUM_FIXED64 every sum is an integer, so the image of a fixed ray-id range must not depend on how many ranks traced
+    it - to the last bit.  Every rank traces its share of the ids [0, BITWISE_RAYS) (distributed.shard_range: the strong
+    sharding), ONE int64 reduce to rank 0, then rank 0
+      (a) traces the whole range alone on its own GPU and compares the two raw accumulators slot for slot
+          -> multi_rank_bitwise_equal_to_single_gpu (world 1: the range as three launches against one launch);
+      (b) finalizes, hashes the image and compares SHA-256 + the flux's bit pattern + N_PASSED with the constants committed
+          from a one-GPU run (tests/golden/bench_bitwise_fixed64.json) -> matches_committed_constants (null when this
+          host built other input tables than the host the constants come from).
+    Outside the timed region.  Returns the block (rank 0) or None."""
+    import hashlib
+    import numpy as np
+    import torch
+    import solaraxionraytracing_amd as sa
+    from solaraxionraytracing_amd import _lib as L
+    rt.set_accumulation_mode("fixed64")
+    try:
+        n_acc = sa.accumulator_len(256)
+        acc = torch.zeros(n_acc, dtype=torch.float64, device=dev)
+        lo, hi = D.shard_range(BITWISE_RAYS, rank, world)
+        if world == 1:
+            cuts = (0, 1, BITWISE_RAYS // 3, BITWISE_RAYS)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                rt.trace_histogram_device(rt.trace_params(b - a, seed=seed, ray_id_offset=a, accumulate=True, flags=flags), acc.data_ptr())
+        else:
+            rt.trace_histogram_device(rt.trace_params(hi - lo, seed=seed, ray_id_offset=lo, accumulate=True, flags=flags), acc.data_ptr())
+        D.reduce_accumulator(acc, dst=0, fixed64=True)
+        if rank != 0:
+            return None
+        alone = torch.zeros(n_acc, dtype=torch.float64, device=dev)
+        rt.trace_histogram_device(rt.trace_params(BITWISE_RAYS, seed=seed, accumulate=True, flags=flags), alone.data_ptr())
+        torch.cuda.synchronize(dev)
+        n_diff = int((acc.view(torch.int64) != alone.view(torch.int64)).sum().item())
+        rt.finalize_accumulator_device(rt.trace_params(1), acc.data_ptr())
+        rt.synchronize()
+        host = acc.cpu().numpy()
+    finally:
+        rt.set_accumulation_mode(*restore)
+    n_img = 256 * 256
+    summ = {k: float(host[n_img + i]) for k, i in L.ACC.items()}
+    blk = {"rays": BITWISE_RAYS, "seed": seed, "ranks": world, "slots_that_differ": n_diff, "equal": n_diff == 0,
+           "image_sha256": hashlib.sha256(host[:n_img].tobytes()).hexdigest(), "sum_weights_hex": float(summ["SUM_WEIGHTS"]).hex(),
+           "sum_weights": summ["SUM_WEIGHTS"], "n_passed": int(summ["N_PASSED"]), "n_rays": int(summ["N_RAYS"]),
+           "tables_sha256": tables_sha256(full), "matches_committed_constants": None, "committed": None}
+    assert blk["n_rays"] == BITWISE_RAYS, blk
+    try:
+        with open(BITWISE_CONSTANTS) as f:
+            want = json.load(f)
+    except Exception:
+        want = None
+    if want is not None:
+        if want.get("tables_sha256") != blk["tables_sha256"]:
+            blk["committed"] = "not applicable: this host built other input tables (tables_sha256) than the host the constants come from"
+        else:
+            blk["committed"] = os.path.relpath(BITWISE_CONSTANTS, ROOT)
+            blk["matches_committed_constants"] = all(want[k] == blk[k] for k in ("image_sha256", "sum_weights_hex", "n_passed", "rays", "seed"))
+    return blk
+
+
+def flat_scalars(out: dict) -> dict:
+    """BASELINE's whole metric as top-level scalars (the driver's parsed record keeps scalars and dicts of scalars; the lists
+    and nested blocks of this line do not survive it): the second metric - the effective-area curve's RMS against the CPU
+    reference, raytracer.nim:2799-2802 - and the rate of every other configuration of BASELINE.json."""
+    flat = {}
+    ea = out.get("effective_area_rms")
+    if ea:
+        flat["effective_area_rms_value"] = ea["value"]
+        flat["effective_area_rms_fused_value"] = ea["fused_scan_value"]
+    for w in out.get("other_workloads", []):
+        name = w["workload"]
+        if name == WORKLOADS["cast_llnl_gold"]:
+            flat["cast_llnl_gold_rays_per_s"] = w["rays_per_s"]
+        elif name == WORKLOADS["cast_llnl"]:
+            flat["cast_llnl_4coatings_rays_per_s"] = w["rays_per_s"]
+        elif name == WORKLOADS["babyiaxo_xmm_gas"]:
+            flat["gas_rays_per_s"] = w["rays_per_s"]
+        elif name == WORKLOADS["babyiaxo_xmm_rot"]:
+            flat["rot_rays_per_s"] = w["rays_per_s"]
+        elif name == WORKLOADS["babyiaxo_xmm_gas_scan32"]:
+            flat["scan32_ray_mass_per_s"] = w["ray_mass_evaluations_per_s"]
+            flat["scan32_speedup_over_host_loop"] = w["speedup_over_host_loop"]
+        elif name == WORKLOADS["babyiaxo_xmm_ascan16"]:
+            flat["ascan16_ray_angle_per_s"] = w["ray_angle_evaluations_per_s"]
+            flat["ascan16_speedup_over_host_loop"] = w["speedup_over_host_loop"]
+        elif "cells_per_s" in w:
+            flat["emission_table_cells_per_s"] = w["cells_per_s"]
+    rec = out.get("record_interface")
+    if rec:
+        flat["records_every_rays_per_s"] = rec["every_record"]["rays_per_s"]
+        flat["records_passed_rays_per_s"] = rec["passed_records_only"]["rays_per_s"]
+    det = out.get("deterministic_accumulation")
+    if det:
+        flat["fixed64_vs_f64_rate"] = det["vs_f64_rate"]
+        flat["fixed64_bitwise_equal_across_launch_split_and_replicas"] = det["bitwise_equal_across_launch_split_and_replicas"]
+    cpu = out.get("cpu_baseline")
+    if cpu:
+        flat["cpu_rays_per_s"] = cpu["value"]
+        flat["cpu_cores"] = cpu["cores"]
+        flat["cpu_1t_rays_per_s"] = cpu.get("single_thread_rays_per_s")
+        flat["gpu_over_cpu"] = out["value"] / cpu["value"]
+    bw = out.get("bitwise_proof")
+    if bw:
+        flat["multi_rank_bitwise_equal_to_single_gpu"] = bw["equal"] if out["n_gpus"] > 1 else None
+        flat["fixed64_launch_split_bitwise_equal"] = bw["equal"] if out["n_gpus"] == 1 else None
+        flat["fixed64_image_matches_committed_constants"] = bw["matches_committed_constants"]
+    return flat
 
 
 def main():
@@ -350,6 +485,11 @@ def main():
     reduce_ms = (t1 - t_red) * 1e3
     kernel_ms, n_launch = rt.kernel_timing()
     rt.enable_kernel_timing(False)
+    # the result, not only the rate: a fixed id range traced by all ranks in FIXED64 against rank 0 alone (every rank takes part)
+    proof = None
+    if scan_masses is None and scan_angles is None and full.fluxRadiusCDF is not None:
+        proof = bitwise_proof(rt, full, flags, rank, world, dev, seed, D, restore=(args.accumulation, args.headroom))
+    proof_failed = False
 
     if rank == 0:
         host = acc.cpu().numpy()
@@ -420,6 +560,15 @@ def main():
                         "reached_telescope_fraction": summ["N_REACHED_TELESCOPE"] / total_rays,
                         "shell_selected_fraction": summ["N_SHELL_SELECTED"] / total_rays},
         }
+        if proof is not None:
+            out["bitwise_proof"] = proof
+            proof_failed = not proof["equal"] or proof["matches_committed_constants"] is False
+            if args.emit_bitwise_constants and world == 1:
+                with open(args.emit_bitwise_constants, "w") as f:
+                    json.dump({k: proof[k] for k in ("rays", "seed", "image_sha256", "sum_weights_hex", "sum_weights", "n_passed",
+                                                     "tables_sha256")} | {"workload": wl_name, "build_id": L.build_id(),
+                               "made_by": "python bench.py --emit-bitwise-constants PATH (one MI355X)"}, f, indent=1)
+                    f.write("\n")
         if scan_block is not None:
             out["mass_scan"] = scan_block
         if ascan_block is not None:
@@ -434,19 +583,25 @@ def main():
             out["energy"] = en
             out["cpu_baseline"] = cpu_baseline(full, int(args.cpu_sample), seed)
             if args.workload == "babyiaxo_xmm":
-                out["other_workloads"] = [other_workload_rate(w) for w in ("cast_llnl_gold", "babyiaxo_xmm_gas", "babyiaxo_xmm_rot")]
+                out["other_workloads"] = [other_workload_rate(w) for w in ("cast_llnl_gold", "cast_llnl", "babyiaxo_xmm_gas", "babyiaxo_xmm_rot")]
                 out["other_workloads"].append(mass_scan_rate())
                 out["other_workloads"].append(angular_scan_rate())
                 out["other_workloads"].append(emission_table_rate())
                 out["deterministic_accumulation"] = fixed64_block(full, value)
                 out["record_interface"] = record_interface_block(full)
                 out["effective_area_rms"] = effective_area_rms()
+        out.update(flat_scalars(out))
         print(json.dumps(out))
     rt.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     D.report_stage("done")
+    if proof_failed:
+        # the line above says which comparison failed (bitwise_proof); a run whose reduced image is not the single-GPU image is
+        # not a measurement of this path: non-zero exit (the self-launcher hands rank 0's code on)
+        sys.stderr.write("bench.py: bitwise proof FAILED: %s\n" % json.dumps(proof))
+        raise SystemExit(5)
 
 
 def energy_block(step, stream, rays_per_step: float, seconds: float = 5.0):
@@ -786,7 +941,7 @@ def cpu_baseline(full, n_sample: int, seed: int):
     n1 = max(200_000, n_sample // 50)
     o.trace_histogram(n1, seed=seed, n_threads=1)
     dt1 = time.perf_counter() - t0
-    return {"value": n_sample / dt, "unit": "rays/s", "cores": used, "kind": "port",
+    return {"value": n_sample / dt, "unit": "rays/s", "cores": used, "kind": "port", "single_thread_rays_per_s": n1 / dt1,
             "sample": "%d rays of the same workload, C restatement of traceAxion (oracle/sart_oracle.c, %s), "
                       "%.1f s; single thread: %.3g rays/s" % (n_sample, build, dt, n1 / dt1)}
 

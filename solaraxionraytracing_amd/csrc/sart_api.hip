@@ -4,6 +4,7 @@
 // There is NO CPU fallback in this library: without a HIP device sart_create() fails with
 // SART_ERR_NO_DEVICE, and nothing here links or loads oracle/.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // declarations only (types, enums, signatures): the library itself is dlopen()ed
 #include <dlfcn.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -2084,22 +2085,25 @@ int sart_trace_angular_scan(sart_context* c, const sart_trace_params_t* p, const
   return status_take(c);
 }
 
-// RCCL through dlopen (the library is only needed by hosts that drive several GPUs from one process)
+// RCCL through dlopen (the library is only needed by hosts that drive several GPUs from one process).  Types, enum values and the
+// entry points' signatures are the installed header's (decltype of its declarations: nothing typed by hand); the symbols are
+// looked up at run time, so libsart.so carries no link-time dependency on librccl.
 namespace {
 struct Rccl {
   void* lib = nullptr;
-  int (*CommInitAll)(void**, int, const int*) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  int (*Reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool ok = false;
   static Rccl& get() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+    static Rccl r = load();   // (thread-safe: a function-local static is initialised once)
+    return r;
+  }
+  static Rccl load() {
+    Rccl r;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", nullptr};
     for (int i = 0; names[i] && !r.lib; ++i) r.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
     if (!r.lib) return r;
@@ -2113,56 +2117,83 @@ struct Rccl {
     return r;
   }
 };
-}  // namespace
 
-int sart_reduce_across_devices(sart_context* const* ctxs, double* const* accs, int32_t n, size_t n_doubles, int32_t root) {
+// One communicator set per ordered device list, created on first use and kept for the life of the process: a scan
+// reduces once per point, and ncclCommInitAll costs orders of magnitude more than the 512 KB reduce itself.
+std::mutex g_comm_mutex;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comm_cache;
+
+enum : uint32_t {
+  kReduceForceRccl = 1u,       // take the RCCL route for n == 1 too (the public entry returns before it: nothing to add up)
+  kReduceInjectFailure = 2u,   // hand ncclReduce a data type that does not exist: the real failure branch, communicators dropped
+};
+
+// The body of sart_reduce_across_devices.  `recv` (test entry only): out-of-place receive buffers, NULL = in place as the public
+// entry does it.  info[0] = 1 if the communicators came from the cache, info[1] = communicator sets alive after the call.
+int reduce_across_devices_impl(sart_context* const* ctxs, double* const* accs, double* const* recv, int32_t n, size_t n_doubles,
+                               int32_t root, uint32_t flags, int32_t* info) {
   if (!ctxs || !accs || n < 1 || root < 0 || root >= n) return fail(SART_ERR_INVALID_ARGUMENT, "sart_reduce_across_devices: bad argument");
   for (int i = 0; i < n; ++i) {
-    if (!ctxs[i] || !accs[i]) return fail(SART_ERR_INVALID_ARGUMENT, "NULL context / accumulator");
+    if (!ctxs[i] || !accs[i] || (recv && !recv[i])) return fail(SART_ERR_INVALID_ARGUMENT, "NULL context / accumulator");
     if (ctxs[i]->accum_mode != ctxs[0]->accum_mode) return fail(SART_ERR_INVALID_ARGUMENT, "contexts differ in their accumulation mode");
     for (int j = 0; j < i; ++j)
       if (ctxs[j]->device == ctxs[i]->device) return fail(SART_ERR_INVALID_ARGUMENT, "contexts must be on distinct devices");
   }
-  const int nccl_dtype = ctxs[0]->accum_mode == SART_ACCUM_FIXED64 ? 4 /* ncclInt64 */ : 8 /* ncclDouble (ncclFloat64) */;
+  ncclDataType_t dtype = ctxs[0]->accum_mode == SART_ACCUM_FIXED64 ? ncclInt64 : ncclFloat64;
+  if (flags & kReduceInjectFailure) dtype = static_cast<ncclDataType_t>(ncclNumTypes + 17);
   for (int i = 0; i < n; ++i) {   // everything queued so far must be visible to the collective
     SART_HIP(hipSetDevice(ctxs[i]->device));
     SART_HIP(hipStreamSynchronize(ctxs[i]->stream));
   }
-  if (n == 1) return 0;
+  if (n == 1 && !(flags & kReduceForceRccl)) return 0;
   Rccl& r = Rccl::get();
   if (!r.ok) return fail(SART_ERR_UNSUPPORTED, "librccl could not be loaded");
   std::vector<int> devs(n);
   for (int i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
-  // One communicator set per ordered device list, created on first use and kept for the life of the process: a scan
-  // reduces once per point, and ncclCommInitAll costs orders of magnitude more than the 512 KB reduce itself.
-  static std::mutex comm_mutex;
-  static std::map<std::vector<int>, std::vector<void*>> comm_cache;
-  std::lock_guard<std::mutex> lock(comm_mutex);
-  auto it = comm_cache.find(devs);
-  if (it == comm_cache.end()) {
-    std::vector<void*> fresh(n, nullptr);
-    const int rc_init = r.CommInitAll(fresh.data(), n, devs.data());
-    if (rc_init != 0) return fail(SART_ERR_INTERNAL, std::string("ncclCommInitAll: ") + r.GetErrorString(rc_init));
-    it = comm_cache.emplace(devs, std::move(fresh)).first;
+  std::lock_guard<std::mutex> lock(g_comm_mutex);
+  auto it = g_comm_cache.find(devs);
+  if (info) info[0] = it != g_comm_cache.end();
+  if (it == g_comm_cache.end()) {
+    std::vector<ncclComm_t> fresh(n, nullptr);
+    const ncclResult_t rc_init = r.CommInitAll(fresh.data(), n, devs.data());
+    if (rc_init != ncclSuccess) return fail(SART_ERR_INTERNAL, std::string("ncclCommInitAll: ") + r.GetErrorString(rc_init));
+    it = g_comm_cache.emplace(devs, std::move(fresh)).first;
   }
-  const std::vector<void*>& comms = it->second;
-  int rc = r.GroupStart();
-  for (int i = 0; i < n && rc == 0; ++i) {
-    if (hipSetDevice(ctxs[i]->device) != hipSuccess) { rc = -1; break; }
-    rc = r.Reduce(accs[i], accs[i], n_doubles, nccl_dtype, 0 /* ncclSum */, root, comms[i], ctxs[i]->stream);
+  const std::vector<ncclComm_t>& comms = it->second;
+  ncclResult_t rc = r.GroupStart();
+  bool set_device_failed = false;
+  for (int i = 0; i < n && rc == ncclSuccess; ++i) {
+    if (hipSetDevice(ctxs[i]->device) != hipSuccess) { set_device_failed = true; break; }
+    rc = r.Reduce(accs[i], recv ? recv[i] : accs[i], n_doubles, dtype, ncclSum, root, comms[i], ctxs[i]->stream);
   }
-  const int rc_end = r.GroupEnd();
-  if (rc == 0) rc = rc_end;
+  const ncclResult_t rc_end = r.GroupEnd();
+  if (rc == ncclSuccess) rc = rc_end;
   for (int i = 0; i < n; ++i) {
     (void)hipSetDevice(ctxs[i]->device);
     (void)hipStreamSynchronize(ctxs[i]->stream);
   }
-  if (rc != 0) {   // a failed collective leaves the communicators in an unknown state: drop them
-    for (void* cm : comms) r.CommDestroy(cm);
-    comm_cache.erase(it);
+  const bool failed = rc != ncclSuccess || set_device_failed;
+  if (failed) {   // a failed collective leaves the communicators in an unknown state: drop them
+    for (ncclComm_t cm : comms) r.CommDestroy(cm);
+    g_comm_cache.erase(it);
   }
-  if (rc != 0) return fail(SART_ERR_INTERNAL, std::string("ncclReduce: ") + (rc > 0 ? r.GetErrorString(rc) : "hipSetDevice failed"));
+  if (info) info[1] = static_cast<int32_t>(g_comm_cache.size());
+  if (failed) return fail(SART_ERR_INTERNAL, std::string("ncclReduce: ") + (set_device_failed ? "hipSetDevice failed" : r.GetErrorString(rc)));
   return 0;
+}
+}  // namespace
+
+int sart_reduce_across_devices(sart_context* const* ctxs, double* const* accs, int32_t n, size_t n_doubles, int32_t root) {
+  return reduce_across_devices_impl(ctxs, accs, nullptr, n, n_doubles, root, 0u, nullptr);
+}
+
+// Test entry (not part of include/sart.h): sart_reduce_across_devices with the switches above, so that a one-GPU box runs every
+// line of the RCCL leg - dlopen + symbol lookup, ncclCommInitAll, the grouped ncclReduce in both element types, the communicator
+// cache and the failure branch (tests/test_gpu_rccl_leg.py).
+__attribute__((visibility("default"))) int sart_internal_reduce_across_devices(sart_context* const* ctxs, double* const* accs,
+                                                                               double* const* recv, int32_t n, size_t n_doubles,
+                                                                               int32_t root, uint32_t flags, int32_t* info) {
+  return reduce_across_devices_impl(ctxs, accs, recv, n, n_doubles, root, flags, info);
 }
 
 int sart_enable_kernel_timing(sart_context* c, int enable) {

@@ -6,6 +6,8 @@ emission CDFs behind the log-spaced energy guide, 1000 x 1000 reflectivity re-ta
 the four BASELINE configurations that reach the GPU:
 
   configs[1]  CAST magnet + LLNL telescope, gold reflectivities
+              ... and the two pairings the reference itself ships for that magnet: LLNL with its four multilayer coatings by
+              shell group (raytracer.nim:1164-1187, computeReflectivity :1571-1580) and Abrixas (27 shells, :1320-1346)
   configs[2]  BabyIAXO magnet + XMM-Newton shells, vacuum
   configs[3]  XMM shells, telescope turned (one angle bin of the effective-area scan: chip 100 mm, effective-area flags)
   configs[4]  full AGSS09 emission (all terms, made by the emission kernel) + gas stage
@@ -36,6 +38,12 @@ def full_setup(name):
             full = sa.initFullSetup()
         elif name == "cast_llnl_gold":                  # configs[1]
             full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
+        elif name == "cast_llnl":                       # the reference's own LLNL pairing: 4 coatings, 48 MB re-tabulated
+            full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL)
+            assert full.reflectivity.data.shape[0] == 4 and full.setup.n_coatings == 4
+        elif name == "cast_abrixas":                    # raytracer.nim:1320-1346
+            full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2017, L.SK_VACUUM, L.TK_ABRIXAS)
+            assert full.setup.n_shells == 27
         elif name == "babyiaxo_xmm_gas_agss09":         # configs[4]
             full = sa.initFullSetup(stage=L.SK_GAS, emission="agss09")
         elif name == "babyiaxo_xmm_rot_effarea":        # configs[3]
@@ -51,7 +59,7 @@ def full_setup(name):
     return _cache[name]
 
 
-NAMES = ["babyiaxo_xmm", "cast_llnl_gold", "babyiaxo_xmm_gas_agss09", "babyiaxo_xmm_rot_effarea"]
+NAMES = ["babyiaxo_xmm", "cast_llnl_gold", "cast_llnl", "cast_abrixas", "babyiaxo_xmm_gas_agss09", "babyiaxo_xmm_rot_effarea"]
 
 
 @pytest.mark.parametrize("name", NAMES)
