@@ -255,8 +255,9 @@ def bitwise_proof(rt, full, flags, rank: int, world: int, dev, seed: int, D, res
     it - to the last bit.  Every rank traces its share of the ids [0, BITWISE_RAYS) (distributed.shard_range: the strong
     sharding), ONE int64 reduce to rank 0, then rank 0
       (a) traces the whole range alone on its own GPU and compares the two raw accumulators slot for slot
+          after sart_finalize_accumulator_device (image, flux, sums, counters as doubles)
           -> multi_rank_bitwise_equal_to_single_gpu (world 1: the range as three launches against one launch);
-      (b) finalizes, hashes the image and compares SHA-256 + the flux's bit pattern + N_PASSED with the constants committed
+      (b) hashes the image and compares SHA-256 + the flux's bit pattern + N_PASSED with the constants committed
           from a one-GPU run (tests/golden/bench_bitwise_fixed64.json) -> matches_committed_constants (null when this
           host built other input tables than the host the constants come from).
     Outside the timed region.  Returns the block (rank 0) or None."""
@@ -281,10 +282,13 @@ def bitwise_proof(rt, full, flags, rank: int, world: int, dev, seed: int, D, res
             return None
         alone = torch.zeros(n_acc, dtype=torch.float64, device=dev)
         rt.trace_histogram_device(rt.trace_params(BITWISE_RAYS, seed=seed, accumulate=True, flags=flags), alone.data_ptr())
-        torch.cuda.synchronize(dev)
-        n_diff = int((acc.view(torch.int64) != alone.view(torch.int64)).sum().item())
+        # both through the finalize kernel (integers -> doubles, exact products with the power-of-two quanta), then bit for bit.
+        # (The RAW arrays may differ in representation: the six two-limb sums are (hi 2^40 + lo) with lo < 2^40 after a launch,
+        # and a reduce adds the ranks' limbs without carrying - the same integer, other limbs.)
         rt.finalize_accumulator_device(rt.trace_params(1), acc.data_ptr())
+        rt.finalize_accumulator_device(rt.trace_params(1), alone.data_ptr())
         rt.synchronize()
+        n_diff = int((acc.view(torch.int64) != alone.view(torch.int64)).sum().item())
         host = acc.cpu().numpy()
     finally:
         rt.set_accumulation_mode(*restore)

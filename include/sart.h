@@ -552,7 +552,15 @@ int sart_finalize_mass_scan_device(sart_context* ctx, const sart_trace_params_t*
  * Angles are processed in groups of up to 32 per kernel launch (balanced: 50 angles = 25 + 25); every group traces
  * the rays again.  FIXED64: the quanta are a function of (setup, tables, flags, headroom) alone, the same for every angle and
  * every rank of a multi-GPU job; a reduce is an int64 sum of the raw scan accumulators; sart_finalize_angular_scan_device
- * converts to doubles.
+ * converts to doubles.  The common quantum comes from the on-axis weight bound: an angle far off axis whose few passed rays carry
+ * weights it does not resolve (on average below 2^12 quanta per passed ray) reads NaN in ITS row's SUM_WEIGHTS (and
+ * SUM_WEIGHTS_SQ); the other rows and the call's status are not affected - use a smaller headroom or SART_ACCUM_F64 for such
+ * a scan.
+ * Angles: every turned_y_deg[k] must be finite and inside (-90, 90) degrees (SART_ERR_INVALID_ARGUMENT otherwise; the host loop
+ * sart_set_telescope_angles + sart_trace_histogram takes any finite angle).  Stage A0 retires, before anything is sampled, the
+ * rays whose bore-exit radius alone proves them dead at EVERY angle of a launch group (pipes; inner disc, ring and the annulus
+ * beyond the last shell narrowed by the group's largest tilt) - a wide scan is best given in ascending |angle|, so that the
+ * groups of 32 have small ranges.
  */
 enum { SART_ASCAN_SUM_WEIGHTS = 0, SART_ASCAN_SUM_WEIGHTS_SQ = 1, SART_ASCAN_N_PASSED = 2, SART_ASCAN_N_SHELL_SELECTED = 3,
        SART_ASCAN_SUM_WEIGHTS_HI = 4, SART_ASCAN_SUM_WEIGHTS_SQ_HI = 5, SART_ASCAN_N_HIT_NICKEL = 6,

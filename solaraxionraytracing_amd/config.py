@@ -23,6 +23,52 @@ _ENUMS = {
 }
 
 
+# Every section and key of config/config_default.toml:1-50 and who reads it here (tests/test_config_io.py holds this table to the
+# key set of the reference's file, tests/golden/reference_constants.json["config_default_toml"]: a key the reference adds or drops
+# turns that test red, a key nobody reads cannot hide in a sample file).
+CONFIG_KEYS = {
+    "Resources": {
+        "resourcePath": "init_full_setup_from_config, read_opacity_file: directory of the input files (relative to the config file)",
+        "outputPath": "init_full_setup_from_config -> FullRaytraceSetup.outpath; read_opacity_file: where the solar model CSV goes",
+        "llnlEfficiency": "resolve_resources -> tables.llnl_effective_area(path): the DTU-thesis curve the LLNL plots overlay",
+        "goldFilePrefix": "resolve_resources -> tools/convert_reflectivities_to_h5.py: the Henke download directory",
+        "rawSolarModel": "read_opacity_file: the AGSS09 table",
+        "solarModelFile": "init_full_setup_from_config: emission table CSV (raytracer.nim:2645-2647)",
+        "llnlReflFile": "init_full_setup_from_config: 4-coating reflectivity H5 for tkLLNL (:1170-1171)",
+        "goldReflFile": "init_full_setup_from_config: gold reflectivity H5 for the other telescopes (:1193-1194)",
+    },
+    "ReadOpacityFile": {
+        "solarModelFile": "read_opacity_file: name of the CSV it writes",
+        "opcdPath": "resolve_opcd_path: OPCD 3.3 directory (readOpacityFile.nim:114-117)",
+    },
+    "Setup": {k: "parse_setup (raytracer.nim:1024-1030)" for k in ("experimentSetup", "detectorSetup", "stageSetup", "telescopeSetup")},
+    "Magnet": {k: "maybeParseMagnetConfig (:1032-1051)" for k in ("useConfig", "B", "radiusCB", "lengthColdbore", "lengthB", "pGasRoom", "tGas")},
+    "TestXraySource": {k: "maybeParseTestXraySource (:1053-1076)" for k in (
+        "useConfig", "active", "parallel", "energy", "distance", "radius", "offAxisUp", "offAxisLeft", "activity", "lengthCol")},
+    "DetectorInstallation": {k: "maybeParseDetectorInstallation (:1078-1096)" for k in (
+        "useConfig", "distanceDetectorXRT", "distanceWindowFocalPlane", "lateralShift", "transversalShift")},
+}
+
+
+def check_keys(cfg: dict) -> list:
+    """Keys of a parsed config file that nothing here reads (typos, keys of a newer reference): returned, not raised - the reference's
+    parsers ignore unknown keys too (parsetoml lookups by name)."""
+    return ["[%s].%s" % (sec, k) for sec, body in cfg.items() if isinstance(body, dict)
+            for k in body if k not in CONFIG_KEYS.get(sec, {})] + ["[%s]" % sec for sec in cfg if sec not in CONFIG_KEYS]
+
+
+def resolve_resources(cfg: dict, base: str) -> dict:
+    """Every `[Resources]` entry as the path the reference would open (resourcePath / name, :1012-1022; the two directories relative
+    to the config file's directory), whether or not the file is there."""
+    res = cfg.get("Resources", {})
+    rdir = os.path.normpath(os.path.join(base, res.get("resourcePath", "../resources")))
+    out = {"resourcePath": rdir, "outputPath": os.path.normpath(os.path.join(base, res.get("outputPath", "../out")))}
+    for k in ("llnlEfficiency", "goldFilePrefix", "rawSolarModel", "solarModelFile", "llnlReflFile", "goldReflFile"):
+        if res.get(k):
+            out[k] = os.path.join(rdir, res[k])
+    return out
+
+
 def flags_from_cli(ignoreDetWindow=False, ignoreGasAbs=False, ignoreConvProb=False, ignoreReflection=False, xrayTest=False,
                    detectorInstall=False, magnet=False) -> int:
     """set[ConfigFlags] from the switches of `main` (raytracer.nim:2842-2849)."""
@@ -71,7 +117,8 @@ def init_full_setup_from_config(config_path: str, flags: int = 0, **overrides) -
     es, dk, sk, tk = parse_setup(cfg)
     base = os.path.dirname(os.path.abspath(config_path))
     res = cfg.get("Resources", {})
-    rdir = os.path.normpath(os.path.join(base, res.get("resourcePath", "../resources")))
+    paths = resolve_resources(cfg, base)
+    rdir = paths["resourcePath"]
 
     magnet_cfg = source_cfg = install_cfg = None
     m = cfg.get("Magnet", {})
@@ -110,7 +157,10 @@ def init_full_setup_from_config(config_path: str, flags: int = 0, **overrides) -
         notes.append("%s %s not found: synthetic Henke-derived reflectivity" % (refl_key, refl))
     kw.update(overrides)
     full = initFullSetup(es, dk, sk, tk, flags, **kw)
-    full.outpath = os.path.normpath(os.path.join(base, res.get("outputPath", "../out")))
+    full.outpath = paths["outputPath"]
     full.meta["config"] = config_path
+    unknown = check_keys(cfg)
+    if unknown:
+        notes.append("config keys nothing reads: " + ", ".join(unknown))
     full.meta["notes"] = notes + list(full.meta.get("notes", []))
     return full

@@ -637,14 +637,35 @@ double shell0_miss_radius_of(const sart_setup_t& s, const DevParams& P, int n_ra
   return -1.0;
 }
 
+// A bound on the angle of the telescope's rotation (rotateInY o rotateInX about (0, 0, lT/2), raytracer.nim:1888-1894) for
+// telescope_turned_y = angle_y_deg: the angle of a product of two rotations is at most the sum of their angles.  Exactly 0 for a
+// telescope that is not turned (then build_zones adds no margin: the zones of rounds 1-5).  With SART_NO_TILT_ZONES set in the
+// environment (experiments: A/B of the zones for turned telescopes) a turned telescope gets none of kind (b), as before round 6.
+double tilt_bound_of(const sart_setup_t& s, double angle_y_deg) {
+  const double t = std::fabs(deg2rad(s.telescope_turned_x_deg)) + std::fabs(deg2rad(angle_y_deg));
+  if (t == 0.0) return 0.0;
+  static const bool no_tilt_zones = std::getenv("SART_NO_TILT_ZONES") != nullptr;
+  return no_tilt_zones ? -1.0 : t * (1.0 + 1e-9);
+}
+
 // Stage A0 zones (see HotA).  With r = R sqrt(u3) the distance of the point on the bore exit from the axis and
 // |slope| <= s_max for every ray from the Sun, the ray's distance from the axis at a plane dz further on lies in
 // [r - dz s_max, r + dz s_max].  From that: (a) r - dz_k s_max >= R_k for one of the three cuts behind the
 // magnetic field (cold-bore exit, two pipe cuts; raytracer.nim:1846-1868) => dead, not "reached";
-// (b) telescopes on the magnet axis (entrance offset 0, not rotated): r certainly inside bore + pipes and
-// certainly inside the inner disc / the XMM ring / beyond the outermost shell (:1653, :1674-1692, :1934) => dead,
-// "reached".  Every bound carries a safety margin far above f64 rounding, so the verdict equals the reference's.
-void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h) {
+// (b) telescopes on the magnet axis (entrance offset 0): r certainly inside bore + pipes and certainly inside the inner
+// disc / the XMM ring / beyond the outermost shell (:1653, :1674-1692, :1934) => dead, "reached".  Every bound carries a
+// safety margin far above f64 rounding, so the verdict equals the reference's.
+//
+// (b) for a TURNED telescope (round 6; `tilt_max` = a bound on the angle of the rotation :1888-1894, |turnedX| + |turnedY|, in
+// radians; a fused angular scan passes the largest of its launch).  The frame change maps the ray's two points A = (x1, y1, -Lp),
+// B = (x3, y3, 0) with q - c = Rot (p - c), c = (0, 0, lT/2), and measures the radial distance where the new line meets z = 0
+// (:1897-1905).  A rotation by an angle <= tilt_max moves B by delta <= 2 sin(tilt_max / 2) |B - c| <= 2 sin(tilt_max / 2)
+// sqrt(R_pipe^2 + (lT/2)^2) (B passed the last pipe cut: zones of kind (b) hold below K_in only), in particular |b_z| <= delta;
+// the turned line makes an angle gamma <= atan(s_max) + tilt_max with the z axis, so from b to the plane z = 0 it moves
+// sideways by at most delta tan(gamma).  Hence | (X0, Y0) - (x3, y3) | <= delta (1 + tan(gamma)): the radial uncertainty at the
+// entrance grows by that much and the three zones shrink accordingly (0.3 deg on BabyIAXO / XMM: 2.5 mm on 65 / 350 mm).  No
+// zone of kind (b) beyond gamma = 0.5 rad (they would be empty anyway).
+void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h, double tilt_max) {
   h.n_zones = 0;
   h.zone_reached = 0;
   for (int z = 0; z < kMaxZones; ++z) { h.zone_lo[z] = 1u; h.zone_hi[z] = 0u; }   // empty
@@ -661,12 +682,19 @@ void build_zones(const sart_setup_t& s, const DevParams& P, int n_radii, HotA& h
   // r <= K_in => certainly through entrance plane, cold-bore exit and both pipes
   double K_in = R - P.length_b * s_max - eps;
   for (int k = 0; k < 3; ++k) K_in = std::min(K_in, Rk[k] - dz[k] * s_max - eps);
-  const double spread = dz[2] * s_max + eps;   // radial uncertainty at the telescope entrance
+  double spread = dz[2] * s_max + eps;   // radial uncertainty at the telescope entrance
+  const double gamma = std::atan(s_max) + tilt_max;
+  const bool tilt_ok = tilt_max >= 0.0 && gamma < 0.5;
+  if (tilt_max > 0.0 && tilt_ok) {
+    const double h_tel = P.half_length_telescope;
+    const double delta = 2.0 * std::sin(0.5 * tilt_max) * std::sqrt(Rk[2] * Rk[2] + h_tel * h_tel);
+    spread += delta * (1.0 + std::tan(gamma)) * (1.0 + 1e-6) + eps;
+  }
   struct Z { double lo, hi; bool reached; };
   std::vector<Z> zones;
   if (K_dead < R) zones.push_back({K_dead, 1e300, false});
   // zones in terms of the radial distance at the telescope entrance need the telescope on the magnet axis
-  const bool on_axis = (P.entrance_x == 0.0 && P.entrance_y == 0.0) && !P.rotated;
+  const bool on_axis = (P.entrance_x == 0.0 && P.entrance_y == 0.0) && tilt_ok;
   if (on_axis && K_in > 0) {
     auto add_reached = [&](double lo, double hi) {   // radial in [lo, hi] certainly => blocked; clip to r <= K_in
       hi = std::min(hi, K_in);
@@ -731,7 +759,7 @@ int sync_blob(sart_context* c) {
   c->hotb.refl_n_angles = c->refl_na;
   c->hotb.cdf_stride = c->n_energies + kEnergyCdfPad;
   c->hotb._pad = 0;
-  if (!c->knobs.no_early_reject) build_zones(c->setup, c->params, c->n_radii, c->hot);
+  if (!c->knobs.no_early_reject) build_zones(c->setup, c->params, c->n_radii, c->hot, tilt_bound_of(c->setup, c->setup.telescope_turned_y_deg));
   c->path_const = path_is_constant(c->params, c->hot, c->n_radii);
   c->blob_dirty = false;
   if (c->spot_may_have_moved) c->tile.valid = false;   // a new axion mass alone (weights only) keeps the tile where it is
@@ -1285,6 +1313,15 @@ __attribute__((visibility("default"))) int sart_internal_trace_records_uniforms(
   SART_HIP(hipMemcpyAsync(out_host, c->d_rec.p, p->n_rays * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->stream));
   SART_HIP(hipStreamSynchronize(c->stream));
   return 0;
+}
+
+// Test entry (not in sart.h): the stage-A0 zone table a single launch of this context would use (words of the disc-radius stream, sart_kernels.hip).
+__attribute__((visibility("default"))) int sart_internal_zones(sart_context* c, uint32_t* lo, uint32_t* hi, uint32_t* reached_bits) {
+  if (!c || !lo || !hi || !reached_bits) return -1;
+  if (hipSetDevice(c->device) != hipSuccess || refresh_derived(c) != 0 || sync_blob(c) != 0) return -1;
+  for (int z = 0; z < c->hot.n_zones; ++z) { lo[z] = c->hot.zone_lo[z]; hi[z] = c->hot.zone_hi[z]; }
+  *reached_bits = c->hot.zone_reached;
+  return c->hot.n_zones;
 }
 
 // Test entry (not in sart.h): DevParams::shell0_miss_radius as the next launch would use it (-1: the shortcut is off for this setup).
@@ -1967,8 +2004,8 @@ int sart_trace_angular_scan_device(sart_context* c, const sart_trace_params_t* p
   if (int rc = ascan_check(c, p, n_angles)) return rc;
   if (!turned_y_deg || !scan_dev) return fail(SART_ERR_INVALID_ARGUMENT, "NULL argument");
   for (int32_t k = 0; k < n_angles; ++k)
-    if (!std::isfinite(turned_y_deg[k]) || std::fabs(turned_y_deg[k]) > 45.0)
-      return fail(SART_ERR_INVALID_ARGUMENT, "telescope angles must be finite and within +-45 degrees");
+    if (!std::isfinite(turned_y_deg[k]) || !(std::fabs(turned_y_deg[k]) < 90.0))
+      return fail(SART_ERR_INVALID_ARGUMENT, "telescope angles must be finite and inside (-90, 90) degrees");
   SART_HIP(hipSetDevice(c->device));
   if (int rc = refresh_derived(c)) return rc;
   if (int rc = sync_blob(c)) return rc;
@@ -1991,16 +2028,12 @@ int sart_trace_angular_scan_device(sart_context* c, const sart_trace_params_t* p
   if (p->n_rays == 0) return 0;
   const DevParams& P = c->params;
   const bool fast = !P.test_active && !(P.telescope_kind == SART_TK_XMM && P.inner_blocks < 0) && !c->knobs.force_generic && !P.stage_gas;
-  // Stage A0 for a telescope that is (or may be) rotated: the zones that need the telescope on the magnet's axis do not hold;
-  // what is left - the bore-exit radius alone proves the ray dead at one of the three cuts behind the field - is independent
-  // of the angle, so the zones of the launch are the intersection over its angles by construction.
+  // Stage A0 for a telescope that is turned through several angles: the cuts behind the field do not depend on the angle; the
+  // zones in terms of the radial distance at the entrance (inner disc, ring, beyond the last shell) are built per launch group
+  // with the margin of its largest tilt (build_zones) - a ray inside one of them is dead at EVERY angle of the group and is never
+  // sampled, stashed or turned.
   HotA hot = c->hot;
   hot.rotated = 1;
-  if (!c->knobs.no_early_reject) {
-    DevParams Pz = P;
-    Pz.rotated = 1;
-    build_zones(c->setup, Pz, c->n_radii, hot);
-  }
   int& bpc = c->blocks_per_cu_ascan[fast ? 1 : 0];
   if (bpc == 0) {
     bpc = std::max(1, angular_scan_blocks_per_cu(fast));
@@ -2024,7 +2057,13 @@ int sart_trace_angular_scan_device(sart_context* c, const sart_trace_params_t* p
       std::memset(&an, 0, sizeof an);
       an.n_angles = n_angles / n_groups + (g < n_angles % n_groups ? 1 : 0);
       an.partials = c->d_ascan_partials.p;
-      for (int k = 0; k < an.n_angles; ++k) an.a[k] = ascan_angle_of(c, turned_y_deg[k0 + k]);
+      double tilt_max = 0.0;
+      for (int k = 0; k < an.n_angles; ++k) {
+        an.a[k] = ascan_angle_of(c, turned_y_deg[k0 + k]);
+        const double t = tilt_bound_of(c->setup, turned_y_deg[k0 + k]);
+        tilt_max = (t < 0.0 || tilt_max < 0.0) ? -1.0 : std::max(tilt_max, t);
+      }
+      if (!c->knobs.no_early_reject) build_zones(c->setup, P, c->n_radii, hot, tilt_max);
       double* const rows = scan_dev + static_cast<size_t>(k0) * SART_ASCAN_ROW;
       double* const shared = (k0 == 0) ? scan_dev + static_cast<size_t>(n_angles) * SART_ASCAN_ROW : nullptr;   // counters: once per piece
       {
@@ -2050,8 +2089,9 @@ int sart_finalize_angular_scan_device(sart_context* c, const sart_trace_params_t
   if (int rc = quanta_exp_of(c, weight_bound_of(c, p->flags, c->params.gas_dm2_abs), qe)) return rc;
   double q_w[kScanMaxMasses], q_w2[kScanMaxMasses];
   for (int k = 0; k < kScanMaxMasses; ++k) { q_w[k] = std::ldexp(1.0, qe.w); q_w2[k] = std::ldexp(1.0, qe.w2); }
+  // bit 31: an angle whose few, faint rays the common quantum does not resolve reads NaN in its own row (finalize_scan_kernel)
   constexpr uint32_t kCounters = (1u << SART_ASCAN_N_PASSED) | (1u << SART_ASCAN_N_SHELL_SELECTED) | (1u << SART_ASCAN_N_HIT_NICKEL) |
-                                 (1u << SART_ASCAN_N_PASSED_TILL_WINDOW);
+                                 (1u << SART_ASCAN_N_PASSED_TILL_WINDOW) | (1u << 31);
   static_assert(SART_ASCAN_ROW == SART_SCAN_ROW && SART_ASCAN_SUM_WEIGHTS == SART_SCAN_SUM_WEIGHTS && SART_ASCAN_SUM_WEIGHTS_SQ == SART_SCAN_SUM_WEIGHTS_SQ &&
                     SART_ASCAN_SUM_WEIGHTS_HI == SART_SCAN_SUM_WEIGHTS_HI && SART_ASCAN_SUM_WEIGHTS_SQ_HI == SART_SCAN_SUM_WEIGHTS_SQ_HI &&
                     SART_ASCAN_N_PASSED == SART_SCAN_N_PASSED, "the two scans share the row layout of their sums and the finalize kernel");

@@ -2547,9 +2547,15 @@ __global__ __launch_bounds__(256) void rollover_fixed_kernel(long long* acc, lon
 // travel in the kernel arguments) and, if `shared_row`, the counter row behind the whole scan.  One thread per row.
 struct FinalizeScanArgs {
   int32_t n_masses, shared_row;    // shared_row: row index of the counters relative to `in`, or -1
-  uint32_t counter_slots, _pad;    // bit j: slot j of a row is a plain counter (mass scan: N_PASSED; angular scan: its four counters)
+  uint32_t counter_slots, _pad;    // bit j < 8: slot j of a row is a plain counter (mass scan: N_PASSED; angular scan: its four counters)
+                                   // bit 31 (kFinalizeScanRowsUnresolvedNaN): see finalize_scan_kernel
   double q_w[kScanMaxMasses], q_w2[kScanMaxMasses];
 };
+// Unresolved weights (the row's SUM_WEIGHTS averages below 2^12 quanta per passed ray).  The mass scan has a quantum per mass, derived
+// from that mass's own weight bound: an unresolved row there means the bound is off, and the whole scan reports
+// SART_ERR_ACCUMULATOR.  The angular scan has ONE quantum for all its angles, from the on-axis weight bound - an angle far off axis
+// can pass a few rays of tiny R1 R2 that it does not resolve while every other row is fine: with bit 31 of counter_slots that row's
+// SUM_WEIGHTS reads NaN (as an unresolved SUM_WEIGHTS_SQ does everywhere) and the status stays clean.
 __global__ __launch_bounds__(64) void finalize_scan_kernel(const long long* in, double* out, FinalizeScanArgs F, FixedCheck* C) {
   uint32_t* const status = &C->status;
   const int k = threadIdx.x;
@@ -2559,13 +2565,20 @@ __global__ __launch_bounds__(64) void finalize_scan_kernel(const long long* in, 
     const double two40 = (double)(1ll << kFixedLimbBits);
     const double sw = (double)v[SART_SCAN_SUM_WEIGHTS_HI] * two40 + (double)v[SART_SCAN_SUM_WEIGHTS];
     const double sw2 = (double)v[SART_SCAN_SUM_WEIGHTS_SQ_HI] * two40 + (double)v[SART_SCAN_SUM_WEIGHTS_SQ];
-    const bool sq_ok = fixed_status_check_means(sw, sw2, (double)v[SART_SCAN_N_PASSED], status);
+    const double n_passed = (double)v[SART_SCAN_N_PASSED];
+    bool w_ok = true, sq_ok;
+    if (F.counter_slots >> 31) {
+      w_ok = !(n_passed > 0.0) || sw >= 4096.0 * n_passed;
+      sq_ok = !(n_passed > 0.0) || sw2 >= 64.0 * n_passed;
+    } else {
+      sq_ok = fixed_status_check_means(sw, sw2, n_passed, status);
+    }
     double* const o = out + (size_t)k * SART_SCAN_ROW;
     for (int j = 0; j < SART_SCAN_ROW; ++j) o[j] = 0.0;
-    o[SART_SCAN_SUM_WEIGHTS] = sw * F.q_w[k];
+    o[SART_SCAN_SUM_WEIGHTS] = w_ok ? sw * F.q_w[k] : __builtin_nan("");
     o[SART_SCAN_SUM_WEIGHTS_SQ] = sq_ok ? sw2 * F.q_w2[k] : __builtin_nan("");
     for (int j = 0; j < SART_SCAN_ROW; ++j)
-      if ((F.counter_slots >> j) & 1u) o[j] = (double)v[j];
+      if ((F.counter_slots >> j) & 1u) o[j] = (double)v[j];   // (SART_SCAN_ROW = 8: bit 31 is not a slot)
   } else if (k == 63 && F.shared_row >= 0) {
     for (int j = 0; j < SART_SCAN_ROW; ++j) { v[j] = in[(size_t)F.shared_row * SART_SCAN_ROW + j]; fixed_status_check_slot(v[j], status); }
     for (int j = 0; j < SART_SCAN_ROW; ++j) out[(size_t)F.shared_row * SART_SCAN_ROW + j] = (double)v[j];

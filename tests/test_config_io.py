@@ -60,6 +60,65 @@ transversalShift = 0.0
 """
 
 
+def _reference_config():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_constants.json")) as f:
+        return json.load(f)["config_default_toml"]
+
+
+def _toml_text(cfg: dict) -> str:
+    def lit(v):
+        return ("true" if v else "false") if isinstance(v, bool) else ('"%s"' % v if isinstance(v, str) else repr(float(v)))
+    return "\n".join("[%s]\n%s\n" % (sec, "\n".join("%s = %s" % (k, lit(v)) for k, v in body.items())) for sec, body in cfg.items())
+
+
+def test_config_key_set_is_the_reference_files():
+    """config/config_default.toml:1-50, pinned like the constants (tools/make_reference_constants.py reads the file in the build
+    container; sections, keys and default values as data): config.py reads exactly that key set - nothing the reference has is
+    unknown here, nothing here is unknown to the reference - and the hand-written SAMPLE above has it too."""
+    import tomli
+    ref = _reference_config()
+    assert {sec: set(body) for sec, body in ref.items()} == {sec: set(body) for sec, body in config.CONFIG_KEYS.items()}
+    assert {sec: set(body) for sec, body in tomli.loads(SAMPLE).items()} == {sec: set(body) for sec, body in ref.items()}
+    assert config.check_keys(ref) == []
+    assert config.check_keys({"Setup": {"telescopSetup": "XMM"}, "Plots": {}}) == ["[Setup].telescopSetup", "[Plots]"]
+    # the value types the parsers expect (raytracer.nim:1040-1096: getFloat / getBool / getStr)
+    for sec in ("Magnet", "TestXraySource", "DetectorInstallation"):
+        for k, v in ref[sec].items():
+            assert isinstance(v, bool) if k in ("useConfig", "active", "parallel") else isinstance(v, float), (sec, k, v)
+
+
+def test_reference_defaults_build_the_babyiaxo_setup_and_trace_on_the_cpu(tmp_path):
+    """BASELINE configs[0]: config_default.toml, 1e5 rays on the CPU path (plumbing, no GPU).  The reference's default VALUES
+    (fixture) written back as a config.toml drive init_full_setup_from_config to BabyIAXO / InGridIAXO / vacuum / XMM with every
+    optional block off (useConfig = false: the magnet is the builder's BabyIAXO magnet, not the [Magnet] block's 350 mm bore), all
+    paths resolve as the reference resolves them, and 1e5 rays go through the CPU restatement of traceAxion."""
+    from oracle.oracle import Oracle
+    ref = _reference_config()
+    cfgdir = tmp_path / "config"
+    cfgdir.mkdir()
+    p = cfgdir / "config.toml"
+    p.write_text(_toml_text(ref))
+    full = config.init_full_setup_from_config(str(p), n_radii=400, n_energies=300, refl_n_angles=200, refl_n_energies=200)
+    s = full.setup
+    assert (s.experiment, s.detector_kind, s.stage, s.telescope_kind) == (L.ES_BABYIAXO, L.DK_INGRIDIAXO, L.SK_VACUUM, L.TK_XMM)
+    assert s.test_active == 0 and s.n_shells == 58
+    assert s.magnet_radiusCB == 500.0 != ref["Magnet"]["radiusCB"]       # initMagnet's BabyIAXO bore (raytracer.nim:1113): block not read
+    assert not any("nothing reads" in n for n in full.meta["notes"])
+    paths = config.resolve_resources(ref, str(cfgdir))
+    assert paths["resourcePath"] == str(tmp_path / "resources") and full.outpath == str(tmp_path / "out")
+    assert paths["goldReflFile"] == str(tmp_path / "resources" / "gold_0.25microns_reflectivities.h5")
+    assert set(paths) == set(ref["Resources"])
+    n = 100_000
+    img, summ, _ = Oracle(full).trace_histogram(n, seed=299792458)
+    assert summ["N_RAYS"] == n and 0.19 * n < summ["N_PASSED"] < 0.27 * n
+    assert img.sum() == pytest.approx(summ["SUM_WEIGHTS"], rel=1e-12) and summ["SUM_WEIGHTS"] > 0
+    # with --magnet (or useConfig = true) the block IS read: the reference's default [Magnet] is a 350 mm bore
+    full_m = config.init_full_setup_from_config(str(p), config.flags_from_cli(magnet=True), n_radii=60, n_energies=50,
+                                                refl_n_angles=30, refl_n_energies=30)
+    assert (full_m.setup.magnet_radiusCB, full_m.setup.magnet_B, full_m.setup.magnet_tGas) == (350.0, 2.0, 100.0)
+
+
 def _h5_available():
     try:
         tables.write_reflectivity_h5("/tmp/_sart_probe.h5", tables.analytic_reflectivity_grid(1, 4, 4))

@@ -356,3 +356,50 @@ def test_flux_only_launch_carries_the_spectra(mode):
         else:
             np.testing.assert_allclose(spec0[key], spec[key], rtol=1e-11, atol=1e-30)
     assert spec0["radial_weights"].sum() == pytest.approx(s0["SUM_WEIGHTS"], rel=1e-12)
+
+
+def test_an_unresolved_far_off_angle_reads_nan_in_its_own_row_only():
+    """the FIXED64 scan has one quantum for all its angles (from the on-axis weight bound).  An angle far off axis passes
+    few rays of tiny R1 R2; when the quantum does not resolve them (average below 2^12 quanta per passed ray) THAT row's SUM_WEIGHTS
+    reads NaN - and nothing else: no SART_ERR_ACCUMULATOR for the scan, the other rows exactly what a resolved scan gives, the
+    counters of the unresolved row intact.  Provoked with the coarsest quanta the library accepts (headroom 44: quantum = 2^-19 of
+    the weight bound) and angles out to where the flux has dropped by orders of magnitude."""
+    full = make_setup("babyiaxo_xmm_rot")
+    full.setup.telescope_turned_x_deg = 0.0
+    an = np.array([0.0, 0.05, 0.7, 0.9, 1.1])
+    n = 4_000_000
+    with sa.RayTracer(full) as rt:
+        ref, _ = rt.trace_angular_scan(an, n, seed=9)                       # f64: the truth about every row
+        rt.set_accumulation_mode("fixed64", 44)
+        per, shared = rt.trace_angular_scan(an, n, seed=9)                  # raises if the status were set
+        rt.set_accumulation_mode("fixed64")                                 # default headroom: everything resolves
+        fine, _ = rt.trace_angular_scan(an, n, seed=9)
+    assert shared["N_RAYS"] == n
+    bad = np.isnan(per["SUM_WEIGHTS"])
+    assert bad.any() and not bad[:2].any(), (per["SUM_WEIGHTS"], ref["SUM_WEIGHTS"], ref["N_PASSED"])
+    assert (ref["N_PASSED"][bad] > 0).all()                                 # (a row without passed rays is resolved: it reads 0)
+    for k in ("N_PASSED", "N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW"):
+        np.testing.assert_array_equal(per[k], ref[k])
+    np.testing.assert_allclose(per["SUM_WEIGHTS"][~bad], ref["SUM_WEIGHTS"][~bad], rtol=2e-3)   # coarse quanta, but numbers
+    assert not np.isnan(fine["SUM_WEIGHTS"]).any()
+    np.testing.assert_allclose(fine["SUM_WEIGHTS"], ref["SUM_WEIGHTS"], rtol=1e-6)
+
+
+def test_angles_beyond_45_degrees_are_accepted_and_90_is_refused():
+    """the fused scan used to refuse |angle| > 45 deg, which the host loop traces.  Now any angle inside (-90, 90) runs
+    (nothing passes at such tilts; the counters equal the single launch's), 90 deg and non-finite angles are invalid arguments."""
+    import torch
+    full = make_setup("babyiaxo_xmm_rot")
+    an = np.array([0.1, 50.0, -80.0])
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode("fixed64")
+        scan = raw_scan(rt, torch, an, [(0, 300_000)], seed=3)
+        for k, a in enumerate(an):
+            one = raw_single(rt, torch, a, 300_000, seed=3)
+            assert scan[k, L.ASCAN["N_PASSED"]] == one[L.ACC["N_PASSED"]] and scan[k, L.ASCAN["N_SHELL_SELECTED"]] == one[L.ACC["N_SHELL_SELECTED"]]
+            assert scan[k, L.ASCAN["SUM_WEIGHTS"]] == one[L.ACC["SUM_WEIGHTS"]]
+        assert scan[0, L.ASCAN["N_PASSED"]] > 0 and scan[1, L.ASCAN["N_PASSED"]] == 0
+        for bad in (90.0, -90.0, float("nan"), float("inf")):
+            with pytest.raises(L.SartError) as e:
+                rt.trace_angular_scan(np.array([0.1, bad]), 1000, seed=3)
+            assert e.value.code == L.SART_ERR_INVALID_ARGUMENT

@@ -389,6 +389,34 @@ def test_bench_two_rank_rehearsal(scaling):
     assert d["results"]["passed_fraction"] == pytest.approx(0.2144, abs=2e-3)
     assert d["results"]["image_sum"] == pytest.approx(d["results"]["flux"], rel=1e-9)
     assert d["value"] > 1e9
+    # the result, not only the rate: the FIXED64 image of the ids [0, 2e8) reduced from the two ranks is rank 0's own image of
+    # those ids slot for slot, and (same input tables as the host of the constants) the committed one-GPU image
+    proof = d["bitwise_proof"]
+    assert proof["ranks"] == 2 and proof["equal"] is True and proof["slots_that_differ"] == 0 and proof["n_rays"] == 200_000_000
+    assert d["multi_rank_bitwise_equal_to_single_gpu"] is True
+    assert proof["matches_committed_constants"] in (True, None), proof     # None: this host built other tables; False fails
+    if proof["matches_committed_constants"] is None:
+        assert "tables_sha256" in proof["committed"] or proof["committed"] is None
+
+
+def test_bench_bitwise_constants_are_current():
+    """tests/golden/bench_bitwise_fixed64.json (made by `bench.py --emit-bitwise-constants` on one MI355X) is what this build
+    computes on one GPU: a --gpus N run of the driver is then held to the same bytes.  Skipped - loudly - when this host's
+    libm built other input tables than the host of the constants (tables_sha256)."""
+    import json
+    import os
+    import torch
+    import bench
+    from solaraxionraytracing_amd import distributed as D
+    with open(bench.BITWISE_CONSTANTS) as f:
+        want = json.load(f)
+    full, flags = bench.make_setup("babyiaxo_xmm")
+    if bench.tables_sha256(full) != want["tables_sha256"]:
+        pytest.skip("this host built other input tables than the host of the committed constants")
+    with sa.RayTracer(full) as rt:
+        blk = bench.bitwise_proof(rt, full, flags, 0, 1, torch.device("cuda", 0), want["seed"], D)
+    assert blk["equal"] and blk["matches_committed_constants"] is True, (blk, want)
+    assert blk["image_sha256"] == want["image_sha256"] and blk["sum_weights_hex"] == want["sum_weights_hex"]
 
 
 def test_trace_records_chunked_path_is_byte_identical():
@@ -495,19 +523,28 @@ def test_bench_gpus_n_starts_its_own_ranks_and_refuses_to_lie():
     assert out.returncode == 2 and "{" not in out.stdout
 
 
-@pytest.mark.parametrize("variant", ["vacuum", "gas", "rotated"])
+@pytest.mark.parametrize("variant", ["vacuum", "gas", "rotated", "rotated_0.5", "rotated_3", "abrixas_rotated"])
 def test_early_rejection_stage_is_exact(variant):
     """Stage A0 (rays classified from the bore-exit radius alone) must not change any counter or the image: same
     launch with the stage switched off (SART_NO_EARLY_REJECT, read when a context uploads its parameter block).
-    The three variants are the three instantiations of the histogram kernel (specialised / generic / generic rotated:
-    only the zone of rays that die in the pipes applies when the telescope is turned)."""
+    vacuum / gas / rotated are the instantiations of the histogram kernel.  For a turned telescope the zones in terms of the
+    radial distance at the entrance (inner disc, ring, beyond the last shell) carry the margin of the tilt (round 6,
+    sart_api.hip: build_zones): 0.11, 0.5 and 3 degrees - a margin that were too small by any factor would retire live rays at
+    one of them -, and Abrixas (the other telescope with an inner disc) behind the CAST magnet."""
     import os
     from solaraxionraytracing_amd import _lib as L
     # full-size BabyIAXO / XMM tables: the configuration the stage exists for
-    full = sa.initFullSetup(stage=L.SK_GAS) if variant == "gas" else sa.initFullSetup()
+    if variant == "abrixas_rotated":
+        full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2017, L.SK_VACUUM, L.TK_ABRIXAS)
+        full.setup.telescope_turned_y_deg = 0.2
+    else:
+        full = sa.initFullSetup(stage=L.SK_GAS) if variant == "gas" else sa.initFullSetup()
     if variant == "rotated":
         full.setup.telescope_turned_y_deg = 0.1
         full.setup.telescope_turned_x_deg = -0.05
+    elif variant.startswith("rotated_"):
+        full.setup.telescope_turned_y_deg = float(variant.split("_")[1])
+        full.setup.chip_x_max = full.setup.chip_y_max = 100.0
     n = 20_000_000
     with sa.RayTracer(full) as rt:
         img_a, s_a = rt.trace_histogram(n, seed=17)
@@ -519,9 +556,45 @@ def test_early_rejection_stage_is_exact(variant):
         del os.environ["SART_NO_EARLY_REJECT"]
     for k in ("N_RAYS", "N_REACHED_TELESCOPE", "N_SHELL_SELECTED", "N_HIT_NICKEL", "N_PASSED_TILL_WINDOW", "N_PASSED", "N_OUTSIDE_IMAGE"):
         assert s_a[k] == s_b[k], k
-    assert s_a["N_REACHED_TELESCOPE"] / n == pytest.approx(0.5475, abs=1e-3)
+    if variant != "abrixas_rotated":
+        assert s_a["N_REACHED_TELESCOPE"] / n == pytest.approx(0.5475, abs=1e-3)
     np.testing.assert_allclose(img_a, img_b, rtol=1e-10, atol=img_b.max() * 1e-14)
     assert s_a["SUM_WEIGHTS"] == pytest.approx(s_b["SUM_WEIGHTS"], rel=1e-12)
+
+
+def test_turned_telescope_has_the_zones_of_the_entrance_plane():
+    """The zones of stage A0 for a turned telescope (round 6): beside the pipes' zone the inner disc and the annulus beyond the last
+    shell, narrower by the tilt's margin; none of them with SART_NO_TILT_ZONES - checked on the zone table the launch would use."""
+    import os
+    import subprocess
+    import sys
+    code = ("import ctypes as C, json, solaraxionraytracing_amd as sa\n"
+            "full = sa.initFullSetup(n_radii=400, n_energies=300, refl_n_angles=50, refl_n_energies=50)\n"
+            "out = {}\n"
+            "for y in (0.0, 0.1, 0.3, 40.0):\n"
+            "    full.setup.telescope_turned_y_deg = y\n"
+            "    with sa.RayTracer(full) as rt:\n"
+            "        lo, hi, reached = (C.c_uint32 * 8)(), (C.c_uint32 * 8)(), C.c_uint32()\n"
+            "        n = rt.lib.sart_internal_zones(rt.handle, lo, hi, C.byref(reached))\n"
+            "        out[str(y)] = [n, reached.value, [(hi[i] - lo[i]) / 2.0 ** 32 for i in range(n)]]\n"
+            "print(json.dumps(out))\n")
+    import json
+    res = {}
+    for knob in (False, True):
+        env = dict(os.environ)
+        if knob:
+            env["SART_NO_TILT_ZONES"] = "1"
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[knob] = json.loads(out.stdout.strip().splitlines()[-1])
+    on, off = res[False], res[True]
+    assert on["0.0"] == off["0.0"] and on["0.0"][0] >= 3               # not turned: the zones of rounds 1-5, with or without the knob
+    assert off["0.1"][0] == off["0.3"][0] == 1 and off["0.1"][1] == 0   # knob: only the pipes' zone for a turned telescope
+    assert on["0.1"][0] == on["0.0"][0] and on["0.3"][0] == on["0.0"][0]
+    area = lambda z: sum(z[2])                                         # fraction of the rays stage A0 retires (u3 is uniform)
+    assert area(on["0.0"]) > area(on["0.1"]) > area(on["0.3"]) > area(off["0.3"]) + 0.05
+    assert on["40.0"][0] == 1                                          # no radial zone survives a tilt of 40 degrees
 
 
 def test_launch_splitting_beyond_32bit_ray_indices():

@@ -11,6 +11,7 @@ Sections read (line ranges as of the reference's commit): module constants :248-
 initMagnet :1098-1123, initPipes :1125-1155, initReflectivity :1158-1168 (kind + layers), initTelescope :1250-1348,
 initTestXraySource :1350-1379, initDetectorInstallation :1381-1407, newDetectorSetup :1464-1490.
 calcWindowVals (:1431-1462) is restated here and evaluated for the window parameters the reference uses.
+Round 6: the sections, keys and default values of config/config_default.toml:1-50 (parsed, not copied) under "config_default_toml".
 
   python tools/make_reference_constants.py [--reference /root/reference] [--out tests/golden/reference_constants.json]
 """
@@ -184,6 +185,12 @@ def main():
     out["detector"] = det
     out["calcWindowVals"] = [{"radiusWindow": r, "numberOfStrips": n, "openApertureRatio": o, "width_dist": list(calc_window_vals(r, n, o))}
                              for r, n, o in sorted({(d["radiusWindow"], d["numberOfStrips"], d["openApertureRatio"]) for d in det.values()})]
+
+    # config/config_default.toml:1-50 (BASELINE configs[0]'s plumbing): every section, key and default VALUE (numbers, booleans, file
+    # and enum names) as data - comments and layout are not kept.  tests/test_config_io.py holds config.py to exactly this key set.
+    import tomli
+    with open(os.path.join(args.reference, "config", "config_default.toml"), "rb") as f:
+        out["config_default_toml"] = tomli.load(f)
 
     n_numbers = sum(1 for _ in re.finditer(NUM, json.dumps(out)))
     with open(args.out, "w") as f:

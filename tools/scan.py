@@ -7,9 +7,10 @@
             (xmm_newton_angular_effective_area.csv, McXtrace_angular_xmm.csv; :2805-2813).
             Default: the reference's shape, a flux-only re-trace per angle on fresh rays.  --fused: the FUSED scan kernel
             (sart_trace_angular_scan): every ray is sampled and taken through bore and pipes once and turned through every
-            angle of the rank's group (--shard bins: the angles are dealt out to the ranks, every rank traces all ray ids
-            for its angles; --shard rays: every rank traces its share of the ray ids for all angles, one reduce of the scan
-            accumulator) - all angles see the same rays, the curve does not depend on the number of ranks.
+            angle (--shard rays, the default with --fused: every rank traces its share of the ray ids for all angles, one
+            reduce of the scan accumulator - the cheaper sharding by the kernel's own cost model; --shard bins:
+            the angles are dealt out to the ranks, every rank traces all ray ids for its angles) - all angles see the same
+            rays, the curve does not depend on the number of ranks.
   mass      gas-stage axion-mass scan on the full AGSS09 emission table (BASELINE configs[4]) through the FUSED scan kernel
             (sart_trace_mass_scan): every rank traces its share of the ray ids ONCE and weighs each ray for every mass; one
             reduce of the scan accumulator (8 (points + 1) slots) over the ranks closes the scan ("1e10 rays across 8 MI355X
@@ -40,10 +41,14 @@ def main():
     ap.add_argument("--massMax", type=float, default=0.02, help="eV; the literal-units gas stage has m_gamma = 0.008235 eV")
     ap.add_argument("--rays", type=float, default=1e7, help="rays per scan point")
     ap.add_argument("--chip", type=float, default=100.0, help="chip size in mm for the angular scan (SURVEY App. C)")
-    ap.add_argument("--shard", default="bins", choices=["bins", "rays"],
-                    help="angular scan, mass --host-loop: bins = every scan point is a full run on one rank (BASELINE config 4); "
-                         "rays = every rank traces its share of the ray ids of every point and the accumulators are reduced once per "
-                         "point.  The fused mass scan always shards the rays")
+    ap.add_argument("--shard", default=None, choices=["bins", "rays"],
+                    help="angular scan, mass --host-loop: bins = every scan point is a full run on one rank (BASELINE configs[3]'s "
+                         "wording; the default of the re-trace scans); rays = every rank traces its share of the ray ids of every point and "
+                         "the accumulators are reduced once.  Default with --fused: rays - the fused kernel pays its shared part "
+                         "(sampling, bore, pipes, energy draw: ~12 ps per ray) once per launch and ~5.7 ps per (ray, angle), so G ranks "
+                         "cost (L t_shared + K t_angle) / G per ray by ray id (L = ceil(K / 32) launches) against t_shared ceil(ceil(K / G) / 32) + "
+                         "ceil(K / G) t_angle by angle group: by-ray is never slower and 19 %% faster at K = 50, G = 8 (DESIGN.md 6).  The "
+                         "fused mass scan always shards the rays")
     ap.add_argument("--xrayTest", action="store_true",
                     help="angular: the parallel X-ray test source in front of the bore (raytracer.nim:1765-1806) instead of the sun - "
                          "the cleaner effective-area probe (SURVEY 8(d) config 4)")
@@ -76,6 +81,8 @@ def main():
     rank, world, local_rank = D.init_process_group_from_env(os.environ.get("SART_BENCH_BACKEND"))
     if "SART_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["SART_BENCH_DEVICE"])
+    if args.shard is None:
+        args.shard = "rays" if (args.mode == "angular" and args.fused) else "bins"
     n_rays = int(args.rays)
     emission = args.emission or ("agss09-device" if args.mode == "mass" else "primakoff")
     if args.mode == "angular":
