@@ -25,9 +25,10 @@
 extern "C" {
 #endif
 
-#define SART_ABI_VERSION 4   /* 2: SART_ACC_COUNT 16 -> 24 (SUM_WEIGHTS_SQ_HI), fused mass scan, FIXED64 status;
+#define SART_ABI_VERSION 5   /* 2: SART_ACC_COUNT 16 -> 24 (SUM_WEIGHTS_SQ_HI), fused mass scan, FIXED64 status;
                                 3: SART_ERR_ACCUMULATOR, fused angular scan, flux-only launches, accumulator roll-over;
-                                4: sart_trace_records_passed */
+                                4: sart_trace_records_passed;
+                                5: sart_release_scratch (additive: a v4 caller runs unchanged) */
 #define SART_MAX_SHELLS 64
 #define SART_MAX_COATINGS 8
 
@@ -373,6 +374,15 @@ int sart_trace_records_passed(sart_context* ctx, const sart_trace_params_t* para
  * counts grow (several launches into one buffer); 0: the counts start from zero. */
 int sart_trace_records_passed_device(sart_context* ctx, const sart_trace_params_t* params, sart_axion_t* ax_buf_device,
                                      uint64_t capacity, uint64_t* counts_device);
+/*
+ * Device scratch of the record entries.  sart_trace_records and sart_trace_records_passed[_device] trace into buffers the
+ * context owns: one of min(n_rays, 2^20) records (208 B each: 218 MB at full size), a second one as soon as a call needs more
+ * than one chunk, and - host form of the passed-only call above one chunk - a third for the compacted records (436 - 654 MB in
+ * all).  The buffers only grow (a call never frees: hipFree would synchronise the device) and stay until sart_destroy - or
+ * until this call, which waits for the context's streams and frees them; the next record call allocates again.  The
+ * histogram / scan entries do not use them.
+ */
+int sart_release_scratch(sart_context* ctx);
 
 /*
  * Fused trace + accumulation: traceAxionWrapper + prepareHeatmap(256,256,...,norm=1) (:2629)

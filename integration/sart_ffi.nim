@@ -121,6 +121,7 @@ proc sart_trace_records_passed*(ctx: ptr SartContext, p: ptr SartTraceParams, ax
                                 counts: ptr SartRecordCounts): cint {.importc, header: sartH.}
 proc sart_trace_records_passed_device*(ctx: ptr SartContext, p: ptr SartTraceParams, axBufDevice: pointer, capacity: uint64,
                                        countsDevice: pointer): cint {.importc, header: sartH.}
+proc sart_release_scratch*(ctx: ptr SartContext): cint {.importc, header: sartH.}
 proc sart_trace_histogram_device*(ctx: ptr SartContext, p: ptr SartTraceParams, accumulatorDevice: ptr cdouble): cint {.importc, header: sartH.}
 proc sart_trace_histogram*(ctx: ptr SartContext, p: ptr SartTraceParams, imageOutHost: ptr cdouble, summary: ptr SartSummary): cint {.importc, header: sartH.}
 proc sart_trace_histogram_spectra*(ctx: ptr SartContext, p: ptr SartTraceParams, imageOutHost: ptr cdouble, summary: ptr SartSummary,

@@ -16,7 +16,7 @@ LIBSART_HOST_PATH = os.path.join(_PKG_DIR, "libsart_host.so")
 SART_MAX_SHELLS = 64
 SART_MAX_COATINGS = 8
 SART_ACC_COUNT = 24
-SART_ABI_VERSION = 4
+SART_ABI_VERSION = 5
 
 # enums (values of include/sart.h)
 ES_CAST, ES_BABYIAXO = 0, 1
@@ -202,6 +202,7 @@ SART_SYMBOLS = {
     "sart_trace_records_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p]),
     "sart_trace_records_passed": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p, C.c_uint64, _P(RecordCounts)]),
     "sart_trace_records_passed_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p, C.c_uint64, C.c_void_p]),
+    "sart_release_scratch": (C.c_int, [C.c_void_p]),
     "sart_trace_histogram_device": (C.c_int, [C.c_void_p, _P(TraceParams), C.c_void_p]),
     "sart_trace_histogram": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _P(Summary)]),
     "sart_trace_histogram_spectra": (C.c_int, [C.c_void_p, _P(TraceParams), _dp, _P(Summary), _dp]),

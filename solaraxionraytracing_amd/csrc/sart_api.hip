@@ -97,6 +97,13 @@ struct DevBuf {
     n = count;
     return 0;
   }
+  // Grow-only scratch: room for at least `count` elements.  (hipFree synchronises the device: a scratch buffer that followed the
+  // size of every call would do that whenever consecutive calls differ in size.)
+  int reserve(size_t count) { return (p && n >= count) ? 0 : resize(count); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+  }
 };
 
 // numericalnim newLinear1D.eval (reference call sites raytracer.nim:1522-1527, 2170-2190)
@@ -210,7 +217,7 @@ struct sart_context {
   DevBuf<sart_axion_t> d_rec2; // its second half-buffer (chunked, double-buffered record path)
   // passed-rays-only record path: compacted chunks (two half-buffers), scan scratch, counts {n_rays, n_passed, n_passed_till_window,
   // n_hit_nickel} per half-buffer on the device and in pinned host memory
-  DevBuf<sart_axion_t> d_cmp[2];
+  DevBuf<sart_axion_t> d_cmp;  // passed records only: second compacted half-buffer (the first is d_rec2, which that path does not use otherwise)
   DevBuf<uint32_t> d_cmp_counts;
   DevBuf<unsigned long long> d_cmp_first, d_cmp_totals;
   unsigned long long* h_cmp_totals = nullptr;
@@ -1308,7 +1315,7 @@ __attribute__((visibility("default"))) int sart_internal_trace_records_uniforms(
   SART_HIP(hipSetDevice(c->device));
   DevBuf<double> d_u;
   if (int rc = d_u.upload(uniforms_host, 6 * p->n_rays)) return rc;
-  if (int rc = c->d_rec.resize(p->n_rays)) return rc;
+  if (int rc = c->d_rec.reserve(p->n_rays)) return rc;
   if (int rc = trace_records_impl(c, p, c->d_rec.p, d_u.p)) return rc;
   SART_HIP(hipMemcpyAsync(out_host, c->d_rec.p, p->n_rays * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->stream));
   SART_HIP(hipStreamSynchronize(c->stream));
@@ -1436,14 +1443,14 @@ int sart_trace_records(sart_context* c, const sart_trace_params_t* p, sart_axion
   const uint64_t n = p->n_rays;
   const uint64_t chunk = c->knobs.records_chunk > 0 ? static_cast<uint64_t>(c->knobs.records_chunk) : (uint64_t(1) << 20);   // 208 MiB of records
   if (n <= chunk) {   // one launch, one copy
-    if (int rc = c->d_rec.resize(n)) return rc;
+    if (int rc = c->d_rec.reserve(n)) return rc;
     if (int rc = sart_trace_records_device(c, p, c->d_rec.p)) return rc;
     SART_HIP(hipMemcpyAsync(out, c->d_rec.p, n * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->stream));
     SART_HIP(hipStreamSynchronize(c->stream));
     return 0;
   }
-  if (int rc = c->d_rec.resize(chunk)) return rc;
-  if (int rc = c->d_rec2.resize(chunk)) return rc;
+  if (int rc = c->d_rec.reserve(chunk)) return rc;
+  if (int rc = c->d_rec2.reserve(chunk)) return rc;
   if (!c->copy_stream) SART_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
   for (int k = 0; k < 2; ++k) {
     if (!c->rec_traced[k]) SART_HIP(hipEventCreateWithFlags(&c->rec_traced[k], hipEventDisableTiming));
@@ -1497,7 +1504,7 @@ int sart_trace_records(sart_context* c, const sart_trace_params_t* p, sart_axion
 // records_count / scan / scatter), and only the passed ones travel.
 namespace {
 int compact_scratch(sart_context* c, uint64_t chunk) {
-  if (int rc = c->d_rec.resize(chunk)) return rc;
+  if (int rc = c->d_rec.reserve(chunk)) return rc;
   if (int rc = c->d_cmp_counts.resize(1024)) return rc;
   if (int rc = c->d_cmp_first.resize(1024)) return rc;
   return 0;
@@ -1534,8 +1541,11 @@ int sart_trace_records_passed(sart_context* c, const sart_trace_params_t* p, sar
   SART_HIP(hipSetDevice(c->device));
   const uint64_t n = p->n_rays, chunk = compact_chunk_of(c), n_chunks = (n + chunk - 1) / chunk;
   if (int rc = compact_scratch(c, std::min(chunk, n))) return rc;
+  // two compacted half-buffers (one when a single chunk does it): the record path's second trace buffer and one of this path's
+  // own, both grow-only and kept until sart_release_scratch / sart_destroy (include/sart.h: "device scratch")
+  DevBuf<sart_axion_t>* const cmp[2] = {&c->d_rec2, &c->d_cmp};
   for (int k = 0; k < (n_chunks > 1 ? 2 : 1); ++k)
-    if (int rc = c->d_cmp[k].resize(std::min(chunk, n))) return rc;
+    if (int rc = cmp[k]->reserve(std::min(chunk, n))) return rc;
   if (int rc = c->d_cmp_totals.resize(8)) return rc;
   if (!c->h_cmp_totals) SART_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_cmp_totals), 8 * sizeof(unsigned long long), hipHostMallocDefault));
   if (!c->copy_stream) SART_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -1568,7 +1578,7 @@ int sart_trace_records_passed(sart_context* c, const sart_trace_params_t* p, sar
                ? fail(SART_ERR_INTERNAL, "sart_trace_records_passed: failure injected by SART_RECORDS_FAIL_CHUNK (test hook)")
                : sart_trace_records_device(c, &q, c->d_rec.p);
       if (rc) break;
-      launch_compact_records(c->d_rec.p, static_cast<uint32_t>(q.n_rays), c->d_cmp[b].p, q.n_rays, c->d_cmp_counts.p, c->d_cmp_first.p, totals, c->stream);
+      launch_compact_records(c->d_rec.p, static_cast<uint32_t>(q.n_rays), cmp[b]->p, q.n_rays, c->d_cmp_counts.p, c->d_cmp_first.p, totals, c->stream);
       if (!step(hipGetLastError(), "compaction kernels")) break;
       if (!step(hipMemcpyAsync(c->h_cmp_totals + 4 * b, totals, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream), "hipMemcpyAsync(counts)")) break;
       if (!step(hipEventRecord(c->rec_traced[b], c->stream), "hipEventRecord(traced)")) break;
@@ -1582,7 +1592,7 @@ int sart_trace_records_passed(sart_context* c, const sart_trace_params_t* p, sar
       if (cnt) {
         prefault.allow((written + 3 * cnt) / chunk + 1);   // this copy and, at this pass rate, the next two
         for (uint64_t j = written / chunk; j <= (written + cnt - 1) / chunk; ++j) prefault.wait(j);   // (its chunks: `chunk` records each)
-        if (!step(hipMemcpyAsync(out + written, c->d_cmp[b].p, cnt * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->copy_stream), "hipMemcpyAsync(records)")) break;
+        if (!step(hipMemcpyAsync(out + written, cmp[b]->p, cnt * sizeof(sart_axion_t), hipMemcpyDeviceToHost, c->copy_stream), "hipMemcpyAsync(records)")) break;
         written += cnt;
       }
       if (!step(hipEventRecord(c->rec_copied[b], c->copy_stream), "hipEventRecord(copied)")) break;
@@ -1592,6 +1602,17 @@ int sart_trace_records_passed(sart_context* c, const sart_trace_params_t* p, sar
   if (rc) return rc;
   if (he != hipSuccess) return fail(SART_ERR_NO_DEVICE, std::string("sart_trace_records_passed: ") + what + ": " + hipGetErrorString(he));
   if (e1 != hipSuccess || e2 != hipSuccess) return fail(SART_ERR_NO_DEVICE, std::string("sart_trace_records_passed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+  return 0;
+}
+
+int sart_release_scratch(sart_context* c) {
+  if (!c) return fail(SART_ERR_INVALID_ARGUMENT, "ctx is NULL");
+  SART_HIP(hipSetDevice(c->device));
+  SART_HIP(hipStreamSynchronize(c->stream));
+  if (c->copy_stream) SART_HIP(hipStreamSynchronize(c->copy_stream));
+  c->d_rec.release();
+  c->d_rec2.release();
+  c->d_cmp.release();
   return 0;
 }
 

@@ -366,7 +366,9 @@ def test_an_unresolved_far_off_angle_reads_nan_in_its_own_row_only():
     the weight bound) and angles out to where the flux has dropped by orders of magnitude."""
     full = make_setup("babyiaxo_xmm_rot")
     full.setup.telescope_turned_x_deg = 0.0
-    an = np.array([0.0, 0.05, 0.7, 0.9, 1.1])
+    # on axis, nearly on axis, and 24 angles across the edge of the field of view (nothing passes beyond ~0.7 deg): the last rays
+    # that still pass there reflect at grazing angles where R1 R2 is orders of magnitude below its on-axis values
+    an = np.concatenate([[0.0, 0.05], np.linspace(0.4, 0.7, 24)])
     n = 4_000_000
     with sa.RayTracer(full) as rt:
         ref, _ = rt.trace_angular_scan(an, n, seed=9)                       # f64: the truth about every row

@@ -120,3 +120,25 @@ def test_null_arguments():
         assert rt.lib.sart_trace_records_passed(rt.handle, C.byref(p), None, 10, C.byref(cnt)) == L.SART_ERR_INVALID_ARGUMENT
         assert rt.lib.sart_trace_records_passed(rt.handle, C.byref(p), None, 0, None) == L.SART_ERR_INVALID_ARGUMENT
         assert rt.lib.sart_trace_records_passed(rt.handle, C.byref(p), None, 0, C.byref(cnt)) == 0 and cnt.n_rays == 10
+
+
+def test_record_scratch_only_grows_and_can_be_released():
+    """the record entries keep their device scratch (up to three buffers of 2^20 records) in the context.  It only
+    grows - calls of different sizes do not free and reallocate (hipFree synchronises the device) - and sart_release_scratch
+    (ABI 5) hands it back; the next call allocates again and returns the same bytes."""
+    import torch
+    with sa.RayTracer(make_setup("babyiaxo_xmm")) as rt:
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        big, cb = rt.traceAxionWrapperPassed(300_000, seed=4)
+        after_big = torch.cuda.mem_get_info()[0]
+        assert free0 - after_big >= 300_000 * 208                          # at least the trace buffer
+        small, cs = rt.traceAxionWrapperPassed(40_000, seed=4)
+        again, ca = rt.traceAxionWrapperPassed(300_000, seed=4)
+        assert torch.cuda.mem_get_info()[0] == after_big                   # nothing freed, nothing allocated in between
+        assert again.tobytes() == big.tobytes() and ca == cb and small.tobytes() == big[:cs["n_passed"]].tobytes()
+        L.check(rt.lib.sart_release_scratch(rt.handle))
+        assert torch.cuda.mem_get_info()[0] >= after_big + 300_000 * 208   # handed back
+        once_more, cm = rt.traceAxionWrapperPassed(300_000, seed=4)
+        assert once_more.tobytes() == big.tobytes() and cm == cb
+        assert rt.lib.sart_release_scratch(None) == L.SART_ERR_INVALID_ARGUMENT

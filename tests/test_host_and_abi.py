@@ -25,7 +25,7 @@ def test_libsart_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(L.SART_SYMBOLS) == names          # the ctypes table binds exactly the header
-    assert lib.sart_abi_version() == L.SART_ABI_VERSION == 4
+    assert lib.sart_abi_version() == L.SART_ABI_VERSION == 5
 
 
 def test_libsart_host_exports_every_declared_symbol():
@@ -197,7 +197,7 @@ def test_c_host_records_agree_with_histogram(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     out, scan, ascan = lines[0], lines[1]["mass_scan"], lines[2]["angular_scan"]
-    assert out["agree"] is True and out["passed"] > 10000 and out["build"] == L.build_id() and out["abi"] == 4
+    assert out["agree"] is True and out["passed"] > 10000 and out["build"] == L.build_id() and out["abi"] == 5
     assert abs(out["flux_records"] - out["flux_histogram"]) <= 1e-11 * out["flux_histogram"]
     # step 3b: sart_trace_records_passed gives the records filterIt(it.passed) keeps, byte for byte, and the three counts
     assert out["passed_only_records_agree"] is True
