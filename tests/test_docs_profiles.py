@@ -1,4 +1,4 @@
-"""Every profile file that DESIGN.md, README.md, INTEGRATION.md or profiles/README.md names exists (the numbers in the documents
+"""Every profile file that DESIGN.md, README.md, INTEGRATION.md, profiles/README.md or profiles/EXPERIMENTS.md names exists (the numbers in the documents
 are only as good as the files they point to; the per-build file sets are renamed whenever a build is re-profiled)."""
 import glob
 import os
@@ -19,7 +19,7 @@ def candidates(doc):
 
 def test_documents_name_existing_profile_files():
     missing = []
-    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md", "tools/README.md"):
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md", "tools/README.md", "profiles/EXPERIMENTS.md"):
         for name in candidates(doc):
             if not glob.glob(os.path.join(ROOT, name)):
                 missing.append((doc, name))
