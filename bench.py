@@ -440,6 +440,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Progress reports for the self-launcher's stall clock (distributed.heartbeat: every live rank silent for SART_STALL_TIMEOUT ->
+    # exit 3 with the last report of each rank; a file write, no-op without a launcher - outside the device's work either way)
+    D.heartbeat("warmup")
     for k in range(args.warmup):
         step(10_000 + k)   # ray ids outside the timed range
     if world > 1:  # warm the communicator
@@ -453,8 +456,11 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k)
+        if (k & 63) == 63:
+            D.heartbeat("step %d of %d queued" % (k + 1, args.steps))
     stream.synchronize()                 # this rank's launches are done (the reduce would wait for them anyway)
     t_red = time.perf_counter()
+    D.heartbeat("reduce")
     if roll:                             # fold once more: every slot < 2^40 on every rank, then both limb arrays reduce as int64 sums
         rt.rollover_accumulator_device(rt.trace_params(1), acc.data_ptr(), hi_limbs.data_ptr())
         D.reduce_accumulator(hi_limbs, dst=0, fixed64=True)
@@ -470,6 +476,7 @@ def main():
             rt.finalize_accumulator_device(rt.trace_params(1), acc.data_ptr())
     barrier()
     t1 = time.perf_counter()
+    D.heartbeat("timed region done")
     rt.synchronize()                     # raises what the FIXED64 finalize found (unresolved weights, a wrapped slot)
     # Only rank 0 finalizes, so only rank 0 can raise here - the other ranks walk into the all_reduce below and wait for it.  Under
     # the self-launcher that ends well (it sees rank 0's exit code, names the rank and ends the others: distributed.py).  The knob
@@ -490,6 +497,7 @@ def main():
     kernel_ms, n_launch = rt.kernel_timing()
     rt.enable_kernel_timing(False)
     # the result, not only the rate: a fixed id range traced by all ranks in FIXED64 against rank 0 alone (every rank takes part)
+    D.heartbeat("bitwise proof")
     proof = None
     if scan_masses is None and scan_angles is None and full.fluxRadiusCDF is not None:
         proof = bitwise_proof(rt, full, flags, rank, world, dev, seed, D, restore=(args.accumulation, args.headroom))

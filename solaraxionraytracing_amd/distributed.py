@@ -97,7 +97,8 @@ START_TIMEOUT_S = 600         # from the launch to the rendezvous of every rank:
 RDZV_TIMEOUT_S = 120          # torch.distributed rendezvous + communicator bring-up of one rank (SART_RDZV_TIMEOUT overrides)
 LAUNCH_TIMEOUT_S = 0          # wall-clock limit of a self-launched multi-rank run: none unless SART_LAUNCH_TIMEOUT asks for one
 TERM_GRACE_S = 10             # between SIGTERM and SIGKILL for ranks that are being ended (SART_TERM_GRACE)
-STAGES = ("started", "rendezvous", "up", "done")
+STALL_TIMEOUT_S = 900         # silence of EVERY live rank after one of them has reported progress (heartbeat): SART_STALL_TIMEOUT, 0 = off
+STAGES = ("started", "rendezvous", "up", "done")   # + "beat:<what>" (heartbeat): the group is up and the rank is working
 
 
 def report_stage(stage: str) -> None:
@@ -111,6 +112,32 @@ def report_stage(stage: str) -> None:
             f.write(stage)
     except OSError:
         pass
+
+
+def heartbeat(what: str) -> None:
+    """Progress report of a rank whose process group is up ("beat:<what>" in its status file; no-op without a launcher).  A run
+    without a wall limit (the default: a long production run is not a hang) still must not wait for ever on a collective that
+    never completes - with every rank alive nothing else would end it.  Scripts that call this between their steps
+    get a stall clock in the launcher: when EVERY live rank has been silent for SART_STALL_TIMEOUT seconds (default 900) the
+    ranks are ended, the exit code is 3 and the last report of each rank says where it stopped.  Scripts that never call it are
+    not watched."""
+    report_stage("beat:" + what)
+
+
+def _is_up(stage: str) -> bool:
+    return stage in ("up", "done") or stage.startswith("beat:")
+
+
+def _last_reports(status_dir: str, ranks) -> float:
+    """Seconds since the most recent status report of any of `ranks` (inf if none of them ever reported)."""
+    import time
+    newest = 0.0
+    for r in ranks:
+        try:
+            newest = max(newest, os.path.getmtime(os.path.join(status_dir, "rank%d" % r)))
+        except OSError:
+            pass
+    return time.time() - newest if newest else float("inf")
 
 
 def _rank_stages(status_dir: str, n_ranks: int) -> list:
@@ -154,7 +181,9 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list, need_devices: 
       must report its process group up (report_stage) within SART_RDZV_TIMEOUT + 60 s of the first rank reaching the
       rendezvous; past either the ranks are ended and the exit code is 3, with one line per rank saying what it last
       reported - a hang becomes a diagnosable failure instead of the driver's own limit.  A limit on the whole run is opt-in
-      (SART_LAUNCH_TIMEOUT=<seconds>; unset or 0 = none: a long production run is not a hang).  Ending ranks means SIGTERM by
+      (SART_LAUNCH_TIMEOUT=<seconds>; unset or 0 = none: a long production run is not a hang); what ends a run that hangs with
+      every rank alive (a collective that never completes) is the stall clock: ranks that report progress (heartbeat) and then
+      ALL fall silent for SART_STALL_TIMEOUT (900 s) are ended with exit code 3.  Ending ranks means SIGTERM by
       exact PID, then - for ranks still alive SART_TERM_GRACE (10 s) later, e.g. blocked in a driver call - SIGKILL, with their
       numbers on stderr: the launcher itself always returns.
 
@@ -194,6 +223,7 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list, need_devices: 
     rdzv_limit = float(os.environ.get("SART_RDZV_TIMEOUT", RDZV_TIMEOUT_S)) + float(os.environ.get("SART_RDZV_MARGIN", 60.0))
     start_limit = float(os.environ.get("SART_START_TIMEOUT", START_TIMEOUT_S))
     wall_limit = float(os.environ.get("SART_LAUNCH_TIMEOUT", LAUNCH_TIMEOUT_S))
+    stall_limit = float(os.environ.get("SART_STALL_TIMEOUT", STALL_TIMEOUT_S))
     status_dir = tempfile.mkdtemp(prefix="sart_ranks_")
     procs, pumps = [], []
     err_sink = getattr(sys.stderr, "buffer", None) or sys.stderr
@@ -223,6 +253,7 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list, need_devices: 
     t_rdzv = None       # when the first rank reached the rendezvous
     t_term = None       # when the remaining ranks were told to end (SIGTERM)
     all_up = False
+    beating = False     # a rank has sent a heartbeat: the stall clock applies
     grace = float(os.environ.get("SART_TERM_GRACE", TERM_GRACE_S))
     try:
         while alive:
@@ -251,7 +282,7 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list, need_devices: 
                 what = None
                 if not all_up:
                     stages = _rank_stages(status_dir, n_ranks)
-                    all_up = all(s in ("up", "done") for s in stages)
+                    all_up = all(_is_up(s) for s in stages)
                     if t_rdzv is None and any(s != "nothing" and s != "started" for s in stages):
                         t_rdzv = time.monotonic()
                     if not all_up and t_rdzv is not None and time.monotonic() - t_rdzv > rdzv_limit:
@@ -260,11 +291,16 @@ def launch_ranks_if_needed(n_ranks: int, script: str, argv: list, need_devices: 
                         what = "not every rank reached the rendezvous within %.0f s" % start_limit
                 if what is None and wall_limit > 0 and elapsed > wall_limit:
                     what = "the run did not end within %.0f s (SART_LAUNCH_TIMEOUT)" % wall_limit
+                if what is None and all_up and stall_limit > 0:
+                    # the stall clock runs for scripts that report progress (heartbeat): every live rank silent for stall_limit
+                    beating = beating or any(s.startswith("beat:") for s in _rank_stages(status_dir, n_ranks))
+                    if beating and _last_reports(status_dir, [procs.index(q) for q in alive]) > stall_limit:
+                        what = "no live rank reported progress for %.0f s (SART_STALL_TIMEOUT): a collective that never completes?" % stall_limit
                 if what is not None:
                     stages = _rank_stages(status_dir, n_ranks)
                     print("launcher: %s; last report of every rank: %s" % (what, ", ".join("rank %d: %s" % (r, s) for r, s in enumerate(stages))),
                           file=sys.stderr)
-                    never = [r for r, s in enumerate(stages) if s in ("nothing", "started", "rendezvous")]
+                    never = [r for r, s in enumerate(stages) if not _is_up(s)]
                     if never and not all_up:
                         print("launcher: rank(s) %s never reported their process group up" % ", ".join(map(str, never)), file=sys.stderr)
                     rc = 3

@@ -463,6 +463,56 @@ def test_rank0_failing_behind_the_reduce_ends_the_launch_and_is_named(tmp_path, 
         assert "launcher: rank(s) 1, 2 still alive 3 s after SIGTERM: killed" in r.stderr, r.stderr[-1500:]
 
 
+_STALL_SCRIPT = '''
+import os, sys, time
+sys.path.insert(0, %r)
+from solaraxionraytracing_amd import distributed as D
+rank, world, _ = D.init_process_group_from_env("gloo")
+mode = sys.argv[1]
+for k in range(3):
+    if mode != "silent":
+        D.heartbeat("step %%d" %% k)
+    time.sleep(0.3)
+if mode == "hang":
+    D.heartbeat("reduce")
+    time.sleep(300)                      # every rank alive, nobody makes progress: a collective that never completes
+if mode == "slow_rank0" and rank == 0:
+    for k in range(8):                   # rank 0 works on (and says so) while the others wait for it: not a stall
+        time.sleep(1.0)
+        D.heartbeat("side work %%d" %% k)
+if mode == "silent":
+    time.sleep(6)                        # a script that never reports progress is not watched
+import torch.distributed as dist
+dist.barrier()
+D.report_stage("done")
+'''
+
+
+@pytest.mark.parametrize("mode", ["hang", "slow_rank0", "silent"])
+def test_stall_clock_ends_a_run_whose_ranks_all_fall_silent(tmp_path, mode):
+    """ADVICE r05: with the wall limit opt-in, a run that hangs with every rank alive (a stuck collective) was never ended by the
+    launcher.  Ranks that report progress (heartbeat) get a stall clock: all of them silent for SART_STALL_TIMEOUT -> exit 3 and
+    the last report of each rank; one rank that keeps reporting keeps the run alive; a script without heartbeats is not watched."""
+    import subprocess
+    import time
+    script = tmp_path / "stall.py"
+    script.write_text(_STALL_SCRIPT % ROOT)
+    launcher = tmp_path / "launcher.py"
+    launcher.write_text("import sys\nsys.path.insert(0, %r)\nfrom solaraxionraytracing_amd import distributed as D\nD.visible_devices = lambda: 2\n"
+                        "raise SystemExit(D.launch_ranks_if_needed(2, %r, [%r]))\n" % (ROOT, str(script), mode))
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(launcher)], env=_clean_env(SART_BENCH_BACKEND="gloo", SART_STALL_TIMEOUT="3"), capture_output=True,
+                       text=True, timeout=280)
+    if mode == "hang":
+        assert r.returncode == 3 and "SART_STALL_TIMEOUT" in r.stderr and "rank 0: beat:reduce" in r.stderr and "rank 1: beat:reduce" in r.stderr, (
+            r.returncode, r.stderr[-1500:])
+        assert time.time() - t0 < 250
+    else:
+        assert r.returncode == 0, (r.returncode, r.stderr[-1500:])
+    from solaraxionraytracing_amd import distributed as D
+    assert D.STALL_TIMEOUT_S == 900
+
+
 def test_a_wall_limit_is_opt_in(tmp_path):
     """ADVICE r04: the launcher used to end any self-launched run after 25 minutes.  Now only when SART_LAUNCH_TIMEOUT asks."""
     import subprocess

@@ -83,6 +83,7 @@ def main():
         local_rank = int(os.environ["SART_BENCH_DEVICE"])
     if args.shard is None:
         args.shard = "rays" if (args.mode == "angular" and args.fused) else "bins"
+    D.heartbeat("tables")
     n_rays = int(args.rays)
     emission = args.emission or ("agss09-device" if args.mode == "mass" else "primakoff")
     if args.mode == "angular":
@@ -170,6 +171,7 @@ def main():
             fixed64 = args.accumulation == "fixed64"
             rt.set_accumulation_mode(args.accumulation)
             for i, x in enumerate(xs):
+                D.heartbeat("point %d of %d" % (i + 1, len(xs)))
                 if args.mode == "angular":
                     rt.set_telescope_angles(float("nan"), float(x))
                 else:
