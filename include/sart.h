@@ -202,8 +202,10 @@ typedef struct sart_axion_t {
 /* Parameters of one trace call. */
 typedef struct sart_trace_params_t {
   uint64_t n_rays;         /* bufLen of traceAxionWrapper                               */
-  uint64_t seed;           /* Philox4x32-10 key (replaces randomize(299792458), :276); the six uniforms of a ray are a
-                              function of (seed, global ray id) only, see oracle/sart_oracle.c: sart_oracle_uniforms */
+  uint64_t seed;           /* Philox4x32-7 key (replaces randomize(299792458), :276); the six uniforms of a ray are a
+                              function of (seed, global ray id) only, see oracle/sart_oracle.c: sart_oracle_uniforms.  The
+                              mapping changed in ABI 5 (one seven-round block per ray, 32 / 21 / 22-bit fractions): the same
+                              (seed, id) names other rays than under ABI <= 4 - statistically equivalent, not identical */
   uint64_t ray_id_offset;  /* global id of ray 0 of this call: counter = offset + i      */
   uint32_t flags;          /* SART_CF_* bitset                                          */
   int32_t image_nx;        /* columns (x bins) of the focal-plane image, 256 in :2629    */

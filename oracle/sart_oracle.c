@@ -88,14 +88,17 @@ static inline real deg_to_rad(real d) { return d * RAD_PER_DEG; }
 static inline real rad_to_deg(real r) { return r / RAD_PER_DEG; }
 
 /* ------------------------------------------------------------------------------------------
- * RNG: Philox4x32-10 (Salmon et al., SC'11), key = (seed lo, seed hi),
- * counter = (ray id lo, ray id hi, block, 0).  The six uniforms of a ray are built from blocks 0 and 1
- * by mantissa fill, as Nim's rand(1.0) turns its 64 random bits into a float in [0, 1) — the high word
- * of u3 comes from a word stream shared by consecutive rays (see sart_oracle_uniforms).
+ * RNG: Philox4x32-7 (Salmon et al., SC'11: the fewest rounds that pass BigCrush), key = (seed lo, seed hi),
+ * counter = (ray id lo, ray id hi, 0, 0).  The six uniforms of a ray are cut out of that one block and of one
+ * word of a stream shared by consecutive rays (see sart_oracle_uniforms).  Round 6 of the HIP path went from ten
+ * rounds and two blocks per ray to this; the stream is a free parameter of the path (the reference draws from
+ * xoroshiro128+, sart_oracle_nim_rand_* below: parity with it is statistical), and this function IS its definition:
+ * the HIP kernel (sart_kernels.hip: uniforms_of) and this restatement must change together.
  * ---------------------------------------------------------------------------------------- */
-static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                 uint32_t k0, uint32_t k1, uint32_t out[4]) {
-  for (int round = 0; round < 10; ++round) {
+#define SART_PHILOX_ROUNDS 7
+static inline void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+  for (int round = 0; round < SART_PHILOX_ROUNDS; ++round) {
     uint64_t p0 = (uint64_t)0xD2511F53u * c0;
     uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -119,26 +122,24 @@ static inline double fill52(uint32_t hi, uint32_t lo) {
 }
 
 void sart_oracle_uniforms(uint64_t seed, uint64_t ray_id, double u[6]) {
-  /* Two counter blocks per ray (256 bits) + one word of the shared stream serve the six uniforms: the two CDF draws
-   * (u2 radius, u5 energy) and the disc angle (u4) are filled with 52 random mantissa bits like Nim's rand(1.0); the two
-   * angles of the solar point (u0, u1) and the disc radius (u3) get 44: a high word of their own and the 12 bits that a
-   * 52-bit fill leaves over in its low word (2^-44 of a turn = 3.6e-13 rad; no bit is used twice). */
-  uint32_t w0[4], w1[4];
-  philox4x32_10((uint32_t)ray_id, (uint32_t)(ray_id >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w0);
-  philox4x32_10((uint32_t)ray_id, (uint32_t)(ray_id >> 32), 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w1);
-  /* The high word of u3 (the uniform behind the radius of the point on the bore exit, :418) is word `ray_id` of a
+  /* One counter block (x, y, z, w) + one word s of the shared stream = 160 random bits for the six uniforms, none used twice:
+   * the two CDF draws (u2 radius, u5 energy) and the disc radius (u3) are 32-bit fractions, the two angles of the solar point
+   * (u0, u1) 21-bit ones, the disc angle (u4) a 22-bit one made of what the other two leave over in their words. */
+  uint32_t b[4];
+  philox4x32((uint32_t)ray_id, (uint32_t)(ray_id >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), b);
+  /* The word behind u3 (the uniform behind the radius of the point on the bore exit, :418) is word `ray_id` of a
    * word stream with random access: stream[n] = word (n & 3) of the block with counter (n >> 2, 3, 0).  Four
    * consecutive rays share that block, which is what lets the HIP kernel's first stage (rays that this word alone
    * proves dead) cost a quarter of a Philox block per ray. */
   uint32_t sh[4];
   const uint64_t g = ray_id >> 2;
-  philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), 3u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), sh);
-  u[2] = fill52(w0[0], w0[1]);
-  u[5] = fill52(w0[2], w0[3]);
-  u[0] = fill52(w1[0], w0[1] << 20);
-  u[1] = fill52(w1[1], w0[3] << 20);
-  u[4] = fill52(w1[2], w1[3]);
-  u[3] = fill52(sh[ray_id & 3u], w1[3] << 20);
+  philox4x32((uint32_t)g, (uint32_t)(g >> 32), 3u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), sh);
+  u[2] = fill52(b[0], 0u);
+  u[5] = fill52(b[2], 0u);
+  u[0] = fill52(b[1] & 0xFFFFF800u, 0u);
+  u[1] = fill52(b[3] & 0xFFFFF800u, 0u);
+  u[4] = fill52((b[1] << 21) | ((b[3] & 0x7FFu) << 10), 0u);
+  u[3] = fill52(sh[ray_id & 3u], 0u);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -36,9 +36,10 @@ typedef struct sart_oracle_tables_t {
   const double* gas_abs_x; const double* gas_abs_y; int32_t n_gas_abs; int32_t _pad3;
 } sart_oracle_tables_t;
 
-/* The six uniforms of ray `ray_id` (Philox4x32-10, key = seed, counter = (id, block), blocks 0 and 1: 52 random mantissa
- * bits for the CDF draws u2, u5 and the disc angle u4, 44 for u0, u1, u3; the high word of u3 is word `ray_id` of a word
- * stream shared by consecutive rays: counter = (id >> 2, 3), word id & 3). */
+/* The six uniforms of ray `ray_id` (Philox4x32-7, key = seed, counter = (id, 0, 0): ONE block (x, y, z, w) + word `ray_id` s of a
+ * word stream shared by consecutive rays - counter = (id >> 2, 3, 0), word id & 3 -: u2 = x / 2^32, u5 = z / 2^32 (the CDF draws),
+ * u3 = s / 2^32 (disc radius), u0 = (y >> 11) / 2^21, u1 = (w >> 11) / 2^21 (solar point), u4 = the low 11 bits of y and w as a
+ * 22-bit fraction (disc angle).  This is the stream's definition; the HIP kernel's uniforms_of computes the same bits. */
 void sart_oracle_uniforms(uint64_t seed, uint64_t ray_id, double u[6]);
 
 /* traceAxion for one ray given its uniforms; *res must be zero-initialised by the caller

@@ -11,7 +11,7 @@
 //   * mirror hits use the cancellation-free form of the same quadratic roots; the reflection
 //     v cos2a - (v x axis) sin2a (:778-779) is evaluated algebraically (no asin/sin/cos), and on a
 //     hit the surface normals reduce to closed forms without a square root;
-//   * a Philox4x32-10 counter block per ray (key = seed, counter = global ray id) replaces the
+//   * a Philox4x32-7 counter block per ray (key = seed, counter = global ray id) replaces the
 //     reference's shared xoroshiro stream, draw order as in the reference;
 //   * the path is split where most rays die (bore, pipes, spider, glass fronts: ~2/3 of all rays for
 //     BabyIAXO) into three stages that each run on full waves: A0 (one Philox block: rays that the
@@ -37,14 +37,18 @@
 namespace sart {
 
 // ------------------------------------------------------------------------------------------------
-// Philox4x32-10
+// Philox4x32-7 (Salmon et al., SC'11: seven rounds are the fewest that pass BigCrush; ten are the paper's default with margin).
+// Round 6 went from ten rounds and two blocks per ray to seven rounds and one block per ray (uniforms_of): the counter RNG was a
+// quarter of the ray kernel's vector instructions, and v_mad_u64_u32 is not a full-rate one.  The stream is a free parameter of
+// the path (the reference draws from xoroshiro128+; parity with it is statistical, tests/test_gpu_parity.py: independent streams).
 // ------------------------------------------------------------------------------------------------
 struct U4 { uint32_t x, y, z, w; };
+constexpr int kPhiloxRounds = 7;
 
-__device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                            uint32_t k1) {
+__device__ __forceinline__ U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                         uint32_t k1) {
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < kPhiloxRounds; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0;   // one v_mad_u64_u32 yields both halves
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
@@ -63,7 +67,7 @@ __device__ __forceinline__ U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c
 // Word n of the shared word stream behind the high word of u3: word (n & 3) of the Philox block with counter
 // (n >> 2, 3, 0).  Four consecutive ray ids share one block (stage A0 computes it once per lane for four rays).
 __device__ __forceinline__ U4 stream_block(uint64_t group, uint32_t k0, uint32_t k1) {
-  return philox4x32_10((uint32_t)group, (uint32_t)(group >> 32), 3u, 0u, k0, k1);
+  return philox4x32((uint32_t)group, (uint32_t)(group >> 32), 3u, 0u, k0, k1);
 }
 __device__ __forceinline__ uint32_t word_of(const U4& b, uint32_t k) {
   return k == 0u ? b.x : (k == 1u ? b.y : (k == 2u ? b.z : b.w));
@@ -898,22 +902,25 @@ __device__ __forceinline__ bool phase_a_core(const HotA& H, const DevParams& P, 
   return phase_a_telescope<FAST, ROT>(H, P, tel_rot_of(P), L, br, st, radial_out, M);
 }
 
-// Phase A of the ray with global id `ray_id`: its six uniforms from TWO Philox counter blocks (256 bits) + its word of the
-// shared stream (sart_oracle_uniforms): the two CDF draws (u2, u5) and the disc angle (u4) have 52 random mantissa bits, the
-// two angles of the solar point (u0, u1) and the disc radius (u3) 44: a high word of their own + the 12 bits the 52-bit fills
-// leave over in a word.  u3_hi = word ray_id of the shared stream.
+// Phase A of the ray with global id `ray_id`: its six uniforms from ONE Philox counter block (x, y, z, w) + its word s of the
+// shared stream (sart_oracle_uniforms) - 160 random bits, none used twice:
+//   u2 (radius CDF draw)  = x / 2^32            u5 (energy CDF draw) = z / 2^32          u3 (disc radius) = s / 2^32
+//   u0 (solar point, theta1) = (y >> 11) / 2^21    u1 (theta2) = (w >> 11) / 2^21
+//   u4 (disc angle) = ((y & 0x7FF) << 11 | (w & 0x7FF)) / 2^22
+// 2^-21 of a turn is 3e-6 rad of position on a source 4.6e-3 rad wide seen from the magnet; 2^-22 of a turn on the bore-exit disc
+// is under a micrometre of arc; the CDF draws resolve 2^-32 where the tables' entries are 5e-4 (radius) and ~7e-4 (energy) apart.
+// u3_hi = word ray_id of the shared stream.
 __device__ __forceinline__ Uniforms uniforms_of(uint32_t seed_lo, uint32_t seed_hi, uint64_t ray_id, uint32_t u3_hi) {
   const uint32_t id_lo = (uint32_t)ray_id, id_hi = (uint32_t)(ray_id >> 32);
-  const U4 b0 = philox4x32_10(id_lo, id_hi, 0u, 0u, seed_lo, seed_hi);
-  const U4 b1 = philox4x32_10(id_lo, id_hi, 1u, 0u, seed_lo, seed_hi);
+  const U4 b0 = philox4x32(id_lo, id_hi, 0u, 0u, seed_lo, seed_hi);
   Uniforms U;
-  U.u2 = u52(b0.x, b0.y);
-  U.u2_hi = b0.x;   // (hi:lo) >> 12 is u2's 52-bit integer; its upper 32 bits are the word itself
-  U.u5 = u52(b0.z, b0.w);
-  U.u0 = u52(b1.x, b0.y << 20);
-  U.u1 = u52(b1.y, b0.w << 20);
-  U.u4 = u52(b1.z, b1.w);
-  U.u3 = u52(u3_hi, b1.w << 20);
+  U.u2 = u52(b0.x, 0u);
+  U.u2_hi = b0.x;   // floor(u2 2^32) is the word itself
+  U.u5 = u52(b0.z, 0u);
+  U.u0 = u52(b0.y & 0xFFFFF800u, 0u);
+  U.u1 = u52(b0.w & 0xFFFFF800u, 0u);
+  U.u4 = u52((b0.y << 21) | ((b0.w & 0x7FFu) << 10), 0u);
+  U.u3 = u52(u3_hi, 0u);
   return U;
 }
 template <bool FAST, int ROT, bool ZEXT, bool NOWALL = false>

@@ -237,9 +237,10 @@ transversalShift = 0.0
 
 
 def test_ray_uniforms_are_uniform_and_uncorrelated():
-    """The six uniforms of a ray (Philox4x32-10 blocks keyed by seed and ray id; the high word of u3 from the word stream
-    that four consecutive rays share) behave like independent U[0,1) samples: moments, lag correlations along the ray id
-    (including inside a group of four rays that share a stream block), cross-correlations, and a chi-square of u3."""
+    """The six uniforms of a ray (one Philox4x32-7 block keyed by seed and ray id, cut into 32 / 21 / 22-bit fractions; u3 from
+    the word stream that four consecutive rays share) behave like independent U[0,1) samples: moments, lag correlations along the
+    ray id (including inside a group of four rays that share a stream block), cross-correlations - among them u0 / u4 and u1 / u4,
+    which are cut out of the same two words -, and a chi-square of u3."""
     import ctypes as C
     from oracle import oracle as O
     lib = O.load("f64")
@@ -261,9 +262,19 @@ def test_ray_uniforms_are_uniform_and_uncorrelated():
     # rays 4g .. 4g+3 take the four words of one block for the high word of u3: pairwise correlation inside the groups
     g = u[: n // 4 * 4, 3].reshape(-1, 4)
     assert np.abs(np.corrcoef(g.T) - np.eye(4)).max() < 2.0 * tol
-    hist, _ = np.histogram(u[:, 3], bins=256, range=(0.0, 1.0))
-    chi2 = ((hist - n / 256.0) ** 2 / (n / 256.0)).sum()
-    assert chi2 < 255.0 + 5.0 * np.sqrt(2.0 * 255.0)
+    for k in range(6):
+        hist, _ = np.histogram(u[:, k], bins=256, range=(0.0, 1.0))
+        chi2 = ((hist - n / 256.0) ** 2 / (n / 256.0)).sum()
+        assert chi2 < 255.0 + 5.0 * np.sqrt(2.0 * 255.0), (k, chi2)
+    # the cut of the 160 bits: 32-bit fractions for the CDF draws and the disc radius, 21 bits for the solar point's angles, 22 for
+    # the disc angle (the bits the other two leave over in their words: jointly uniform with each of them)
+    for k, bits in ((2, 32), (5, 32), (3, 32), (0, 21), (1, 21), (4, 22)):
+        scaled = u[:, k] * 2.0 ** bits
+        assert (scaled == np.floor(scaled)).all() and not (u[:, k] * 2.0 ** (bits - 1) == np.floor(u[:, k] * 2.0 ** (bits - 1))).all(), (k, bits)
+    for a, b in ((0, 4), (1, 4), (2, 5), (0, 1)):
+        h2, _, _ = np.histogram2d(u[:, a], u[:, b], bins=16, range=((0, 1), (0, 1)))
+        chi2 = ((h2 - n / 256.0) ** 2 / (n / 256.0)).sum()
+        assert chi2 < 255.0 + 5.0 * np.sqrt(2.0 * 255.0), (a, b, chi2)
     # different seeds and far-apart ids give different streams; the same (seed, id) the same numbers
     lib.sart_oracle_uniforms(12345, 7_000_000_001, buf)
     assert list(buf) == list(u[0])

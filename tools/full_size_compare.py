@@ -10,7 +10,7 @@ from oracle.oracle import Oracle
 ap = argparse.ArgumentParser()
 ap.add_argument("--rays", type=float, default=1e9)
 ap.add_argument("--chunk", type=float, default=2.5e8, help="rays per oracle call (progress lines in between)")
-ap.add_argument("--workload", default="babyiaxo_xmm", choices=["babyiaxo_xmm", "cast_llnl_gold", "babyiaxo_xmm_rot", "babyiaxo_xmm_gas"],
+ap.add_argument("--workload", default="babyiaxo_xmm", choices=["babyiaxo_xmm", "cast_llnl_gold", "cast_llnl", "cast_abrixas", "babyiaxo_xmm_rot", "babyiaxo_xmm_gas"],
                 help="BASELINE configs[2] / configs[1] / one angle bin of configs[3] (rotated, 100 mm chip, effective-area flags) / configs[4]'s gas stage")
 args = ap.parse_args()
 n, chunk = int(args.rays), int(args.chunk)
@@ -20,6 +20,10 @@ if args.workload == "babyiaxo_xmm":
     full = sa.initFullSetup()
 elif args.workload == "cast_llnl_gold":
     full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL, reflectivity="gold")
+elif args.workload == "cast_llnl":          # the reference's own LLNL pairing: four multilayer coatings by shell group (raytracer.nim:1164-1187)
+    full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL)
+elif args.workload == "cast_abrixas":       # raytracer.nim:1320-1346
+    full = sa.initFullSetup(L.ES_CAST, L.DK_INGRID2017, L.SK_VACUUM, L.TK_ABRIXAS)
 elif args.workload == "babyiaxo_xmm_gas":
     full = sa.initFullSetup(stage=L.SK_GAS)
 else:

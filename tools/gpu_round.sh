@@ -24,7 +24,7 @@ for STEP in "$@"; do
     pmc)
       (cd $ROOT && timeout -k 10 900 bash tools/pmc_profile.sh ${TAG}_babyiaxo_xmm --workload babyiaxo_xmm) ;;
     pmc_side)
-      for W in cast_llnl_gold babyiaxo_xmm_gas babyiaxo_xmm_rot; do
+      for W in cast_llnl_gold cast_llnl babyiaxo_xmm_gas babyiaxo_xmm_rot; do
         (cd $ROOT && timeout -k 10 900 bash tools/pmc_profile.sh ${TAG}_$W --workload $W --rays-per-step 1e8)
       done ;;
     pmc_emission)
@@ -39,6 +39,8 @@ for STEP in "$@"; do
     fullsize)   # BASELINE configs[2] / [1] at full size through the HIP path and the f64 CPU oracle + the throughput table + metric 2
       (cd $ROOT && timeout -k 10 300 python tools/full_size_compare.py > gpurun_out/${TAG}_full_size_compare_1e9.json 2> gpurun_out/${TAG}_fsc.err) || { tail -20 $ROOT/gpurun_out/${TAG}_fsc.err; exit 1; }
       (cd $ROOT && timeout -k 10 200 python tools/full_size_compare.py --workload cast_llnl_gold --rays 1e8 > gpurun_out/${TAG}_full_size_compare_cast_1e8.json 2>> gpurun_out/${TAG}_fsc.err)
+      (cd $ROOT && timeout -k 10 200 python tools/full_size_compare.py --workload cast_llnl --rays 1e8 > gpurun_out/${TAG}_full_size_compare_cast_llnl_4coatings_1e8.json 2>> gpurun_out/${TAG}_fsc.err)
+      (cd $ROOT && timeout -k 10 200 python tools/full_size_compare.py --workload cast_abrixas --rays 1e8 > gpurun_out/${TAG}_full_size_compare_cast_abrixas_1e8.json 2>> gpurun_out/${TAG}_fsc.err)
       (cd $ROOT && timeout -k 10 200 python tools/full_size_compare.py --workload babyiaxo_xmm_rot --rays 1e8 > gpurun_out/${TAG}_full_size_compare_rot_1e8.json 2>> gpurun_out/${TAG}_fsc.err)
       (cd $ROOT && timeout -k 10 200 python tools/full_size_compare.py --workload babyiaxo_xmm_gas --rays 1e8 > gpurun_out/${TAG}_full_size_compare_gas_1e8.json 2>> gpurun_out/${TAG}_fsc.err)
       (cd $ROOT && timeout -k 10 200 python tools/throughput_table.py > gpurun_out/${TAG}_throughput_table.md 2>&1 && cat gpurun_out/${TAG}_throughput_table.md)

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
 WORKLOADS = {   # workload -> (rays per profiled launch, kernel-name substring)
-    "babyiaxo_xmm": (1e9, "trace_histogram"), "cast_llnl_gold": (1e8, "trace_histogram"), "babyiaxo_xmm_gas": (1e8, "trace_histogram"),
+    "babyiaxo_xmm": (1e9, "trace_histogram"), "cast_llnl_gold": (1e8, "trace_histogram"), "cast_llnl": (1e8, "trace_histogram"), "babyiaxo_xmm_gas": (1e8, "trace_histogram"),
     "babyiaxo_xmm_rot": (1e8, "trace_histogram"), "babyiaxo_xmm_gas_scan32": (1e9, "trace_histogram"),
     "babyiaxo_xmm_ascan16": (2e8, "trace_angular_scan"), "emission_table": (2952000.0, "emission_table_kernel"),
 }
