@@ -175,6 +175,9 @@ def roofline_block(workload: str, rays_per_launch: float, avg_kernel_s: float, n
            "valu_issue_utilisation": None, "valu_lane_utilisation": None, "valu_insts_per_64_rays": None, "f64_flop_per_ray": None,
            "l2_hit_rate": None, "build_id": lib_id, "pmc_build_id": None, "pmc_source": None,
            "reference_formulation_bytes_per_ray": ref_bytes_per_ray,
+           # SURVEY 8(d)'s own formula, evaluated as written: above 1 by construction of this design (see the note) - reported so
+           # that nobody has to recompute it, never as `frac`
+           "reference_formulation_frac_of_hbm_peak": ref_bytes_per_ray * rays_per_launch / avg_kernel_s / 1e9 / HBM_PEAK_GBS,
            "note": "bound: in cycles the kernel is nearest to the vector-issue wall (valu_issue_utilisation of the SIMDs' cycles "
                    "issue a vector instruction); the cycles themselves are rationed: with all 256 CUs in this kernel the power "
                    "management grants sclk_mhz of 2400 (128 CUs of the same kernel run at 2370, profiles/*_power_cu_mask.txt), so what "

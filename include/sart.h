@@ -28,7 +28,8 @@ extern "C" {
 #define SART_ABI_VERSION 5   /* 2: SART_ACC_COUNT 16 -> 24 (SUM_WEIGHTS_SQ_HI), fused mass scan, FIXED64 status;
                                 3: SART_ERR_ACCUMULATOR, fused angular scan, flux-only launches, accumulator roll-over;
                                 4: sart_trace_records_passed;
-                                5: sart_release_scratch (additive: a v4 caller runs unchanged) */
+                                5: sart_release_scratch (additive); the (seed, ray id) -> uniforms mapping changed
+                                   (Philox4x32-7, one block per ray): a v4 caller runs unchanged and gets other rays */
 #define SART_MAX_SHELLS 64
 #define SART_MAX_COATINGS 8
 
@@ -450,7 +451,8 @@ int sart_trace_histogram_spectra(sart_context* ctx, const sart_trace_params_t* p
  *            finalize internally) examine the raw accumulator and record what they find in a status word of the context;
  *            the next sart_synchronize - and every blocking host-output call - returns SART_ERR_ACCUMULATOR for it:
  *              unresolved  the accumulated weights average below 2^12 quanta per passed ray (an outlier in a table inflated
- *                          the bound): use a smaller headroom.  Squared weights that average below 2^6 quanta are not an
+ *                          the bound): use a smaller headroom.  Judged once 256 rays have passed (the average of a handful
+ *                          of faint rays says nothing about the bound; each of them is still exact to half a quantum).  Squared weights that average below 2^6 quanta are not an
  *                          error - SUM_WEIGHTS_SQ (an error estimate; nothing else depends on it) then reads NaN.
  *              wrapped     a slot is negative or >= 2^62, or the pixels (plus SUM_WEIGHTS_OUTSIDE), the radial weight bins or
  *                          the energy weight bins do not add up to SUM_WEIGHTS - every passed ray adds the same integer to
@@ -595,7 +597,12 @@ int sart_finalize_angular_scan_device(sart_context* ctx, const sart_trace_params
  * Sum the fused accumulators of n contexts (one per GPU of this process) into the one of contexts[root]:
  * a single RCCL ncclReduce(ncclSum) of n_doubles 8-byte elements over xGMI (grouped over the devices): f64 elements, or
  * int64 when the contexts are in SART_ACCUM_FIXED64 mode (all of them must be in the same mode).
- * accumulators_device[i] must live on the device of contexts[i].  Blocking.  n == 1 is a no-op.
+ * accumulators_device[i] must live on the device of contexts[i].  Blocking.  n == 1 waits for the context's stream and returns
+ * (one accumulator: nothing to add up, no RCCL call).  librccl is loaded at the first call with n > 1 (dlopen: the library has
+ * no link-time dependency on it); one communicator set per ordered device list is created on first use (ncclCommInitAll) and
+ * kept for the life of the process; a collective that fails drops its communicators (SART_ERR_INTERNAL with RCCL's message), the
+ * next call builds new ones.  In SART_ACCUM_FIXED64 the two-limb sums (SUM_WEIGHTS, ...: hi 2^40 + lo) add limb by limb without
+ * carrying - the same integers in another representation; sart_finalize_accumulator_device reads either.
  * A host that runs one process per GPU (e.g. under MPI / torchrun) reduces with its own communicator instead
  * (bench.py: torch.distributed, backend "nccl" = RCCL).  Returns SART_ERR_UNSUPPORTED if librccl cannot be loaded.
  */

@@ -2450,8 +2450,13 @@ __device__ __forceinline__ void fixed_status_check_slot(long long v, uint32_t* s
 // Returns false if the squared weights average below 2^6 quanta per passed ray: the integers do not resolve them (their quantum
 // 2^-39 of the squared weight bound is as fine as an int64 per workgroup allows); SUM_WEIGHTS_SQ - an error estimate, nothing
 // else depends on it - then reads NaN in the f64 output instead of a number that looks like one.
+// Both means are judged only once kFixedMinRaysForMeans rays have passed: the check is there to catch a weight BOUND that is off by
+// orders of magnitude (an outlier in a table), and the average of a handful of rays says nothing about that - one faint ray alone
+// in an accumulator (a launch of a single low-energy CAST ray, weight 1e-8 of the bound) is exact to half a quantum like every
+// other and no reason to fail the call (found by the round-6 stream: ray 0 of seed 5 is such a ray).
+constexpr double kFixedMinRaysForMeans = 256.0;
 __device__ __forceinline__ bool fixed_status_check_means(double quanta_w, double quanta_w2, double n_passed, uint32_t* status) {
-  if (!(n_passed > 0.0)) return true;
+  if (!(n_passed >= kFixedMinRaysForMeans)) return true;
   if (quanta_w < 4096.0 * n_passed) atomicOr(status, kFixedStatusUnresolved);
   return quanta_w2 >= 64.0 * n_passed;
 }
@@ -2575,8 +2580,8 @@ __global__ __launch_bounds__(64) void finalize_scan_kernel(const long long* in, 
     const double n_passed = (double)v[SART_SCAN_N_PASSED];
     bool w_ok = true, sq_ok;
     if (F.counter_slots >> 31) {
-      w_ok = !(n_passed > 0.0) || sw >= 4096.0 * n_passed;
-      sq_ok = !(n_passed > 0.0) || sw2 >= 64.0 * n_passed;
+      w_ok = !(n_passed >= kFixedMinRaysForMeans) || sw >= 4096.0 * n_passed;
+      sq_ok = !(n_passed >= kFixedMinRaysForMeans) || sw2 >= 64.0 * n_passed;
     } else {
       sq_ok = fixed_status_check_means(sw, sw2, n_passed, status);
     }

@@ -519,3 +519,24 @@ def test_fixed64_rollover_limbs_carry_an_accumulation_past_the_headroom():
     lit = coarse[:k0] > 1e-3 * coarse[:k0].max()
     assert np.abs(fine[:k0][lit] / coarse[:k0][lit] - 1.0).max() < 1e-6      # (the coarse run's own rounding: 2^-23 of the bound per ray)
     assert fine[:k0].sum() == pytest.approx(fine[k0 + L.ACC["SUM_WEIGHTS"]], rel=1e-12)
+
+
+def test_a_handful_of_faint_rays_is_not_an_unresolved_accumulator():
+    """Found by the round-6 stream: a launch of ONE ray into a fresh FIXED64 accumulator (the first piece of the four-launch split
+    above) whose ray happens to pass with a weight of 1e-8 of the bound averaged below 2^12 quanta per passed ray, and the blocking
+    call failed with SART_ERR_ACCUMULATOR.  The mean is judged once 256 rays have passed; below that every ray is still exact to
+    half a quantum.  Every single-ray launch of the first 300 CAST ray ids runs, and equals the f64 launch to half a quantum."""
+    full = full_setup("cast_llnl_gold")
+    with sa.RayTracer(full) as rt:
+        rt.set_accumulation_mode("f64")
+        ref = [rt.trace_flux(1, seed=5, ray_id_offset=i) for i in range(300)]
+        rt.set_accumulation_mode("fixed64")
+        got = [rt.trace_flux(1, seed=5, ray_id_offset=i) for i in range(300)]
+        q = rt.fixed_quanta()["weight"]
+    passed = [i for i in range(300) if ref[i]["N_PASSED"] == 1]
+    assert len(passed) > 200
+    for i in range(300):
+        assert got[i]["N_PASSED"] == ref[i]["N_PASSED"]
+        assert abs(got[i]["SUM_WEIGHTS"] - ref[i]["SUM_WEIGHTS"]) <= 0.5 * q * (1 + 1e-9)
+    faint = [i for i in passed if ref[i]["SUM_WEIGHTS"] < 4096 * q]
+    assert faint, "no single ray below 2^12 quanta among these ids: pick other ids"

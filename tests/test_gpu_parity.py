@@ -63,7 +63,18 @@ def test_records_match_long_double_oracle_tightly(name):
     with sa.RayTracer(full) as rt:
         rec = rt.traceAxionWrapper(N_REC, seed=43)
     ref = Oracle(full, "ld").trace_records(N_REC, seed=43)
-    compare_records(rec, _as_gold(ref), 5e-6, 1e-6, 5e-5)
+    # 5e-6 mm, with room for the 80-bit build's own rare outliers (its formulation is the reference's: differences of 1e14-mm
+    # points; one ray in ~1e5 lands at 1e-5 mm - Abrixas, seed 43 of the round-6 stream): at most one ray per 5e4 up to 5e-5 mm,
+    # and every such ray must agree with the binary128 build to 1e-10 mm - the noise is the oracle's, not the path's
+    compare_records(rec, _as_gold(ref), 5e-6, 1e-6, 5e-5, pos_outliers=2e-5)
+    both = (rec["passed"] == 1) & (ref["passed"] == 1)
+    off = np.zeros(len(rec), dtype=bool)
+    for f in ("pointdataX", "pointdataY", "pointdataR", "pointdataXBefore", "pointdataYBefore"):
+        off |= both & (np.abs(rec[f] - ref[f]) >= 5e-6)
+    if off.any():
+        exact = Oracle(full, "q").trace_records(N_REC, seed=43)
+        for f in ("pointdataX", "pointdataY", "pointdataR", "pointdataXBefore", "pointdataYBefore"):
+            assert np.abs(rec[f][off] - exact[f][off]).max() < 1e-10, (f, np.flatnonzero(off))
     # every field of every record, including rays that did not pass (zero-initialised like newSeq[Axion])
     dead = (rec["passed"] == 0) & (ref["passed"] == 0)
     # (a ray may reach the end with weight == 0, e.g. behind the strongback: fields set, `passed` false)
