@@ -32,6 +32,7 @@ void launch_finalize_fixed(const void* in, const void* hi, double* out, size_t n
                            double q_w2, double q_pos, double q_refl, void* check_dev, hipStream_t stream);
 void launch_rollover_fixed(void* acc, void* hi, size_t n, void* check_dev, hipStream_t stream);
 size_t fixed_check_bytes();
+std::string fixed_check_describe(const void* host_copy);
 bool launch_trace_mass_scan(const HotA& H, const HotB& HB, const DevBlob* blob, const TraceArgs& A, const ScanArgs& SC, double* rows,
                             double* shared_row, int n_blocks, hipStream_t stream, int variant, bool fixed);
 void launch_finalize_scan(const void* in, double* out, int n_masses, const double* q_w, const double* q_w2, int shared_row,
@@ -906,7 +907,8 @@ struct TimedLaunch {
 int status_ensure(sart_context* c) {
   if (!c->d_status.p) {
     if (int rc = c->d_status.resize(fixed_check_bytes())) return rc;
-    SART_HIP(hipMemset(c->d_status.p, 0, fixed_check_bytes()));
+    // (on the context's stream: a memset on the null stream is not ordered with launches on a non-blocking stream)
+    SART_HIP(hipMemsetAsync(c->d_status.p, 0, fixed_check_bytes(), c->stream));
   }
   if (!c->h_status) {
     SART_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_status), 4 * sizeof(uint32_t), hipHostMallocDefault));
@@ -929,8 +931,13 @@ int status_take(sart_context* c) {   // the stream has been synchronised
   std::string msg = "FIXED64:";
   if (st & 1u) msg += " a slot of the accumulator is negative or >= 2^62 - it wrapped, or is about to (more bound-weight rays on one pixel "
                       "/ bin than 2^headroom_bits: use a larger headroom, or finalize and start a new accumulator earlier);";
-  if (st & 4u) msg += " the pixels / radial / energy bins of the accumulator do not add up to its SUM_WEIGHTS: a slot wrapped since the accumulator "
-                      "was zeroed (use a larger headroom, or finalize and start a new accumulator earlier);";
+  if (st & 4u) {
+    msg += " the pixels / radial / energy bins of the accumulator do not add up to its SUM_WEIGHTS: a slot wrapped since the accumulator "
+           "was zeroed (use a larger headroom, or finalize and start a new accumulator earlier)";
+    std::vector<uint8_t> copy(fixed_check_bytes());   // the sums of the finalize that failed (only read on this path)
+    if (hipMemcpy(copy.data(), c->d_status.p, copy.size(), hipMemcpyDeviceToHost) == hipSuccess) msg += fixed_check_describe(copy.data());
+    msg += ";";
+  }
   if (st & 2u) msg += " the accumulated weights average below 2^12 quanta per passed ray (bound " + std::to_string(c->weight_bound) +
                       ": an outlier in a table inflated it) - choose a smaller headroom or SART_ACCUM_F64;";
   return fail(SART_ERR_ACCUMULATOR, msg);
@@ -1676,7 +1683,9 @@ int sart_trace_histogram_device(sart_context* c, const sart_trace_params_t* p, d
       if (reps.n != need || !reps.p) {
         SART_HIP(hipStreamSynchronize(c->stream));
         if (int rc = reps.resize(need)) return rc;
-        SART_HIP(hipMemset(reps.p, 0, need * sizeof(double)));
+        // (on the context's stream, in front of the launch that adds into them: a memset on the null stream is not ordered with
+        // launches on a non-blocking stream)
+        SART_HIP(hipMemsetAsync(reps.p, 0, need * sizeof(double), c->stream));
       }
       a.replicas = reps.p;
       a.replica_mask = static_cast<uint32_t>(R - 1);

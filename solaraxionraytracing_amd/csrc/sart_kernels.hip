@@ -2420,6 +2420,9 @@ struct FixedCheck {
   long long want_in_lo, want_in_hi;                         // SUM_WEIGHTS - SUM_WEIGHTS_OUTSIDE
   long long want_lo, want_hi;                               // SUM_WEIGHTS
   long long spectra;
+  // (not zeroed per finalize) the sums of the FIRST finalize whose conservation check failed, for the error message: which sum is
+  // off, in which direction and by how much says whether a slot wrapped (a multiple of 2^64 quanta) or an update went astray
+  long long fail[10];                                       // pix, want_in, rad, en, want: (lo, hi) each
 };
 __device__ __forceinline__ void fixed_check_add(long long v, long long v_hi, bool mine, long long* lo_dst, long long* hi_dst) {
   constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
@@ -2442,7 +2445,13 @@ __global__ void fixed_check_kernel(FixedCheck* C) {
   };
   bool ok = same(C->pix_lo, C->pix_hi, C->want_in_lo, C->want_in_hi);
   if (C->spectra) ok = ok && same(C->rad_lo, C->rad_hi, C->want_lo, C->want_hi) && same(C->en_lo, C->en_hi, C->want_lo, C->want_hi);
-  if (!ok) atomicOr(&C->status, kFixedStatusNotConserved);
+  if (!ok) {
+    if (!(C->status & kFixedStatusNotConserved)) {
+      const long long v[10] = {C->pix_lo, C->pix_hi, C->want_in_lo, C->want_in_hi, C->rad_lo, C->rad_hi, C->en_lo, C->en_hi, C->want_lo, C->want_hi};
+      for (int i = 0; i < 10; ++i) C->fail[i] = v[i];
+    }
+    atomicOr(&C->status, kFixedStatusNotConserved);
+  }
 }
 __device__ __forceinline__ void fixed_status_check_slot(long long v, uint32_t* status) {
   if (v < 0 || v >= (1ll << 62)) atomicOr(status, kFixedStatusWrapped);
@@ -2904,6 +2913,22 @@ void launch_trace_angular_scan(const HotA& H, const HotB& HB, const DevBlob* blo
 }
 
 size_t fixed_check_bytes() { return sizeof(FixedCheck); }
+// "pixels 123 + 456 x 2^40 quanta, wanted ..." from a host copy of the context's FixedCheck (the error message of a failed
+// conservation check, sart_api.hip: status_take)
+std::string fixed_check_describe(const void* host_copy) {
+  const FixedCheck& C = *static_cast<const FixedCheck*>(host_copy);
+  constexpr long long kMask = (1ll << kFixedLimbBits) - 1;
+  auto norm = [&](long long lo, long long hi, long long& nlo, long long& nhi) { nhi = hi + (lo >> kFixedLimbBits); nlo = lo & kMask; };
+  const char* names[5] = {"pixels", "SUM_WEIGHTS - outside", "radial bins", "energy bins", "SUM_WEIGHTS"};
+  std::string s = " [quanta as lo + hi x 2^40:";
+  for (int i = 0; i < 5; ++i) {
+    if ((i == 2 || i == 3) && !C.spectra) continue;
+    long long lo, hi;
+    norm(C.fail[2 * i], C.fail[2 * i + 1], lo, hi);
+    s += std::string(i ? "," : "") + " " + names[i] + " " + std::to_string(lo) + " + " + std::to_string(hi);
+  }
+  return s + "]";
+}
 void launch_rollover_fixed(void* acc, void* hi, size_t n, void* check_dev, hipStream_t stream) {
   hipLaunchKernelGGL(rollover_fixed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, static_cast<long long*>(acc),
                      static_cast<long long*>(hi), (long long)n, static_cast<FixedCheck*>(check_dev));
@@ -2913,7 +2938,7 @@ void launch_finalize_fixed(const void* in, const void* hi, double* out, size_t n
   FinalizeArgs F{(long long)n_img, spectra, n_radial_bins, n_energies1, 0, q_w, q_w2, q_pos, q_refl};
   const size_t total = n_img + SART_ACC_COUNT + (spectra ? 2 * (size_t)n_radial_bins + 3 * (size_t)n_energies1 : 0);
   FixedCheck* const C = static_cast<FixedCheck*>(check_dev);
-  (void)hipMemsetAsync(reinterpret_cast<char*>(C) + 8, 0, sizeof(FixedCheck) - 8, stream);   // everything but the status word
+  (void)hipMemsetAsync(reinterpret_cast<char*>(C) + 8, 0, offsetof(FixedCheck, fail) - 8, stream);   // everything but the status word and the failure record
   hipLaunchKernelGGL(finalize_fixed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                      reinterpret_cast<const long long*>(in), reinterpret_cast<const long long*>(hi), out, F, C);
   hipLaunchKernelGGL(fixed_check_kernel, dim3(1), dim3(1), 0, stream, C);
