@@ -234,10 +234,20 @@ def test_scan_flags_accumulation_and_errors():
     ms = masses(5)
     with sa.RayTracer(full) as rt:
         # ignoreConvProb: the mass no longer matters
+        # (f64: every mass adds the same weights, but the sixteen waves of a workgroup reach a mass's LDS cells in an order of their
+        # own per mass - equal up to the summation order, 1e-15 per DESIGN.md 3.1; the demand for identical bits held by luck until
+        # the round-6 stream shifted the timing.  FIXED64: integers - identical to the last bit)
         pm, _ = rt.trace_mass_scan(ms, 500_000, seed=2, flags=L.CF_IGNORE_CONV_PROB)
-        assert np.all(pm["SUM_WEIGHTS"] == pm["SUM_WEIGHTS"][0]) and pm["SUM_WEIGHTS"][0] > 0
+        assert pm["SUM_WEIGHTS"][0] > 0
+        np.testing.assert_allclose(pm["SUM_WEIGHTS"], pm["SUM_WEIGHTS"][0], rtol=1e-13)
+        assert np.all(pm["N_PASSED"] == pm["N_PASSED"][0])
         want = rt.trace_histogram(500_000, seed=2, flags=L.CF_IGNORE_CONV_PROB)[1]
         assert pm["SUM_WEIGHTS"][0] == pytest.approx(want["SUM_WEIGHTS"], rel=1e-12) and pm["N_PASSED"][0] == want["N_PASSED"]
+        rt.set_accumulation_mode("fixed64")
+        pmx, _ = rt.trace_mass_scan(ms, 500_000, seed=2, flags=L.CF_IGNORE_CONV_PROB)
+        assert np.all(pmx["SUM_WEIGHTS"] == pmx["SUM_WEIGHTS"][0]) and np.all(pmx["SUM_WEIGHTS_SQ"] == pmx["SUM_WEIGHTS_SQ"][0])
+        assert pmx["SUM_WEIGHTS"][0] == pytest.approx(want["SUM_WEIGHTS"], rel=1e-9)
+        rt.set_accumulation_mode("f64")
         # no rays: zeros
         pm, sh = rt.trace_mass_scan(ms, 0, seed=2)
         assert not pm["SUM_WEIGHTS"].any() and sh["N_RAYS"] == 0
