@@ -83,6 +83,9 @@ def parse():
                     help="fixed64: bits of headroom (0 = the library's default, 27: one accumulator then lasts ~1e12 BabyIAXO rays; "
                          "31 carries 2.6e12, profiles/r04_v48_fixed64_long_run.txt)")
     ap.add_argument("--profile-run", action="store_true", help="no CPU baseline / side workloads (run under rocprofv3)")
+    ap.add_argument("--no-proof", action="store_true",
+                    help="skip the FIXED64 bitwise proof behind the timed region (counter profiles: its 2e8-ray launches of the same "
+                         "kernel would be averaged into the profiled ones, tools/pmc_summary.py)")
     ap.add_argument("--emit-bitwise-constants", metavar="PATH", default=None,
                     help="one GPU: write the FIXED64 reference image's SHA-256, integer flux and the hash of the input tables to PATH "
                          "(the committed copy is tests/golden/bench_bitwise_fixed64.json; a --gpus N run holds its reduced image to it)")
@@ -507,7 +510,7 @@ def main():
     # the result, not only the rate: a fixed id range traced by all ranks in FIXED64 against rank 0 alone (every rank takes part)
     D.heartbeat("bitwise proof")
     proof = None
-    if scan_masses is None and scan_angles is None and full.fluxRadiusCDF is not None:
+    if scan_masses is None and scan_angles is None and full.fluxRadiusCDF is not None and not args.no_proof:
         proof = bitwise_proof(rt, full, flags, rank, world, dev, seed, D, restore=(args.accumulation, args.headroom))
     proof_failed = False
 

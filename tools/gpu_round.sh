@@ -19,7 +19,7 @@ for STEP in "$@"; do
       (cd $ROOT && timeout -k 10 600 python bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err) || { tail -20 $ROOT/gpurun_out/bench_$TAG.err; exit 1; }
       cat $ROOT/gpurun_out/bench_$TAG.json | python3 -c "import json,sys; d=json.load(sys.stdin); print(d['value'], d['ms_per_step'], json.dumps(d['roofline'])[:600]); [print(w['workload'][:40], w.get('rays_per_s', w.get('cells_per_s'))) for w in d.get('other_workloads',[])]; print(d.get('cpu_baseline'))" ;;
     stats)
-      (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -- python3 $ROOT/bench.py --profile-run --steps 5 --warmup 2 > $ROOT/gpurun_out/prof_$TAG.log 2>&1) || { tail -20 $ROOT/gpurun_out/prof_$TAG.log; exit 1; }
+      (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -- python3 $ROOT/bench.py --profile-run --no-proof --steps 5 --warmup 2 > $ROOT/gpurun_out/prof_$TAG.log 2>&1) || { tail -20 $ROOT/gpurun_out/prof_$TAG.log; exit 1; }
       find $ROOT/gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1 | xargs head -5 ;;
     pmc)
       (cd $ROOT && timeout -k 10 900 bash tools/pmc_profile.sh ${TAG}_babyiaxo_xmm --workload babyiaxo_xmm) ;;

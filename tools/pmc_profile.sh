@@ -30,7 +30,7 @@ for P in "${PASSES[@]}"; do
   if [ -n "$PMC_PROGRAM" ]; then   # another program of this repository under the same passes (e.g. tools/emission_bench.py --no-cpu)
     rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/$PMC_PROGRAM "$@" > $OUT/pass$i.log 2>&1 || { echo "pass $i FAILED ($P)" >&2; tail -5 $OUT/pass$i.log >&2; exit 1; }
   else
-    rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --profile-run --steps 2 --warmup 1 "$@" > $OUT/pass$i.log 2>&1 || { echo "pass $i FAILED ($P)" >&2; tail -5 $OUT/pass$i.log >&2; exit 1; }
+    rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --profile-run --no-proof --steps 2 --warmup 1 "$@" > $OUT/pass$i.log 2>&1 || { echo "pass $i FAILED ($P)" >&2; tail -5 $OUT/pass$i.log >&2; exit 1; }
   fi
   echo "pass $i done: $P"
 done

@@ -26,7 +26,7 @@ i=0
 for P in "${PASSES[@]}"; do
   i=$((i+1))
   if [ -n "$PMC_PASSES" ] && ! echo " $PMC_PASSES " | grep -q " $i "; then continue; fi
-  if ! timeout -k 5 150 rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --profile-run --steps 2 --warmup 1 "$@" > $OUT/pass$i.log 2>&1; then
+  if ! timeout -k 5 150 rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python3 $ROOT/bench.py --profile-run --no-proof --steps 2 --warmup 1 "$@" > $OUT/pass$i.log 2>&1; then
     echo "pass $i FAILED ($P): tail of $OUT/pass$i.log" >&2
     tail -5 $OUT/pass$i.log >&2
     exit 1

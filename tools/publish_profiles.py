@@ -47,7 +47,7 @@ def main():
         dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
         big = [x for x in dur if x > 1.0]
         bench = json.load(open(b)) if os.path.exists(b) else {}
-        out = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --profile-run --steps 5 --warmup 2",
+        out = {"command": "rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --profile-run --no-proof --steps 5 --warmup 2",
                "build_id": bench.get("roofline", {}).get("build_id"), "kernel": rows[0]["Kernel_Name"][:100] if rows else None,
                "dispatch_durations_ms": [round(x, 4) for x in dur], "mean_ms_of_1e9_ray_dispatches": sum(big) / max(1, len(big)),
                "mean_ms_of_last_five": sum(big[-5:]) / max(1, len(big[-5:])),
