@@ -749,7 +749,9 @@ def angular_scan_rate(n: int = 200_000_000, host_loop_points: int = 4):
     full, flags = make_setup("babyiaxo_xmm_ascan16")
     angles = np.linspace(0.0, 0.3, SCAN_ANGLES)
     with sa.RayTracer(full) as rt:
-        rt.trace_angular_scan(angles, 20_000_000, seed=2, flags=flags)   # clocks up, tables in cache
+        rt.trace_angular_scan(angles, n, seed=2, flags=flags)   # clocks up, tables in cache (a launch of the timed size: behind a shorter
+                                                                # one the first timed launch runs below the clock of the second, and the
+                                                                # two-point cost model below charges the difference to t_shared)
         rt.enable_kernel_timing(True)
         t0 = time.perf_counter()
         per_angle, shared = rt.trace_angular_scan(angles, n, seed=1, flags=flags)
