@@ -107,3 +107,17 @@ def test_contexts_in_concurrent_threads_are_independent():
         assert len(together[n]) == len(alone[n])
         for a, b in zip(together[n], alone[n]):
             assert a == b, n
+
+
+def test_concurrent_contexts_stress_rounds():
+    """The case above 200 times over in a process of its own (tools/stress_threads.py).  Round 6: a fresh context zeroed its scratch
+    images with hipMemset - a null-stream operation that nothing orders with the trace kernel on the context's non-blocking stream;
+    with five other contexts keeping the device busy the zeroing could run after the first pixel atomics and wipe them: 5 of 2500
+    rounds failed the FIXED64 conservation check before the memsets moved onto the context's stream, 0 of 2500 after
+    (profiles/r06_stress_threads.txt)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_threads.py"), "200"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "0 of 200 rounds failed" in out.stdout, (out.stdout[-3000:], out.stderr[-1500:])
