@@ -117,6 +117,9 @@ int main(int argc, char** argv) {
       if (ax_buf[i].passed) passed_ok = memcmp(&only[k++], &ax_buf[i], sizeof *only) == 0;
     passed_ok = passed_ok && k == n_passed;
     free(only);
+    /* the record entries keep their device scratch in the context (it only grows); a host that is done with records hands it
+     * back (ABI 5) - the histogram and scan entries below do not use it */
+    CHECK(sart_release_scratch(ctx));
   }
 
   /* 4. the same rays through the fused histogram entry */
