@@ -126,35 +126,78 @@ def run_case(case, n, sa, L, Oracle, compare_records, full_size=False):
                 err = np.abs(rec[f][ok] / ref[f][ok] - 1.0)
                 env = np.abs(f64[f][ok] / ref[f][ok] - 1.0)
                 over = err > 2e-8
-                assert over.sum() <= max(3, 1e-3 * ok.sum()), (f, "rays beyond 2e-8", int(over.sum()), int(ok.sum()))
-                assert np.all(err[over] <= np.maximum(8.0 * env[over], 2e-7)), (f, err[over].tolist(), env[over].tolist())
+                # ... on at most 1e-3 of the rays, or a tenth as many as the f64 build of the reference's own formulas loses: near the
+                # resonance (m_a within a few per cent of m_gamma: q L small, and Gamma L small with it) the bracket 1 + e^(-GL) -
+                # 2 e^(-GL/2) cos(qL) cancels to (GL/2)^2 + (qL)^2 on EVERY ray, and that build is beyond 2e-8 on 30 - 80 % of all
+                # rays (median error 3e-8 ... 9e-8: cases 2762, 2846, 3545 of the extended campaign, and 494, 1673, 1202 as well),
+                # where the HIP path - the same formula with fused multiply-adds and its own exp / cos - is beyond it on 1.2 ... 1.5e-3
+                assert over.sum() <= max(3, 1e-3 * ok.sum(), 0.1 * (env > 2e-8).sum()), (f, "rays beyond 2e-8", int(over.sum()), int(ok.sum()),
+                                                                                        "f64 build beyond 2e-8", int((env > 2e-8).sum()))
+                bad = err[over] > np.maximum(8.0 * env[over], 2e-7)
+                if bad.any() and (env > 2e-8).mean() > 0.05:
+                    # the whole setup is ill-conditioned (near the resonance: see above), tens of rays are "over", and the ray-by-ray
+                    # envelope compares two draws per ray: 30 rays x P(ratio > 8) ~ 0.08 expects a few beyond it (case 2762: two).
+                    # Held instead to the f64 build's error DISTRIBUTION: the k-th worst ray of the HIP path no worse than twice
+                    # the k-th worst ray of that build (HIP 3.4e-5 against 8.5e-5 at k = 1 there)
+                    e_s, v_s = np.sort(err)[::-1][:int(over.sum())], np.sort(env)[::-1][:int(over.sum())]
+                    assert np.all(e_s <= np.maximum(2.0 * v_s, 2e-7)), (f, "order statistics", e_s[:10].tolist(), v_s[:10].tolist())
+                else:
+                    assert not bad.any(), (f, err[over].tolist(), env[over].tolist())
         flux = float(ref["weights"][ref["passed"] != 0].sum())
         only, cnt = rt.traceAxionWrapperPassed(n, seed=seed, ray_id_offset=off, flags=flags)
         assert (cnt["n_passed"], cnt["n_passed_till_window"], cnt["n_hit_nickel"]) == tuple(want.values())
         assert only.tobytes() == rec.view(np.uint8).reshape(n, 208)[rec["passed"] != 0].tobytes()
-        for mode in ("f64", "fixed64"):
-            rt.set_accumulation_mode(mode)
+        def doors_of(mode, headroom=0):
+            """Every accumulating door in one accumulation mode: counters exactly, sums against the binary128 records."""
+            rt.set_accumulation_mode(mode, headroom)
             doors = {"histogram": rt.trace_histogram(n, seed=seed, ray_id_offset=off, flags=flags)[1],
                      "flux only": rt.trace_flux(n, seed=seed, ray_id_offset=off, flags=flags),
                      "spectra": rt.trace_spectra(n, seed=seed, ray_id_offset=off, flags=flags, n_radial_bins=200)[1]}
+            # f64: 1e-7 (summation order, the gas stage's conditioning).  FIXED64 rounds every weight to its quantum: 0.29 quanta rms
+            # per ray, so the sum of N rays is within 4 sigma = 1.2 sqrt(N) quanta of the exact one - 1e-7 of it in all but the
+            # marginal setups (a few dozen passed rays a few thousand quanta each: case 8051, 1.2e-5)
+            tol = 1e-7
+            if mode == "fixed64" and flux > 0:
+                tol = max(tol, 1.2 * np.sqrt(max(want["N_PASSED"], 1)) * rt.fixed_quanta()["weight"] / flux)
             for door, s in doors.items():
                 for k, v in want.items():
                     assert s[k] == v, (mode, door, k, s[k], v)
                 assert s["N_RAYS"] == n
                 if flux > 0:
-                    assert abs(s["SUM_WEIGHTS"] / flux - 1.0) < 1e-7, (mode, door, s["SUM_WEIGHTS"], flux)
+                    assert abs(s["SUM_WEIGHTS"] / flux - 1.0) < tol, (mode, door, s["SUM_WEIGHTS"], flux, tol)
             if gas:
                 m = full.setup.m_axion
                 per, shared = rt.trace_mass_scan([0.5 * m + 1e-4, m, 1.7 * m + 1e-4], n, seed=seed, ray_id_offset=off, flags=flags)
                 assert per["N_PASSED"][1] == want["N_PASSED"] and shared["N_RAYS"] == n
                 if flux > 0:
-                    assert abs(per["SUM_WEIGHTS"][1] / flux - 1.0) < 1e-7, (mode, "mass scan")
+                    assert abs(per["SUM_WEIGHTS"][1] / flux - 1.0) < tol, (mode, "mass scan", per["SUM_WEIGHTS"][1], flux, tol)
             else:
                 a0 = full.setup.telescope_turned_y_deg
                 per, shared = rt.trace_angular_scan([a0, a0 + 0.02], n, seed=seed, ray_id_offset=off, flags=flags)
                 assert per["N_PASSED"][0] == want["N_PASSED"] and per["N_HIT_NICKEL"][0] == want["N_HIT_NICKEL"] and shared["N_RAYS"] == n, (mode, "angular scan")
                 if flux > 0:
-                    assert abs(per["SUM_WEIGHTS"][0] / flux - 1.0) < 1e-7, (mode, "angular scan")
+                    assert abs(per["SUM_WEIGHTS"][0] / flux - 1.0) < tol, (mode, "angular scan", per["SUM_WEIGHTS"][0], flux, tol)
+            return per
+
+        per = doors_of("f64")
+        # FIXED64 says when its quantum does not resolve the weights - and what to do about it ("a smaller headroom or
+        # SART_ACCUM_F64").  Cases 5830, 6658, 7722 of the extended campaign: the X-ray test source at an energy where the window
+        # passes 8e-12 / 4e-10 while the strongback - which the weight bound has to allow for, and which none of the 30 000 rays
+        # meets - passes orders of magnitude more: weights 1e-9 ... 1e-11 of the bound.  The advice is followed: the smallest headroom
+        # (47 fractional bits); where even that does not resolve them (5830) the f64 doors above are the result
+        for headroom in (0, 16, None):
+            if headroom is None:
+                label += " [fixed64: unresolvable, f64 only]"
+                break
+            try:
+                doors_of("fixed64", headroom)
+                if headroom:
+                    label += " [fixed64: headroom %d]" % headroom
+                break
+            except L.SartError as e:
+                if not (e.code == L.SART_ERR_ACCUMULATOR and "quanta per passed ray" in str(e)):
+                    raise
+                rt.set_accumulation_mode("f64")   # (takes the reported status with it)
         rt.set_accumulation_mode("f64")      # (the integer mode rounds every weight to its quantum: not a pixel-for-pixel comparison)
         # a random image window and binning (prepareHeatmap with any nx x ny over any rectangle, :818-842): the histogram of the
         # library against the same arithmetic on its own records - floor((x - x_min) * (1 / ((x_max - x_min) / nx))) - pixel for
