@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Acceptance test of a change of the random stream: the image and counters of BabyIAXO / XMM at 1e9 rays
+"""Acceptance test of a change of the random stream: the image and counters of a workload (default: BabyIAXO / XMM at 1e9 rays)
 from the library with the NEW stream against the library with the OLD one, and - as the calibration of the statistic - the old
 library against itself on another seed family.  Independent streams must agree within Monte-Carlo error:
 
   chi2 = sum over 8 x 8-pixel blocks with > 1e4 expected rays of (a - b)^2 / (var_a + var_b),  var = block sum x <w^2>/<w>
   (compound-Poisson variance of a sum of weights),  expected ndf +- 5 sqrt(2 ndf);  counters within 5 binomial sigma.
 
-  python tools/exp_stream.py OLD.so [NEW.so|default] [rays]   (each library in its own subprocess; images under gpurun_out/)"""
+  python tools/exp_stream.py OLD.so [NEW.so|default] [rays] [babyiaxo_xmm|cast_llnl|babyiaxo_xmm_gas]
+  (each library in its own subprocess; images under gpurun_out/)"""
 import json
 import os
 import subprocess
@@ -20,13 +21,19 @@ import sys, os, json
 sys.path.insert(0, %r)
 import numpy as np
 import solaraxionraytracing_amd as sa
-tag, seed, n, out = sys.argv[1], int(sys.argv[2]), int(float(sys.argv[3])), sys.argv[4]
-full = sa.initFullSetup()
+from solaraxionraytracing_amd import _lib as L
+tag, seed, n, out, wl = sys.argv[1], int(sys.argv[2]), int(float(sys.argv[3])), sys.argv[4], sys.argv[5]
+full = {"babyiaxo_xmm": lambda: sa.initFullSetup(),
+        "cast_llnl": lambda: sa.initFullSetup(L.ES_CAST, L.DK_INGRID2018, L.SK_VACUUM, L.TK_LLNL),
+        "babyiaxo_xmm_gas": lambda: sa.initFullSetup(stage=L.SK_GAS)}[wl]()
 with sa.RayTracer(full) as rt:
     img, s = rt.trace_histogram(n, seed=seed)
 np.savez(out, img=img, keys=np.array(sorted(s)), vals=np.array([s[k] for k in sorted(s)]))
 print(tag, "seed", seed, "passed", int(s["N_PASSED"]), "flux %%.9e" %% s["SUM_WEIGHTS"], flush=True)
 ''' % ROOT
+
+
+WORKLOAD = "babyiaxo_xmm"
 
 
 def run(lib, tag, seed, n):
@@ -35,7 +42,7 @@ def run(lib, tag, seed, n):
         env["SART_LIBSART"] = os.path.abspath(lib)
     out = os.path.join(ROOT, "gpurun_out", "stream_%s_%d.npz" % (tag, seed))
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    subprocess.run([sys.executable, "-c", CHILD, tag, str(seed), str(n), out], env=env, check=True)
+    subprocess.run([sys.executable, "-c", CHILD, tag, str(seed), str(n), out, WORKLOAD], env=env, check=True)
     d = np.load(out)
     return d["img"], dict(zip([str(k) for k in d["keys"]], d["vals"]))
 
@@ -65,11 +72,13 @@ def main():
     old = sys.argv[1]
     new = sys.argv[2] if len(sys.argv) > 2 else "default"
     n = int(float(sys.argv[3])) if len(sys.argv) > 3 else 1_000_000_000
+    global WORKLOAD
+    WORKLOAD = sys.argv[4] if len(sys.argv) > 4 else "babyiaxo_xmm"
     a, sa_ = run(old, "old", 299792458, n)
     c, sc = run(old, "old", 12345, n)
     b, sb = run(new, "new", 299792458, n)
     d, sd = run(new, "new", 12345, n)
-    out = {"rays": n, "old": old, "new": new, "results": [
+    out = {"rays": n, "workload": WORKLOAD, "old": old, "new": new, "results": [
         compare("calibration: OLD stream, seed 299792458 vs seed 12345", a, sa_, c, sc, n),
         compare("OLD stream vs NEW stream, seed 299792458", a, sa_, b, sb, n),
         compare("OLD stream vs NEW stream, seed 12345", c, sc, d, sd, n),
